@@ -1,0 +1,113 @@
+"""ctypes binding of libcolosseum_hip.so (the C ABI in include/colosseum_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, every
+compute entry point raises.  (The CPU restatement under oracle/ is test
+infrastructure and is never imported from this package.)
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libcolosseum_hip.so")
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+
+CRL_STEP_AUTO_RESET = 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    """Raised when libcolosseum_hip.so is missing, cannot be loaded, or a call fails."""
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 with hipcc into colosseumrl_amd/libcolosseum_hip.so (in-tree)."""
+    args = ["make", "-C", CSRC_DIR, "-j4"]
+    if force:
+        args.append("-B")
+    proc = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout)
+    if proc.returncode != 0:
+        raise NativeError("building libcolosseum_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+class TronStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("episode", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
+
+
+class TTTStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
+
+
+class BlokusStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "len_sum", "score_sum", "tests")]
+
+
+_VP, _I, _I64, _U32, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/colosseum_hip.h one to one
+PROTOTYPES = {
+    "crl_last_error": (C.c_char_p, []),
+    "crl_version": (_I, []),
+    "crl_device_count": (_I, []),
+    "crl_destroy": (None, [_VP]),
+    "crl_philox4x32": (_I, [_VP, _U32, _U32, _VP, _I64, _VP]),
+    "crl_tron_create": (_I, [_I, _I, _VP, _VP, C.POINTER(_VP)]),
+    "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "crl_tron_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
+    "crl_tron_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, TronStats, _VP]),
+    "crl_tron_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),
+    "crl_ttt_lines": (_I, [_VP, _VP, _I]),
+    "crl_ttt_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),
+    "crl_ttt_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
+    "crl_ttt_valid": (_I, [_VP, _I64, _VP, _VP, _VP]),
+    "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
+    "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises NativeError when it is not there."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError(
+                    "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+            try:
+                handle = C.CDLL(LIB_PATH)
+            except OSError as e:  # pragma: no cover
+                raise NativeError("cannot load %s: %s" % (LIB_PATH, e))
+            for name, (res, args) in PROTOTYPES.items():
+                try:
+                    fn = getattr(handle, name)
+                except AttributeError:
+                    raise NativeError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().crl_last_error()
+        raise NativeError("%s failed (code %d): %s" % (what or "native call", rc, msg.decode() if msg else "?"))
+
+
+def require_gpu():
+    """Fail loudly unless torch sees a ROCm device AND the HIP library loads."""
+    import torch
+
+    handle = lib()
+    if not torch.cuda.is_available():
+        raise NativeError("no MI355X/ROCm device visible to torch; colosseumrl_amd has no CPU path")
+    return handle

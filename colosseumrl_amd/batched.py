@@ -1,0 +1,239 @@
+"""Batched (vectorised) environment steppers: B independent games resident in HBM.
+
+This is the new surface the reference does not have (it steps one Python state
+per call): ``reset / step / rollout / observe`` over struct-of-arrays state held
+in torch-ROCm tensors and advanced by the HIP kernels behind the C ABI
+(include/colosseum_hip.h).  The single-state ``BaseEnvironment`` classes in
+``colosseumrl_amd.envs`` are thin B=1 clients of these steppers.
+
+No CPU path exists here: constructing a stepper without a visible MI355X raises.
+"""
+from typing import Optional, Sequence
+
+import ctypes as C
+
+import torch
+
+from . import _native
+from ._native import CRL_STEP_AUTO_RESET, TronStats, TTTStats, check
+from .envs.tron import layout as tron_layout
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _want(t: torch.Tensor, dtype, shape, device, name):
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != device:
+        raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s on %s)"
+                         % (name, dtype, tuple(shape), device, t.dtype, tuple(t.shape), t.device))
+    return t
+
+
+class _Ctx:
+    """Owns one crl_ctx handle."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _native.lib().crl_destroy(self.handle)
+                self.handle = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class TronBatch:
+    """B games of N x N Tron with P players (reference: envs/tron/TronGridEnvironment.py).
+
+    State tensors (device):
+      board  int8 [B, N*N]; heads int16 [P, B]; dirs int8 [P, B]; deaths int8 [P, B]
+    """
+
+    def __init__(self, board_size: int = 19, num_players: int = 4, batch: int = 1, device="cuda",
+                 ring_offset: int = 1, spawn_offset: int = 2,
+                 start: Optional[Sequence[Sequence[int]]] = None, first_env_id: int = 0):
+        lib = _native.require_gpu()
+        self.N, self.P, self.B = int(board_size), int(num_players), int(batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.NativeError("TronBatch needs a ROCm device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if start is None:
+            start = tron_layout.start_positions(self.N, self.P, ring_offset, [spawn_offset] * self.P)
+        self.start_heads = [int(h) for h in start[0]]
+        self.start_dirs = [int(d) for d in start[1]]
+        sh = (C.c_int16 * self.P)(*self.start_heads)
+        sd = (C.c_int8 * self.P)(*self.start_dirs)
+        handle = C.c_void_p()
+        check(lib.crl_tron_create(self.N, self.P, sh, sd, C.byref(handle)), "crl_tron_create")
+        self._ctx = _Ctx(handle)
+        self._lib = lib
+        self.first_env_id = int(first_env_id)
+        dev, B, P, NN = self.device, self.B, self.P, self.N * self.N
+        with torch.cuda.device(dev):
+            self.board = torch.zeros((B, NN), dtype=torch.int8, device=dev)
+            self.heads = torch.zeros((P, B), dtype=torch.int16, device=dev)
+            self.dirs = torch.zeros((P, B), dtype=torch.int8, device=dev)
+            self.deaths = torch.zeros((P, B), dtype=torch.int8, device=dev)
+            self.rewards = torch.zeros((P, B), dtype=torch.int8, device=dev)
+            self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            # rollout bookkeeping
+            self.episode = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tstep = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.n_episodes = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.win_count = torch.zeros((P, B), dtype=torch.int32, device=dev)
+            self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.ret_sum = torch.zeros((P, B), dtype=torch.int32, device=dev)
+            self.last_winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.last_len = torch.zeros((B,), dtype=torch.int16, device=dev)
+        self.reset()
+
+    # -- new_state for all (or masked) games
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        if mask is not None:
+            _want(mask, torch.uint8, (self.B,), self.device, "mask")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_reset(self._ctx.handle, self.B, _ptr(mask), _ptr(self.board), _ptr(self.heads),
+                                           _ptr(self.dirs), _ptr(self.deaths), _stream()), "crl_tron_reset")
+
+    def reset_stats(self):
+        for t in (self.episode, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.ret_sum,
+                  self.last_winners, self.last_len):
+            t.zero_()
+
+    # -- next_state for all games; actions int8 [P, B] in {0, +1, -1}
+    def step(self, actions: torch.Tensor, auto_reset: bool = False):
+        _want(actions, torch.int8, (self.P, self.B), self.device, "actions")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_step(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.heads), _ptr(self.dirs),
+                                          _ptr(self.deaths), _ptr(actions), _ptr(self.rewards), _ptr(self.terminal),
+                                          _ptr(self.winners), CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()),
+                  "crl_tron_step")
+        return self.rewards, self.terminal, self.winners
+
+    def _stats(self):
+        return TronStats(*[t.data_ptr() for t in (self.episode, self.tstep, self.n_episodes, self.win_count,
+                                                   self.len_sum, self.ret_sum, self.last_winners, self.last_len)])
+
+    # -- T fused random-agent steps with auto-reset
+    def rollout(self, steps: int, seed: int = 0):
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
+                                             _ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths),
+                                             self._stats(), _stream()), "crl_tron_rollout")
+
+    # -- state_to_observation for all games; player int8 [B]
+    def observe(self, player: torch.Tensor):
+        _want(player, torch.int8, (self.B,), self.device, "player")
+        ob = torch.empty_like(self.board)
+        oh = torch.empty_like(self.heads)
+        od = torch.empty_like(self.dirs)
+        ok = torch.empty_like(self.deaths)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_observe(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.heads), _ptr(self.dirs),
+                                             _ptr(self.deaths), _ptr(player), _ptr(ob), _ptr(oh), _ptr(od), _ptr(ok),
+                                             _stream()), "crl_tron_observe")
+        return {"board": ob.view(self.B, self.N, self.N), "heads": oh, "directions": od, "deaths": ok}
+
+    def results(self):
+        """Per-game episode results packed for the end-of-rollout gather: int32 [B, 3+2P]."""
+        cols = [self.n_episodes, self.len_sum, self.last_winners.to(torch.int32)]
+        cols += [self.win_count[p] for p in range(self.P)] + [self.ret_sum[p] for p in range(self.P)]
+        return torch.stack(cols, dim=1).contiguous()
+
+
+class TTTBatch:
+    """B games of n-player TicTacToe on a dims board, K in a row (reference: envs/tictactoe/*).
+
+    State tensors (device): occ int32 [P, B] bit masks; winner int8 [B] (-1 none); to_move int8 [B].
+    """
+
+    def __init__(self, dims: Sequence[int] = (3, 3), k: int = 3, num_players: int = 2, batch: int = 1,
+                 device="cuda", first_env_id: int = 0):
+        lib = _native.require_gpu()
+        self.dims = tuple(int(d) for d in dims)
+        d3 = (1,) * (3 - len(self.dims)) + self.dims
+        self.K, self.P, self.B = int(k), int(num_players), int(batch)
+        self.n_cells = d3[0] * d3[1] * d3[2]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.NativeError("TTTBatch needs a ROCm device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        handle = C.c_void_p()
+        check(lib.crl_ttt_create(d3[0], d3[1], d3[2], self.K, self.P, C.byref(handle)), "crl_ttt_create")
+        self._ctx = _Ctx(handle)
+        self._lib = lib
+        self.first_env_id = int(first_env_id)
+        dev, B, P = self.device, self.B, self.P
+        with torch.cuda.device(dev):
+            self.occ = torch.zeros((P, B), dtype=torch.int32, device=dev)
+            self.winner = torch.full((B,), -1, dtype=torch.int8, device=dev)
+            self.to_move = torch.zeros((B,), dtype=torch.int8, device=dev)
+            self.reward = torch.zeros((B,), dtype=torch.int8, device=dev)
+            self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.winners = torch.zeros((B,), dtype=torch.int8, device=dev)
+            self.episode = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tstep = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.n_episodes = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.win_count = torch.zeros((P, B), dtype=torch.int32, device=dev)
+            self.draw_count = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
+
+    def lines(self):
+        buf = (C.c_uint32 * 256)()
+        n = self._lib.crl_ttt_lines(self._ctx.handle, buf, 256)
+        return [int(buf[i]) for i in range(n)]
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        if mask is not None:
+            _want(mask, torch.uint8, (self.B,), self.device, "mask")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_reset(self._ctx.handle, self.B, _ptr(mask), _ptr(self.occ), _ptr(self.winner),
+                                          _ptr(self.to_move), _stream()), "crl_ttt_reset")
+
+    def step(self, action: torch.Tensor, auto_reset: bool = False):
+        _want(action, torch.int8, (self.B,), self.device, "action")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_step(self._ctx.handle, self.B, _ptr(self.occ), _ptr(self.winner), _ptr(self.to_move),
+                                         _ptr(action), _ptr(self.reward), _ptr(self.terminal), _ptr(self.winners),
+                                         CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()), "crl_ttt_step")
+        return self.reward, self.terminal, self.winners
+
+    def valid_mask(self):
+        out = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_valid(self._ctx.handle, self.B, _ptr(self.occ), _ptr(out), _stream()), "crl_ttt_valid")
+        return out
+
+    def board(self, player: Optional[torch.Tensor] = None, rel_mod: Optional[int] = None):
+        out = torch.empty((self.B, self.n_cells), dtype=torch.int8, device=self.device)
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_board(self._ctx.handle, self.B, _ptr(self.occ), _ptr(player),
+                                          int(rel_mod if rel_mod else self.P), _ptr(out), _stream()), "crl_ttt_board")
+        return out
+
+    def _stats(self):
+        return TTTStats(*[t.data_ptr() for t in (self.episode, self.tstep, self.n_episodes, self.win_count,
+                                                  self.draw_count, self.len_sum)])
+
+    def rollout(self, steps: int, seed: int = 0):
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
+                                            _ptr(self.occ), _ptr(self.winner), _ptr(self.to_move), self._stats(),
+                                            _stream()), "crl_ttt_rollout")
+
+    def results(self):
+        cols = [self.n_episodes, self.len_sum, self.draw_count] + [self.win_count[p] for p in range(self.P)]
+        return torch.stack(cols, dim=1).contiguous()

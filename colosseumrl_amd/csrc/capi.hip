@@ -1,0 +1,64 @@
+// capi.hip -- context lifetime, error reporting and the RNG test entry point of libcolosseum_hip.so.
+#include "crl_common.hpp"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void crl_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void crl_blokus_free(void *tables);   // blokus.hip
+
+namespace {
+__global__ void __launch_bounds__(256)
+philox_kernel(const uint32_t *__restrict__ ctr, const uint32_t k0, const uint32_t k1, uint32_t *__restrict__ out, const int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 c = reinterpret_cast<const uint4 *>(ctr)[i];
+    const philox_out r = philox4x32_10(c.x, c.y, c.z, c.w, k0, k1);
+    reinterpret_cast<uint4 *>(out)[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+}
+} // namespace
+
+extern "C" {
+
+const char *crl_last_error(void) { return g_err; }
+
+int crl_version(void) { return 100; }
+
+int crl_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        crl_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return CRL_ENODEV;
+    }
+    return n;
+}
+
+void crl_destroy(crl_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->ttt_lines_dev) (void)hipFree(ctx->ttt_lines_dev);
+    if (ctx->blokus) crl_blokus_free(ctx->blokus);
+    delete ctx;
+}
+
+int crl_philox4x32(const uint32_t *ctr, uint32_t key0, uint32_t key1, uint32_t *out, int64_t n, void *stream)
+{
+    CRL_REQUIRE(ctr && out, "crl_philox4x32: NULL pointer");
+    CRL_REQUIRE(n > 0, "crl_philox4x32: n must be positive");
+    CRL_REQUIRE(((((uintptr_t)ctr) | ((uintptr_t)out)) & 15) == 0, "crl_philox4x32: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctr, key0, key1, out, n);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+} // extern "C"

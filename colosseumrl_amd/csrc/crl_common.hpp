@@ -1,0 +1,74 @@
+// crl_common.hpp -- shared pieces of libcolosseum_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/colosseum_hip.h"
+
+#define CRL_WAVE 64
+
+enum crl_game { CRL_GAME_TRON = 1, CRL_GAME_TTT = 2, CRL_GAME_BLOKUS = 3 };
+
+struct crl_tron_cfg {
+    int32_t N, P;
+    int16_t start_heads[CRL_TRON_MAX_P];
+    int8_t start_dirs[CRL_TRON_MAX_P];
+};
+
+struct crl_ttt_cfg {
+    int32_t D0, D1, D2, K, P, n_cells, n_lines;
+    uint32_t full;
+};
+
+struct crl_ctx {
+    int game;
+    crl_tron_cfg tron;
+    crl_ttt_cfg ttt;
+    uint32_t ttt_lines_host[CRL_TTT_MAX_LINES];
+    uint32_t *ttt_lines_dev;   // DEVICE copy of the win-line table
+    void *blokus;              // blokus tables (blokus.hip)
+};
+
+void crl_set_error(const char *fmt, ...);
+
+#define CRL_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) { crl_set_error(__VA_ARGS__); return CRL_EINVAL; } \
+    } while (0)
+
+#define CRL_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            crl_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return CRL_EHIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+#define CRL_LAUNCH_CHECK() CRL_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- Philox-4x32-10
+// Salmon et al., SC'11 (Random123 constants). 10 rounds, 2 x (mul_lo, mul_hi) per round.
+struct philox_out { uint32_t w[4]; };
+
+__device__ __forceinline__ philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    philox_out o;
+    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+#define CRL_TAG_TRON   0x54520000u
+#define CRL_TAG_TTT    0x54540000u
+#define CRL_TAG_BLOKUS 0x424c0000u

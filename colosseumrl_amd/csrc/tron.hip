@@ -1,0 +1,506 @@
+// tron.hip -- batched Tron stepper for gfx950 (MI355X).  Hand-written HIP, wave64.
+//
+// Restates, for B independent games at once:
+//   colosseumrl/envs/tron/CyTronGrid.pyx:3-62      next_state_inplace
+//   colosseumrl/envs/tron/TronGridEnvironment.py:228-263  new_state
+//   colosseumrl/envs/tron/TronGridEnvironment.py:309-323  rewards / terminal / winners
+//   colosseumrl/envs/tron/CyTronGrid.pyx:65-71 + TronGridEnvironment.py:385-405  observation
+//
+// Mapping: one lane per game (the <=P-player loop of a game is inherently serial: the result of
+// player i depends on what players j<i did in the same step); per-player state is
+// [P][B] struct-of-arrays so a wave's 64 lanes load 64 consecutive elements; the board is int8
+// [B][N*N], probed with P byte loads per step that are all issued up front (targets depend only on
+// the pre-step heads) and patched in registers for same-step interactions, so a step costs one
+// round of loads and one round of stores instead of P dependent round trips.
+// Resets are wave-cooperative: the wave ballots its terminal lanes and all 64 lanes clear each
+// such board with 16-byte stores.
+#include "crl_common.hpp"
+
+namespace {
+
+// ---- per-game step, everything in registers -------------------------------------------------
+template <int P>
+struct TronRegs {
+    int h[P];   // heads
+    int d[P];   // dirs
+    int k[P];   // deaths
+};
+
+template <int P>
+__device__ __forceinline__ void tron_step_core(const int N, int8_t *__restrict__ bd, const bool valid,
+                                               TronRegs<P> &s, const int (&act)[P],
+                                               int (&rew)[P], int &term, int &wmask)
+{
+    int tgt[P], val[P], ndir[P];
+    bool oob[P], moved[P];
+    // phase 1: every live player's target cell, probes issued together (CyTronGrid.pyx:21-41)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int x0 = s.h[i] % N, y0 = s.h[i] / N;
+        const int dir = (s.d[i] + act[i] + 4) & 3;
+        const int x = x0 + (dir == 1) - (dir == 3);
+        const int y = y0 + (dir == 2) - (dir == 0);
+        ndir[i] = dir;
+        oob[i] = (x < 0) | (x >= N) | (y < 0) | (y >= N);
+        tgt[i] = y * N + x;
+        moved[i] = false;
+        val[i] = 0;
+        if (valid && s.k[i] == 0 && !oob[i]) val[i] = bd[tgt[i]];
+    }
+    // phase 2: the reference's sequential resolution, on registers (CyTronGrid.pyx:15-62)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (s.k[i] > 0) continue;                       // :16 (may have been killed head-on by j < i)
+        int v = val[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
+            if (moved[j] && tgt[j] == tgt[i]) v = j + 1;
+        s.d[i] = ndir[i];                               // :44 direction is committed even if the move dies
+        if (oob[i]) {
+            s.k[i] = i + 1;                             // :47-48
+        } else if (v > 0) {
+            s.k[i] = v;                                 // :51-53
+#pragma unroll
+            for (int q = 0; q < P; ++q)                 // :56-57 owner's head is this very cell -> owner dies too
+                if (q == v - 1 && s.h[q] == tgt[i]) s.k[q] = i + 1;
+        } else {
+            moved[i] = true;                            // :60-62
+            s.h[i] = tgt[i];
+        }
+    }
+    // phase 3: trail writes
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (valid && moved[i]) bd[tgt[i]] = (int8_t)(i + 1);
+    // TronGridEnvironment.py:309-321
+    int alive = 0;
+    wmask = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        alive += (s.k[i] == 0);
+        wmask |= (s.k[i] == 0) << i;
+    }
+    term = alive <= 1;
+    if (!term) wmask = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) rew[i] = (s.k[i] > 0) ? -1 : (term ? 10 : 1);
+}
+
+// 16 bytes of a freshly reset board starting at byte offset `off` (heads stamped)
+template <int P>
+__device__ __forceinline__ uint4 tron_fresh_chunk16(const crl_tron_cfg &cfg, const int off)
+{
+    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int r = (int)cfg.start_heads[p] - off;
+        if (r >= 0 && r < 16) {
+            const uint32_t byte = (uint32_t)(p + 1) << ((r & 3) * 8);
+            const int w = r >> 2;
+            v0 |= (w == 0) ? byte : 0u;
+            v1 |= (w == 1) ? byte : 0u;
+            v2 |= (w == 2) ? byte : 0u;
+            v3 |= (w == 3) ? byte : 0u;
+        }
+    }
+    return make_uint4(v0, v1, v2, v3);
+}
+
+// all 64 lanes of the wave rewrite one board (wave-uniform pointer) to the start layout
+template <int P>
+__device__ __forceinline__ void tron_wave_reset_board(const crl_tron_cfg &cfg, int8_t *__restrict__ bd,
+                                                      const int NN, const int lane)
+{
+    if ((NN & 15) == 0) {
+        for (int off = lane * 16; off < NN; off += CRL_WAVE * 16)
+            *reinterpret_cast<uint4 *>(bd + off) = tron_fresh_chunk16<P>(cfg, off);
+    } else {
+        for (int c = lane; c < NN; c += CRL_WAVE) {
+            int8_t v = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v = (cfg.start_heads[p] == c) ? (int8_t)(p + 1) : v;
+            bd[c] = v;
+        }
+    }
+}
+
+// ---- kernels ---------------------------------------------------------------------------------
+
+// board part of new_state: one thread per 16-byte chunk (or per byte when N*N % 16 != 0)
+template <int P, bool WIDE>
+__global__ void __launch_bounds__(256)
+tron_reset_board_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t *__restrict__ mask,
+                        int8_t *__restrict__ board)
+{
+    const int NN = cfg.N * cfg.N;
+    const int per_env = WIDE ? NN / 16 : NN;
+    const int64_t total = B * (int64_t)per_env;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_env;
+        const int c = (int)(i - b * per_env);
+        if (mask && !mask[b]) continue;
+        if (WIDE) {
+            *reinterpret_cast<uint4 *>(board + b * NN + c * 16) = tron_fresh_chunk16<P>(cfg, c * 16);
+        } else {
+            int8_t v = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v = (cfg.start_heads[p] == c) ? (int8_t)(p + 1) : v;
+            board[b * NN + c] = v;
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_reset_players_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t *__restrict__ mask,
+                          int16_t *__restrict__ heads, int8_t *__restrict__ dirs, int8_t *__restrict__ deaths)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (mask && !mask[b]) return;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        heads[p * B + b] = cfg.start_heads[p];
+        dirs[p * B + b] = cfg.start_dirs[p];
+        deaths[p * B + b] = 0;
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_step_kernel(const crl_tron_cfg cfg, const int64_t B,
+                 int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                 int8_t *__restrict__ deaths, const int8_t *__restrict__ actions,
+                 int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                 const uint32_t flags)
+{
+    const int N = cfg.N, NN = N * N;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : 0;
+    TronRegs<P> s;
+    int act[P], rew[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s.h[p] = valid ? heads[p * B + bb] : 0;
+        s.d[p] = valid ? dirs[p * B + bb] : 0;
+        s.k[p] = valid ? deaths[p * B + bb] : 1;
+        act[p] = valid ? actions[p * B + bb] : 0;
+    }
+    int term, wm;
+    int8_t *bd = board + bb * NN;
+    tron_step_core<P>(N, bd, valid, s, act, rew, term, wm);
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) rewards[p * B + b] = (int8_t)rew[p];
+        terminal[b] = (uint8_t)term;
+        winners[b] = (uint8_t)wm;
+    }
+    const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
+    if (flags & CRL_STEP_AUTO_RESET) {
+        unsigned long long m = __ballot(do_reset);
+        const int64_t env0 = b - lane;   // wave-uniform
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            tron_wave_reset_board<P>(cfg, board + (env0 + src) * NN, NN, lane);
+        }
+        if (do_reset) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) { s.h[p] = cfg.start_heads[p]; s.d[p] = cfg.start_dirs[p]; s.k[p] = 0; }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            heads[p * B + b] = (int16_t)s.h[p];
+            dirs[p * B + b] = (int8_t)s.d[p];
+            deaths[p * B + b] = (int8_t)s.k[p];
+        }
+    }
+}
+
+// T fused steps, uniform random agent, auto-reset.  State lives in registers across the T steps;
+// boards stay in global memory (L2-resident at the benchmark sizes).
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_rollout_kernel(const crl_tron_cfg cfg, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                    const uint64_t first_env_id, const int T,
+                    int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                    int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    const int N = cfg.N, NN = N * N;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : 0;
+    const int64_t env0 = b - lane;
+    TronRegs<P> s;
+    int act[P], rew[P], ret[P];
+    uint32_t wins[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s.h[p] = valid ? heads[p * B + bb] : 0;
+        s.d[p] = valid ? dirs[p * B + bb] : 0;
+        s.k[p] = valid ? deaths[p * B + bb] : 1;
+        ret[p] = 0;
+        wins[p] = 0;
+    }
+    uint32_t ep = valid ? st.episode[bb] : 0, ts = valid ? st.tstep[bb] : 0;
+    uint32_t n_ep = 0, len_sum = 0;
+    int last_w = -1, last_len = 0;
+    const uint32_t g = (uint32_t)(first_env_id + (uint64_t)bb);
+    int8_t *bd = board + bb * NN;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int q = 0; q < (P + 3) / 4; ++q) {
+            const philox_out r = philox4x32_10(g, ep, ts, CRL_TAG_TRON | (uint32_t)q, seed_lo, seed_hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q * 4 + j < P) {
+                    const uint32_t a3 = __umulhi(r.w[j], 3u);
+                    act[q * 4 + j] = (a3 == 0) ? 0 : ((a3 == 1) ? 1 : -1);
+                }
+        }
+        int term, wm;
+        tron_step_core<P>(N, bd, valid, s, act, rew, term, wm);
+        ts += 1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) ret[p] += rew[p];
+        const bool fin = valid && term;
+        unsigned long long m = __ballot(fin);
+        if (m) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                tron_wave_reset_board<P>(cfg, board + (env0 + src) * NN, NN, lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (fin) {
+                n_ep += 1;
+                len_sum += ts;
+                last_len = (int)ts;
+                last_w = wm;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    wins[p] += (wm >> p) & 1;
+                    s.h[p] = cfg.start_heads[p];
+                    s.d[p] = cfg.start_dirs[p];
+                    s.k[p] = 0;
+                }
+                ep += 1;
+                ts = 0;
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            heads[p * B + b] = (int16_t)s.h[p];
+            dirs[p * B + b] = (int8_t)s.d[p];
+            deaths[p * B + b] = (int8_t)s.k[p];
+            st.ret_sum[p * B + b] += ret[p];
+            st.win_count[p * B + b] += wins[p];
+        }
+        st.episode[b] = ep;
+        st.tstep[b] = ts;
+        st.n_episodes[b] += n_ep;
+        st.len_sum[b] += len_sum;
+        if (last_w >= 0) {
+            st.last_winners[b] = (uint8_t)last_w;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+    }
+}
+
+// observation: board relabel is a pure streaming pass, 16 cells per thread
+__global__ void __launch_bounds__(256)
+tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8_t *__restrict__ board,
+                          const int8_t *__restrict__ player, int8_t *__restrict__ obs)
+{
+    const int64_t total = B * (int64_t)NN;
+    const bool wide = (NN & 15) == 0;
+    const int64_t n_items = wide ? total / 16 : total;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (wide) {
+            const int64_t off = i * 16;
+            const int pl = player[off / NN] + 1;
+            const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int s8 = 0; s8 < 32; s8 += 8) {
+                    const int c = (int)((w[q] >> s8) & 0xffu);
+                    const int n = c > 0 ? ((c - pl + P) % P) + 1 : c;     // CyTronGrid.pyx:70-71
+                    r |= (uint32_t)(n & 0xff) << s8;
+                }
+                o[q] = r;
+            }
+            *reinterpret_cast<uint4 *>(obs + off) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            const int pl = player[i / NN] + 1;
+            const int c = board[i];
+            obs[i] = (int8_t)(c > 0 ? ((c - pl + P) % P) + 1 : c);
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, const int8_t *__restrict__ dirs,
+                            const int8_t *__restrict__ deaths, const int8_t *__restrict__ player,
+                            int16_t *__restrict__ oh, int8_t *__restrict__ od, int8_t *__restrict__ ok)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int pl = player[b];
+    int h[P], d[P], k[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { h[p] = heads[p * B + b]; d[p] = dirs[p * B + b]; k[p] = deaths[p * B + b]; }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        int hh = 0, dd = 0, kk = 0;
+        const int src = (i + pl) % P;                   // TronGridEnvironment.py:392-396
+#pragma unroll
+        for (int q = 0; q < P; ++q) { hh = (q == src) ? h[q] : hh; dd = (q == src) ? d[q] : dd; kk = (q == src) ? k[q] : kk; }
+        oh[i * B + b] = (int16_t)hh;
+        od[i * B + b] = (int8_t)dd;
+        ok[i * B + b] = (int8_t)kk;
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+} // namespace
+
+#define TRON_DISPATCH_P(P_, CALL)          \
+    switch (P_) {                          \
+        case 1: { constexpr int PP = 1; CALL; } break; \
+        case 2: { constexpr int PP = 2; CALL; } break; \
+        case 3: { constexpr int PP = 3; CALL; } break; \
+        case 4: { constexpr int PP = 4; CALL; } break; \
+        case 5: { constexpr int PP = 5; CALL; } break; \
+        case 6: { constexpr int PP = 6; CALL; } break; \
+        case 7: { constexpr int PP = 7; CALL; } break; \
+        case 8: { constexpr int PP = 8; CALL; } break; \
+        default: crl_set_error("tron: P=%d out of range 1..8", P_); return CRL_EINVAL; \
+    }
+
+extern "C" {
+
+int crl_tron_create(int N, int P, const int16_t *start_heads, const int8_t *start_dirs, crl_ctx **out)
+{
+    CRL_REQUIRE(out != nullptr, "crl_tron_create: out is NULL");
+    CRL_REQUIRE(N >= 2 && N <= 181, "crl_tron_create: N=%d out of range 2..181 (int16 heads)", N);
+    CRL_REQUIRE(P >= 1 && P <= CRL_TRON_MAX_P, "crl_tron_create: P=%d out of range 1..%d", P, CRL_TRON_MAX_P);
+    CRL_REQUIRE(start_heads && start_dirs, "crl_tron_create: start arrays are NULL");
+    for (int p = 0; p < P; ++p) {
+        CRL_REQUIRE(start_heads[p] >= 0 && start_heads[p] < N * N, "crl_tron_create: start_heads[%d]=%d outside the board", p, start_heads[p]);
+        CRL_REQUIRE(start_dirs[p] >= 0 && start_dirs[p] < 4, "crl_tron_create: start_dirs[%d]=%d not in 0..3", p, start_dirs[p]);
+        for (int q = 0; q < p; ++q)
+            CRL_REQUIRE(start_heads[p] != start_heads[q], "crl_tron_create: players %d and %d share a start cell", q, p);
+    }
+    crl_ctx *c = new crl_ctx();
+    memset(c, 0, sizeof(*c));
+    c->game = CRL_GAME_TRON;
+    c->tron.N = N;
+    c->tron.P = P;
+    for (int p = 0; p < P; ++p) { c->tron.start_heads[p] = start_heads[p]; c->tron.start_dirs[p] = start_dirs[p]; }
+    for (int p = P; p < CRL_TRON_MAX_P; ++p) { c->tron.start_heads[p] = -1; c->tron.start_dirs[p] = 0; }
+    *out = c;
+    return CRL_OK;
+}
+
+#define TRON_CTX_CHECK(fn)                                                                  \
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TRON, fn ": ctx is not a tron context"); \
+    CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 31), fn ": B=%lld out of range", (long long)B)
+
+int crl_tron_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask,
+                   int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_reset");
+    CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_reset: NULL state pointer");
+    const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = (NN % 16 == 0) && (((uintptr_t)board & 15) == 0);
+    const int64_t items = B * (int64_t)(wide ? NN / 16 : NN);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 65536 * 4 ? 65536 * 4 : (items + 255) / 256);
+    TRON_DISPATCH_P(cfg.P, {
+        if (wide) hipLaunchKernelGGL((tron_reset_board_kernel<PP, true>), dim3(grid), dim3(256), 0, s, cfg, B, mask, board);
+        else hipLaunchKernelGGL((tron_reset_board_kernel<PP, false>), dim3(grid), dim3(256), 0, s, cfg, B, mask, board);
+        hipLaunchKernelGGL((tron_reset_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B, mask, heads, dirs, deaths);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_step(const crl_ctx *ctx, int64_t B,
+                  int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                  const int8_t *actions, int8_t *rewards, uint8_t *terminal, uint8_t *winners,
+                  uint32_t flags, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_step");
+    CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_step: NULL state pointer");
+    CRL_REQUIRE(actions && rewards && terminal && winners, "crl_tron_step: NULL action/output pointer");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_tron_step: unknown flags 0x%x", flags);
+    const crl_tron_cfg &cfg = ctx->tron;
+    CRL_REQUIRE(!(flags & CRL_STEP_AUTO_RESET) || ((cfg.N * cfg.N) % 16 != 0) || (((uintptr_t)board & 15) == 0),
+                "crl_tron_step: board must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B,
+                           board, heads, dirs, deaths, actions, rewards, terminal, winners, flags);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                     int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                     crl_tron_stats st, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_rollout");
+    CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_rollout: NULL state pointer");
+    CRL_REQUIRE(st.episode && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
+                st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
+    CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
+    const crl_tron_cfg &cfg = ctx->tron;
+    CRL_REQUIRE(((cfg.N * cfg.N) % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
+    if (T == 0) return CRL_OK;
+    hipStream_t s = (hipStream_t)stream;
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads,
+                     const int8_t *dirs, const int8_t *deaths, const int8_t *player,
+                     int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_observe");
+    CRL_REQUIRE(board && heads && dirs && deaths && player, "crl_tron_observe: NULL input pointer");
+    CRL_REQUIRE(obs_board && obs_heads && obs_dirs && obs_deaths, "crl_tron_observe: NULL output pointer");
+    const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe: boards must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
+    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
+    hipLaunchKernelGGL(tron_observe_board_kernel, dim3(grid), dim3(256), 0, s, NN, cfg.P, B, board, player, obs_board);
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_observe_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
+                           heads, dirs, deaths, player, obs_heads, obs_dirs, obs_deaths);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+} // extern "C"

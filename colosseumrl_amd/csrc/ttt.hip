@@ -1,0 +1,353 @@
+// ttt.hip -- batched n-player TicTacToe stepper for gfx950 (MI355X).  Hand-written HIP, wave64.
+//
+// Restates, for B independent games at once:
+//   colosseumrl/envs/tictactoe/tictactoe_2p_env.py:139-169  new_state
+//   colosseumrl/envs/tictactoe/tictactoe_2p_env.py:240-315  next_state   (3p/4p files: same logic,
+//   colosseumrl/envs/tictactoe/tictactoe_2p_env.py:317-348  valid_actions  other board shape / P)
+//   WINNING_SHAPES: 2p:12-17, 3p:12-17, 4p:19-38
+//
+// Layout: a board has <= 32 cells, so each player's marks are ONE uint32 per game: occ[P][B].
+// One lane per game; a wave reads 64 consecutive words per player (fully coalesced 256-B rows).
+// Win test: the reference correlates the mover's mask with each line pattern in 'valid' mode,
+// i.e. "some K-window along one of the 13 (3-D) / 4 (2-D) directions is fully the mover's".
+// With the mask in a register that is K-1 shift-ANDs per direction against a per-direction
+// start mask (windows that stay on the board).  Direction strides and start masks are
+// wave-uniform kernel arguments (SGPRs) -- no table traffic at all.
+#include "crl_common.hpp"
+
+namespace {
+
+struct ttt_dirs {
+    int32_t n_dirs, K, P, n_cells;
+    uint32_t full;
+    int32_t stride[13];
+    uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
+};
+
+__device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t m)
+{
+    uint32_t hit = 0;
+    for (int d = 0; d < dd.n_dirs; ++d) {          // wave-uniform loop, scalar operands
+        uint32_t run = m;
+        for (int s = 1; s < dd.K; ++s) run &= m >> (s * dd.stride[d]);
+        hit |= run & dd.start[d];
+    }
+    return hit != 0;
+}
+
+template <int P>
+__device__ __forceinline__ void ttt_step_core(const ttt_dirs &dd, uint32_t (&o)[P], int &winner, int &to_move,
+                                              const int action, int &reward, int &term, int &winners)
+{
+    const int pl = to_move;
+    uint32_t all = 0, mine = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) { all |= o[p]; mine = (p == pl) ? o[p] : mine; }
+    // tictactoe_2p_env.py:293: non-empty action, target cell empty, no sticky winner
+    const bool in_range = (action >= 0) & (action < dd.n_cells);
+    const uint32_t bit = in_range ? (1u << (action & 31)) : 0u;
+    const bool ok = in_range && !(all & bit) && winner < 0;
+    if (ok) {
+        mine |= bit;                                   // :295
+        all |= bit;
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];
+        if (ttt_has_line(dd, mine)) winner = pl;       // :296-300
+    }
+    reward = 0; term = 0; winners = -1;
+    if (winner >= 0) {                                 // :302-308
+        reward = (winner == pl) ? 1 : -1;
+        winners = winner;
+        term = 1;
+    }
+    if (all == dd.full) term = 1;                      // :310-311
+    to_move = (pl + 1 == P) ? 0 : pl + 1;              // :313
+}
+
+// index of the r-th (0-based) set bit of m (row-major np.where order, tictactoe_2p_env.py:345)
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int r)
+{
+    int pos = 0, c;
+    c = __popc(m & 0xffffu); if (r >= c) { r -= c; m >>= 16; pos += 16; }
+    c = __popc(m & 0xffu);   if (r >= c) { r -= c; m >>= 8;  pos += 8; }
+    c = __popc(m & 0xfu);    if (r >= c) { r -= c; m >>= 4;  pos += 4; }
+    c = __popc(m & 0x3u);    if (r >= c) { r -= c; m >>= 2;  pos += 2; }
+    c = (int)(m & 1u);       if (r >= c) { pos += 1; }
+    return pos;
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, int8_t *__restrict__ winner,
+                int8_t *__restrict__ to_move, const int8_t *__restrict__ action, int8_t *__restrict__ reward,
+                uint8_t *__restrict__ terminal, int8_t *__restrict__ winners, const uint32_t flags)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t o[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) o[p] = occ[p * B + b];
+    int w = winner[b], tm = to_move[b], r, t, ws;
+    ttt_step_core<P>(dd, o, w, tm, action[b], r, t, ws);
+    reward[b] = (int8_t)r;
+    terminal[b] = (uint8_t)t;
+    winners[b] = (int8_t)ws;
+    if (t && (flags & CRL_STEP_AUTO_RESET)) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = 0;
+        w = -1; tm = 0;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) occ[p * B + b] = o[p];
+    winner[b] = (int8_t)w;
+    to_move[b] = (int8_t)tm;
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                   const uint64_t first_env_id, const int T, uint32_t *__restrict__ occ,
+                   int8_t *__restrict__ winner, int8_t *__restrict__ to_move, const crl_ttt_stats st)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t o[P], wins[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { o[p] = occ[p * B + b]; wins[p] = 0; }
+    int w = winner[b], tm = to_move[b];
+    uint32_t ep = st.episode[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
+    const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
+    for (int t = 0; t < T; ++t) {
+        uint32_t all = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) all |= o[p];
+        const uint32_t empty = dd.full & ~all;
+        const int n_empty = __popc(empty);
+        const philox_out rnd = philox4x32_10(g, ep, ts, CRL_TAG_TTT, seed_lo, seed_hi);
+        const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(rnd.w[0], (uint32_t)n_empty)) : -1;
+        int r, term, ws;
+        ttt_step_core<P>(dd, o, w, tm, action, r, term, ws);
+        ts += 1;
+        if (term) {
+            n_ep += 1;
+            len_sum += ts;
+            draws += (ws < 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) { wins[p] += (ws == p); o[p] = 0; }
+            w = -1; tm = 0; ep += 1; ts = 0;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) { occ[p * B + b] = o[p]; st.win_count[p * B + b] += wins[p]; }
+    winner[b] = (int8_t)w;
+    to_move[b] = (int8_t)tm;
+    st.episode[b] = ep;
+    st.tstep[b] = ts;
+    st.n_episodes[b] += n_ep;
+    st.draw_count[b] += draws;
+    st.len_sum[b] += len_sum;
+}
+
+__global__ void __launch_bounds__(256)
+ttt_reset_kernel(const int P, const int64_t B, const uint8_t *__restrict__ mask, uint32_t *__restrict__ occ,
+                 int8_t *__restrict__ winner, int8_t *__restrict__ to_move)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (mask && !mask[b]) return;
+    for (int p = 0; p < P; ++p) occ[p * B + b] = 0;
+    winner[b] = -1;
+    to_move[b] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+ttt_valid_kernel(const int P, const uint32_t full, const int64_t B, const uint32_t *__restrict__ occ, uint32_t *__restrict__ valid)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t all = 0;
+    for (int p = 0; p < P; ++p) all |= occ[p * B + b];
+    valid[b] = full & ~all;
+}
+
+// one thread per output byte: coalesced int8 [B][cells] writes, occ words come from L1/L2
+__global__ void __launch_bounds__(256)
+ttt_board_kernel(const int P, const int n_cells, const int64_t B, const uint32_t *__restrict__ occ,
+                 const int8_t *__restrict__ player, const int rel_mod, int8_t *__restrict__ board)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_cells) return;
+    const int64_t b = i / n_cells;
+    const int c = (int)(i - b * n_cells);
+    int v = -1;
+    for (int p = 0; p < P; ++p) v = ((occ[p * B + b] >> c) & 1u) ? p : v;
+    if (player && v >= 0) {
+        // _relative_player_id (2p:26-27): (abs - current) % rel_mod with Python's non-negative modulo
+        int r = (v - (int)player[b]) % rel_mod;
+        v = r < 0 ? r + rel_mod : r;
+    }
+    board[i] = (int8_t)v;
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// host: enumerate directions / lines exactly like the oracle does, independently written
+int build_dirs(const crl_ttt_cfg &c, ttt_dirs &dd, uint32_t *lines, int &n_lines)
+{
+    memset(&dd, 0, sizeof(dd));
+    dd.K = c.K; dd.P = c.P; dd.n_cells = c.n_cells; dd.full = c.full;
+    n_lines = 0;
+    for (int di = 0; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj)
+            for (int dk = -1; dk <= 1; ++dk) {
+                if (di == 0 && dj < 0) continue;
+                if (di == 0 && dj == 0 && dk <= 0) continue;
+                const int stride = (di * c.D1 + dj) * c.D2 + dk;
+                uint32_t start = 0;
+                for (int i = 0; i < c.D0; ++i)
+                    for (int j = 0; j < c.D1; ++j)
+                        for (int k = 0; k < c.D2; ++k) {
+                            const int ei = i + di * (c.K - 1), ej = j + dj * (c.K - 1), ek = k + dk * (c.K - 1);
+                            if (ei < 0 || ei >= c.D0 || ej < 0 || ej >= c.D1 || ek < 0 || ek >= c.D2) continue;
+                            const int cell = (i * c.D1 + j) * c.D2 + k;
+                            start |= 1u << cell;
+                            uint32_t m = 0;
+                            for (int s = 0; s < c.K; ++s) m |= 1u << (cell + s * stride);
+                            if (n_lines >= CRL_TTT_MAX_LINES) return -1;
+                            lines[n_lines++] = m;
+                        }
+                if (start) {
+                    if (stride <= 0 || dd.n_dirs >= 13) return -2;
+                    dd.stride[dd.n_dirs] = stride;
+                    dd.start[dd.n_dirs] = start;
+                    dd.n_dirs++;
+                }
+            }
+    return 0;
+}
+
+ttt_dirs dirs_of(const crl_ctx *ctx)
+{
+    ttt_dirs dd;
+    uint32_t tmp[CRL_TTT_MAX_LINES];
+    int n;
+    build_dirs(ctx->ttt, dd, tmp, n);
+    return dd;
+}
+
+} // namespace
+
+#define TTT_DISPATCH_P(P_, CALL)           \
+    switch (P_) {                          \
+        case 1: { constexpr int PP = 1; CALL; } break; \
+        case 2: { constexpr int PP = 2; CALL; } break; \
+        case 3: { constexpr int PP = 3; CALL; } break; \
+        case 4: { constexpr int PP = 4; CALL; } break; \
+        case 5: { constexpr int PP = 5; CALL; } break; \
+        case 6: { constexpr int PP = 6; CALL; } break; \
+        case 7: { constexpr int PP = 7; CALL; } break; \
+        case 8: { constexpr int PP = 8; CALL; } break; \
+        default: crl_set_error("ttt: P=%d out of range 1..8", P_); return CRL_EINVAL; \
+    }
+
+#define TTT_CTX_CHECK(fn)                                                                  \
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TTT, fn ": ctx is not a tictactoe context"); \
+    CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 31), fn ": B=%lld out of range", (long long)B)
+
+extern "C" {
+
+int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out)
+{
+    CRL_REQUIRE(out != nullptr, "crl_ttt_create: out is NULL");
+    CRL_REQUIRE(D0 >= 1 && D1 >= 1 && D2 >= 1 && (int64_t)D0 * D1 * D2 <= 32, "crl_ttt_create: board %dx%dx%d must have 1..32 cells", D0, D1, D2);
+    CRL_REQUIRE(K >= 2 && K <= 32, "crl_ttt_create: K=%d out of range", K);
+    CRL_REQUIRE(P >= 1 && P <= CRL_TTT_MAX_P, "crl_ttt_create: P=%d out of range 1..%d", P, CRL_TTT_MAX_P);
+    crl_ctx *c = new crl_ctx();
+    memset(c, 0, sizeof(*c));
+    c->game = CRL_GAME_TTT;
+    c->ttt.D0 = D0; c->ttt.D1 = D1; c->ttt.D2 = D2; c->ttt.K = K; c->ttt.P = P;
+    c->ttt.n_cells = D0 * D1 * D2;
+    c->ttt.full = c->ttt.n_cells == 32 ? 0xffffffffu : ((1u << c->ttt.n_cells) - 1u);
+    ttt_dirs dd;
+    int n_lines = 0;
+    if (build_dirs(c->ttt, dd, c->ttt_lines_host, n_lines) != 0) {
+        delete c;
+        crl_set_error("crl_ttt_create: too many win lines for %dx%dx%d K=%d", D0, D1, D2, K);
+        return CRL_EUNSUPPORTED;
+    }
+    c->ttt.n_lines = n_lines;
+    *out = c;
+    return CRL_OK;
+}
+
+int crl_ttt_lines(const crl_ctx *ctx, uint32_t *lines, int cap)
+{
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TTT, "crl_ttt_lines: ctx is not a tictactoe context");
+    if (lines)
+        for (int i = 0; i < ctx->ttt.n_lines && i < cap; ++i) lines[i] = ctx->ttt_lines_host[i];
+    return ctx->ttt.n_lines;
+}
+
+int crl_ttt_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask, uint32_t *occ, int8_t *winner, int8_t *to_move, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_reset");
+    CRL_REQUIRE(occ && winner && to_move, "crl_ttt_reset: NULL state pointer");
+    hipLaunchKernelGGL(ttt_reset_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, ctx->ttt.P, B, mask, occ, winner, to_move);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, int8_t *winner, int8_t *to_move,
+                 const int8_t *action, int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t flags, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_step");
+    CRL_REQUIRE(occ && winner && to_move, "crl_ttt_step: NULL state pointer");
+    CRL_REQUIRE(action && reward && terminal && winners, "crl_ttt_step: NULL action/output pointer");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_ttt_step: unknown flags 0x%x", flags);
+    const ttt_dirs dd = dirs_of(ctx);
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        hipLaunchKernelGGL((ttt_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                           occ, winner, to_move, action, reward, terminal, winners, flags);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, uint32_t *valid, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_valid");
+    CRL_REQUIRE(occ && valid, "crl_ttt_valid: NULL pointer");
+    hipLaunchKernelGGL(ttt_valid_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, ctx->ttt.P, ctx->ttt.full, B, occ, valid);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, int rel_mod, int8_t *board, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_board");
+    CRL_REQUIRE(occ && board, "crl_ttt_board: NULL pointer");
+    CRL_REQUIRE(player == nullptr || rel_mod >= 1, "crl_ttt_board: rel_mod must be >= 1 when player is given");
+    hipLaunchKernelGGL(ttt_board_kernel, dim3(blocks_for(B * ctx->ttt.n_cells, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->ttt.P, ctx->ttt.n_cells, B, occ, player, rel_mod, board);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                    uint32_t *occ, int8_t *winner, int8_t *to_move, crl_ttt_stats st, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_rollout");
+    CRL_REQUIRE(occ && winner && to_move, "crl_ttt_rollout: NULL state pointer");
+    CRL_REQUIRE(st.episode && st.tstep && st.n_episodes && st.win_count && st.draw_count && st.len_sum, "crl_ttt_rollout: NULL stats pointer");
+    CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_ttt_rollout: T=%d out of range", T);
+    if (T == 0) return CRL_OK;
+    const ttt_dirs dd = dirs_of(ctx);
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        hipLaunchKernelGGL((ttt_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,156 @@
+"""Shared host logic of the n-player TicTacToe drop-ins.
+
+The three reference envs (colosseumrl/envs/tictactoe/tictactoe_{2,3,4}p_env.py) are the
+same program with a different board shape and player count; here they are one
+class parameterised by ``SHAPE``/``PLAYERS``/``K`` whose rules run on the GPU through
+``colosseumrl_amd.batched.TTTBatch`` (bit-mask state, B=1).
+
+State: ``(board int8[SHAPE] with -1 = empty, winner: None | int)`` as in the reference
+(tictactoe_2p_env.py:165-169).  Canonical action string: ``str(tuple_of_python_ints)``,
+e.g. ``'(0, 1)'`` -- what the reference emitted under numpy 1.x and what its own
+``string_to_action`` parses.
+"""
+from typing import Dict, List, Tuple, Union
+
+import dill
+import numpy as np
+
+from ...BaseEnvironment import BaseEnvironment
+
+State = object
+
+
+def action_to_string(index) -> str:
+    """Cell index tuple -> action string (reference 2p:30-42), with plain Python ints."""
+    return str(tuple(int(i) for i in index))
+
+
+def string_to_action(action_str: str) -> Union[Tuple[int, ...], None]:
+    """Action string -> index tuple; ``''`` -> None (reference 2p:45-63)."""
+    if action_str == "":
+        return None
+    return tuple(map(int, action_str.replace("(", "").replace(")", "").split(",")))
+
+
+class TicTacToeEnvBase(BaseEnvironment):
+    SHAPE: Tuple[int, ...] = (3, 3)
+    PLAYERS: int = 2
+    K: int = 3
+    REL_MOD: int = 2          # modulus of _relative_player_id (4p uses 3 in the reference, 4p:50)
+
+    def __init__(self, config: str = "", device="cuda"):
+        super().__init__(config)
+        self._device = device
+        self._stepper = None
+
+    @property
+    def min_players(self) -> int:
+        return self.PLAYERS
+
+    @property
+    def max_players(self) -> int:
+        return self.PLAYERS
+
+    @property
+    def observation_shape(self) -> Dict[str, Tuple[int, ...]]:
+        return {"board": tuple(self.SHAPE)}
+
+    @staticmethod
+    def observation_names():
+        return ["board"]
+
+    # ---- device plumbing ------------------------------------------------------------------
+    def _batch(self):
+        if self._stepper is None:
+            from ...batched import TTTBatch
+            self._stepper = TTTBatch(self.SHAPE, self.K, self.PLAYERS, 1, device=self._device)
+        return self._stepper
+
+    def _upload(self, state, mover: int):
+        import torch
+        board, winner = state
+        flat = np.asarray(board).ravel()
+        tb = self._batch()
+        masks = [int(sum(1 << int(c) for c in np.nonzero(flat == p)[0])) for p in range(self.PLAYERS)]
+        occ = np.array(masks, dtype=np.uint32).view(np.int32).reshape(-1, 1)
+        tb.occ.copy_(torch.from_numpy(occ))
+        tb.winner.fill_(-1 if winner is None else int(winner))
+        tb.to_move.fill_(int(mover))
+        return tb
+
+    def _cell_of(self, index) -> int:
+        """Flat cell of an index tuple with Python indexing rules (negative wraps, out of range raises)."""
+        if len(index) != len(self.SHAPE):
+            raise IndexError("too many indices for array" if len(index) > len(self.SHAPE) else "index has too few dimensions")
+        fixed = []
+        for i, n in zip(index, self.SHAPE):
+            if i < -n or i >= n:
+                raise IndexError("index {} is out of bounds for axis with size {}".format(i, n))
+            fixed.append(i + n if i < 0 else i)
+        return int(np.ravel_multi_index(tuple(fixed), self.SHAPE))
+
+    # ---- dynamics ---------------------------------------------------------------------------
+    def new_state(self, num_players: int = None) -> Tuple[State, List[int]]:
+        if num_players is None:
+            num_players = self.PLAYERS
+        assert num_players == self.PLAYERS
+        return (np.full(self.SHAPE, -1, np.int8), None), [0]
+
+    @staticmethod
+    def serializable() -> bool:
+        return True
+
+    @staticmethod
+    def serialize_state(state: object) -> bytearray:
+        return dill.dumps(state)
+
+    @staticmethod
+    def deserialize_state(serialized_state: bytearray) -> State:
+        return dill.loads(serialized_state)
+
+    def current_rewards(self, state: object) -> List[float]:
+        """+1 for the winner, -1 for the others, 0 while undecided (reference 2p:219-238)."""
+        _, winner = state
+        if winner is not None:
+            return [1 if p == winner else -1 for p in range(self.max_players)]
+        return [0 for _ in range(self.max_players)]
+
+    def next_state(self, state: object, players: List[int], actions: List[str]):
+        """One move of ``players[0]`` (reference 2p:240-315), evaluated by the HIP kernel."""
+        import torch
+        action, player_num = actions[0], players[0]
+        cell = -1
+        if len(action) > 0:
+            cell = self._cell_of(string_to_action(action))     # same exceptions as the reference's board[index]
+        tb = self._upload(state, player_num)
+        reward, terminal, winners = tb.step(torch.tensor([cell], dtype=torch.int8, device=tb.device))
+        board = tb.board().cpu().numpy().reshape(self.SHAPE)
+        w = int(tb.winner.cpu().numpy()[0])
+        ws = int(winners.cpu().numpy()[0])
+        return ((board, None if w < 0 else w), [int(tb.to_move.cpu().numpy()[0])],
+                [int(reward.cpu().numpy()[0])], bool(terminal.cpu().numpy()[0]), None if ws < 0 else [ws])
+
+    def valid_actions(self, state: object, player: int) -> List[str]:
+        """Every empty cell in row-major order, or ``['']`` when the board is full (reference 2p:317-348)."""
+        tb = self._upload(state, player)
+        mask = int(tb.valid_mask().cpu().numpy().view(np.uint32)[0])
+        cells = [c for c in range(tb.n_cells) if (mask >> c) & 1]
+        out = [action_to_string(np.unravel_index(c, self.SHAPE)) for c in cells]
+        return out if out else [""]
+
+    def is_valid_action(self, state: object, player_num: int, action: str) -> bool:
+        """Target cell is empty; ``''`` is never valid (reference 2p:350-380)."""
+        if len(action) == 0:
+            return False
+        cell = self._cell_of(string_to_action(action))
+        tb = self._upload(state, player_num)
+        mask = int(tb.valid_mask().cpu().numpy().view(np.uint32)[0])
+        return bool((mask >> cell) & 1)
+
+    def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
+        """Board with ids relative to the observer (reference 2p:382-407; modulus per file, see REL_MOD)."""
+        import torch
+        tb = self._upload(state, player)
+        pl = torch.tensor([player], dtype=torch.int8, device=tb.device)
+        board = tb.board(pl, self.REL_MOD).cpu().numpy().reshape(self.SHAPE)
+        return {"board": board}

@@ -1,0 +1,225 @@
+"""Tron on a finite grid -- drop-in for ``colosseumrl.envs.tron.TronGridEnvironment``.
+
+Same constructor config string (``"board;players;window;remove_on_death"``),
+state tuple ``(board int64[N,N], heads int64[P], directions int64[P],
+deaths int64[P])``, action strings and return types as the reference
+(colosseumrl/envs/tron/TronGridEnvironment.py:61-508).  The game rules are NOT
+evaluated in Python: ``next_state``/``new_state``/``state_to_observation``
+upload the state into a B=1 ``TronBatch`` and run the HIP kernels; without an
+MI355X they raise.  For throughput use ``colosseumrl_amd.batched.TronBatch``
+directly -- this class exists so existing agents and servers drop in unchanged.
+"""
+from collections import Counter
+from time import time
+from typing import Dict, List, Tuple
+
+import numpy as np
+from dill import dumps, loads
+
+from ...BaseEnvironment import BaseEnvironment
+from . import layout
+
+
+def create_tron_config(*args) -> str:
+    """Join constructor options into the ``a;b;c`` config string (reference :12-25)."""
+    return ";".join(str(a) for a in args)
+
+
+def parse_tron_config(config: str) -> Tuple:
+    """Config string -> (board_size, num_players, observation_window, remove_on_death).
+
+    Integers parse as ints, anything else as ``text.lower() == "true"``; missing trailing
+    options default to 4, -1, False; the empty string means ``19;4;-1;False`` (reference :28-58).
+    """
+    if len(config) == 0:
+        return 19, 4, -1, False
+
+    def one(text):
+        try:
+            return int(text)
+        except ValueError:
+            return text.lower() == "true"
+
+    options = [one(t) for t in config.split(";")]
+    for default in ((4, -1, False)[len(options) - 1:] if len(options) < 4 else ()):
+        options.append(default)
+    return options
+
+
+class TronGridEnvironment(BaseEnvironment):
+    STRING_TO_ACTION = {"": 0, "forward": 0, "right": 1, "left": -1}   # reference :62-67
+
+    @staticmethod
+    def create(board_size: int = 19, num_players: int = 4, observation_window: int = -1,
+               remove_on_death: bool = False) -> "TronGridEnvironment":
+        """Keyword-argument constructor (reference :69-90)."""
+        return TronGridEnvironment(create_tron_config(board_size, num_players, observation_window, remove_on_death))
+
+    def __init__(self, config: str = "", device="cuda"):
+        super().__init__(config)
+        board_size, num_players, observation_window, remove_on_death = parse_tron_config(config)
+        self.N = board_size
+        self.num_players = num_players
+        self.observation_window = observation_window
+        self.fully_observable = observation_window < 0
+        self.remove_on_death = remove_on_death       # parsed but without effect, as in the reference
+        self.player_array = np.arange(num_players)
+        self.move_array = ["forward", "right", "left"]
+        # persistent move buffer: an alive player missing from `players` replays its last move (:118,297-298)
+        self._moves = np.zeros(num_players, dtype=np.int64)
+        self._device = device
+        self._stepper = None
+
+    def __repr__(self):
+        return ("Tron Finite Grid Environment\n" + "=" * 50 + "\n"
+                + "\tSize: {0}x{0}\n".format(self.N)
+                + "\tNumber of players: {}\n".format(self.num_players)
+                + "\tFully Observable: {}\n".format("Yes" if self.fully_observable else "No")
+                + "\tRemove old players: {}\n".format("Yes" if self.remove_on_death else "No")
+                + "-" * 50 + "\n")
+
+    __str__ = __repr__
+
+    @property
+    def min_players(self) -> int:
+        return self.num_players
+
+    @property
+    def max_players(self) -> int:
+        return self.num_players
+
+    @staticmethod
+    def observation_names() -> List[str]:
+        return ["board", "heads", "directions", "deaths"]
+
+    @property
+    def observation_shape(self) -> Dict[str, tuple]:
+        p = (self.num_players,)
+        return {"board": (self.N, self.N), "heads": p, "directions": p, "deaths": p}
+
+    # ---- device plumbing ------------------------------------------------------------------
+    def _batch(self):
+        """The B=1 HIP stepper behind this instance (created on first use; raises without a GPU)."""
+        if self._stepper is None:
+            from ...batched import TronBatch
+            self._stepper = TronBatch(self.N, self.num_players, 1, device=self._device)
+        return self._stepper
+
+    def _upload(self, state):
+        import torch
+        board, heads, directions, deaths = state
+        tb = self._batch()
+        tb.board.copy_(torch.from_numpy(np.ascontiguousarray(board, dtype=np.int64).reshape(1, -1).astype(np.int8)))
+        tb.heads.copy_(torch.from_numpy(np.asarray(heads, dtype=np.int64).reshape(-1, 1).astype(np.int16)))
+        tb.dirs.copy_(torch.from_numpy(np.asarray(directions, dtype=np.int64).reshape(-1, 1).astype(np.int8)))
+        tb.deaths.copy_(torch.from_numpy(np.asarray(deaths, dtype=np.int64).reshape(-1, 1).astype(np.int8)))
+        return tb
+
+    def _download(self, tb):
+        n = self.N
+        return (tb.board.cpu().numpy().astype(np.int64).reshape(n, n),
+                tb.heads.cpu().numpy().astype(np.int64).reshape(-1),
+                tb.dirs.cpu().numpy().astype(np.int64).reshape(-1),
+                tb.deaths.cpu().numpy().astype(np.int64).reshape(-1))
+
+    # ---- dynamics ---------------------------------------------------------------------------
+    def generate_start_positions(self, ring_offset: int = 1, spawn_offset=0):
+        """(heads, directions) of the spawn ring (reference :183-226).
+
+        A tuple ``spawn_offset`` draws one offset per player from numpy's global generator, as
+        the reference does (``np.random.randint(lo, hi)`` per player, :222-224).
+        """
+        if isinstance(spawn_offset, int):
+            spawn_offset = (spawn_offset, spawn_offset + 1)
+        offsets = [int(np.random.randint(*spawn_offset)) for _ in range(self.num_players)]
+        heads, dirs = layout.start_positions(self.N, self.num_players, ring_offset, offsets)
+        return np.asarray(heads, dtype=np.int64), np.asarray(dirs, dtype=np.int64)
+
+    def new_state(self, num_players: int = None, ring_offset: int = 1, spawn_offset=2):
+        """Initial state and the acting players (reference :228-263)."""
+        num_players = self.num_players if num_players is None else num_players
+        assert num_players == self.num_players, "Do not change the number of players from the game configuration."
+        np.random.seed(int(time()))                   # reference :255 (observable only with tuple offsets)
+        heads, directions = self.generate_start_positions(ring_offset, spawn_offset)
+        from ...batched import TronBatch
+        tb = TronBatch(self.N, self.num_players, 1, device=self._device, start=(heads.tolist(), directions.tolist()))
+        return self._download(tb), self.player_array
+
+    def next_state(self, state: object, players: List[int], actions: List[str]):
+        """One simultaneous move of every listed player (reference :265-323), evaluated on the GPU."""
+        import torch
+        for player, action in zip(players, actions):
+            self._moves[player] = self.STRING_TO_ACTION[action]      # KeyError on an unknown string, like the reference
+        tb = self._upload(state)
+        act = torch.from_numpy(self._moves.astype(np.int8).reshape(-1, 1)).to(tb.device)
+        rewards, terminal, winners = tb.step(act)
+        new_state = self._download(tb)
+        deaths = new_state[3]
+        new_players = np.where(deaths == 0)[0]
+        rewards = rewards.cpu().numpy().astype(np.int64).reshape(-1)
+        term = np.bool_(bool(terminal.cpu().numpy()[0]))
+        return new_state, new_players, rewards, term, (new_players if term else None)
+
+    def valid_actions(self, state: object, player: int) -> List[str]:
+        return self.move_array                        # every move is always allowed (reference :325-341)
+
+    def is_valid_action(self, state: object, player: int, action: str) -> bool:
+        return True                                   # reference :343-361
+
+    def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
+        """Board relabelled so the observer is player 1; per-player vectors rolled (reference :363-420)."""
+        import torch
+        tb = self._upload(state)
+        obs = tb.observe(torch.tensor([player], dtype=torch.int8, device=tb.device))
+        board = obs["board"].cpu().numpy().astype(np.int64).reshape(self.N, self.N)
+        heads = obs["heads"].cpu().numpy().astype(np.int64).reshape(-1)
+        directions = obs["directions"].cpu().numpy().astype(np.int64).reshape(-1)
+        deaths = obs["deaths"].cpu().numpy().astype(np.int64).reshape(-1)
+        if self.fully_observable:
+            return {"board": board, "heads": heads, "directions": directions, "deaths": deaths}
+        # unfinished window branch of the reference (:407-420): no 'directions', python slice semantics
+        head = heads[0]
+        x, y, delta = head % self.N, head // self.N, self.observation_window
+        return {"board": board[y - delta:y + delta, x - delta:x + delta], "heads": heads, "deaths": deaths}
+
+    # ---- transport ---------------------------------------------------------------------------
+    @staticmethod
+    def serializable() -> bool:
+        return False                                  # reference :422-431
+
+    @staticmethod
+    def serialize_state(state: object) -> bytearray:
+        return dumps(state)                           # reference :433-447
+
+    @staticmethod
+    def deserialize_state(serialized_state: bytearray) -> object:
+        return loads(serialized_state)                # reference :449-463
+
+    # ---- helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def next_cell(x, y, direction, board_size: int = None):
+        """Neighbour of (x, y) in ``direction``; clamped to the board when a size is given (:466-481)."""
+        x += (direction == 1) - (direction == 3)
+        y += (direction == 2) - (direction == 0)
+        if board_size:
+            x = max(min(x, board_size - 1), 0)
+            y = max(min(y, board_size - 1), 0)
+        return x, y
+
+    def compute_ranking(self, state: object, players: List[int], winners: List[int]) -> Dict[int, int]:
+        """Competition ranking by trail length with the mutual-kill tie rule (reference :483-508)."""
+        board, _, _, deaths = state
+        num_players = deaths.shape[0]
+        scores = Counter(np.asarray(board).ravel() - 1)
+        del scores[-1]
+        mutual = np.where(deaths[deaths - 1] - np.arange(num_players) - 1 == 0)[0]
+        for victim in mutual:
+            killer = deaths[victim] - 1
+            scores[victim] = min(scores[victim], scores[killer])
+        rankings, rank, previous = {}, 0, np.inf
+        for position, (player, score) in enumerate(scores.most_common()):
+            if score < previous:
+                rank = position
+            rankings[player] = rank
+            previous = score
+        return rankings

@@ -1,0 +1,154 @@
+/* colosseum_hip.h -- C ABI of libcolosseum_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the colosseumrl hot path: the batched equivalents of
+ *   BaseEnvironment.new_state / next_state / valid_actions (+ the winners output)
+ * for the Tron, TicTacToe and Blokus environments.  Plain pointers and sizes, no
+ * torch types.  The reference's only native boundary is the Cython module
+ *   colosseumrl/envs/tron/CyTronGrid.pyx:3-7   next_state_inplace(board, heads, directions, deaths, actions)
+ *   colosseumrl/envs/tron/CyTronGrid.pyx:65    relative_player_inplace(board, num_players, player)
+ * (C-contiguous buffers mutated in place, caller owns everything, no error path);
+ * the entry points below keep those conventions and add what the Python layers
+ * around it compute (rewards / terminal / winners, resets, legal-move sets).
+ *
+ * Conventions
+ *   - every `void *`/typed pointer marked DEVICE is a device (HBM) address owned by the caller
+ *     (the Python host passes torch-ROCm tensors' data_ptr()); kernels mutate state in place;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are
+ *     asynchronous on it, never synchronise the host, and are graph-capturable
+ *     (crl_*_create / crl_destroy are the only calls that allocate or copy synchronously);
+ *   - every function returns 0 on success and a negative CRL_E* code on error; nothing throws
+ *     across the ABI; crl_last_error() returns a thread-local message for the last failure;
+ *   - contexts are immutable after creation: any number of host threads may use one context
+ *     concurrently on different buffers/streams (several env instances live under the GIL in
+ *     the reference's MatchmakingServer.py:128-135);
+ *   - env b of a batch of B owns board[b*cells .. (b+1)*cells) and element [p*B + b] of every
+ *     per-player array ("[P][B]" struct-of-arrays: consecutive lanes touch consecutive bytes).
+ *
+ * There is NO CPU implementation behind this ABI.  The CPU restatement used by the tests lives
+ * in oracle/ and is a different library.
+ */
+#ifndef COLOSSEUM_HIP_H
+#define COLOSSEUM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRL_OK            0
+#define CRL_EINVAL       -1   /* bad argument (null pointer, size out of range, ...) */
+#define CRL_EHIP         -2   /* HIP runtime error (message has hipGetErrorString) */
+#define CRL_ENODEV       -3   /* no gfx950 device visible */
+#define CRL_EUNSUPPORTED -4
+
+#define CRL_TRON_MAX_P   8
+#define CRL_TTT_MAX_P    8
+#define CRL_TTT_MAX_LINES 256
+
+/* flags for *_step */
+#define CRL_STEP_AUTO_RESET 1u  /* after writing the step outputs, reset every env that just became terminal */
+
+typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
+
+const char *crl_last_error(void);
+int crl_version(void);
+/* number of visible HIP devices, or a negative code */
+int crl_device_count(void);
+void crl_destroy(crl_ctx *ctx);
+
+/* ------------------------------------------------------------------ RNG (exposed for parity tests) */
+/* out[i*4..i*4+3] = Philox-4x32-10(ctr[i*4..], key); n counters; DEVICE pointers */
+int crl_philox4x32(const uint32_t *ctr, uint32_t key0, uint32_t key1, uint32_t *out, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------ Tron
+ * State (reference TronGridEnvironment.py:256-263, int64 there):
+ *   board  int8  [B][N*N]   0 empty, p+1 = trail/head of player p
+ *   heads  int16 [P][B]     flat y*N+x
+ *   dirs   int8  [P][B]     0 N(y-1) 1 E(x+1) 2 S(y+1) 3 W(x-1)
+ *   deaths int8  [P][B]     0 alive, else 1-based killer id
+ */
+/* replaces the per-instance set-up of TronGridEnvironment.__init__/generate_start_positions
+ * (TronGridEnvironment.py:92-118,183-226); start_* are HOST arrays of length P */
+int crl_tron_create(int N, int P, const int16_t *start_heads, const int8_t *start_dirs, crl_ctx **out);
+
+/* replaces TronGridEnvironment.new_state (TronGridEnvironment.py:228-263) for B envs.
+ * mask (DEVICE, uint8 [B]) may be NULL = reset all; else only envs with mask[b] != 0 */
+int crl_tron_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask,
+                   int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths, void *stream);
+
+/* replaces CyTronGrid.next_state_inplace (CyTronGrid.pyx:3-62) + the tail of
+ * TronGridEnvironment.next_state (TronGridEnvironment.py:309-323) for B envs.
+ *   actions  int8 [P][B] in {0 forward, +1 right, -1 left} (dead players' entries ignored)
+ *   rewards  int8 [P][B] out: -1 dead, +1 alive, +10 surviving winner
+ *   terminal uint8 [B]   out: alive <= 1
+ *   winners  uint8 [B]   out: bitmask of alive players if terminal, else 0 (reference: None) */
+int crl_tron_step(const crl_ctx *ctx, int64_t B,
+                  int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                  const int8_t *actions, int8_t *rewards, uint8_t *terminal, uint8_t *winners,
+                  uint32_t flags, void *stream);
+
+/* per-env rollout bookkeeping, all DEVICE arrays (any may NOT be NULL) */
+typedef struct {
+    uint32_t *episode;      /* [B] episode index  = RNG counter word 1 */
+    uint32_t *tstep;        /* [B] steps taken in the current episode = RNG counter word 2 */
+    uint32_t *n_episodes;   /* [B] episodes finished */
+    uint32_t *win_count;    /* [P][B] */
+    uint32_t *len_sum;      /* [B] */
+    int32_t  *ret_sum;      /* [P][B] sum of rewards */
+    uint8_t  *last_winners; /* [B] */
+    uint16_t *last_len;     /* [B] */
+} crl_tron_stats;
+
+/* T fused env-steps per env with a uniform random agent and auto-reset (the benchmark loop of
+ * BASELINE.md section 3; no reference counterpart -- the reference steps one env per Python call).
+ * action of player p at (global env g = first_env_id + b, episode e, step t):
+ *   w = Philox4x32-10(ctr = {g, e, t, 0x54520000 | (p >> 2)}, key = {seed lo, seed hi})[p & 3]
+ *   a = mulhi32(w, 3): 0 -> forward, 1 -> right, 2 -> left */
+int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                     int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                     crl_tron_stats stats, void *stream);
+
+/* replaces CyTronGrid.relative_player_inplace (CyTronGrid.pyx:65-71) + the rolls of
+ * TronGridEnvironment.state_to_observation (TronGridEnvironment.py:385-405), fully observable branch.
+ * player int8 [B]: observer of env b.  Outputs have the shapes of the state arrays. */
+int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads,
+                     const int8_t *dirs, const int8_t *deaths, const int8_t *player,
+                     int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream);
+
+/* ------------------------------------------------------------------ TicTacToe (D0 x D1 x D2, K in a row, P players)
+ * State (reference tictactoe_2p_env.py:165-169: (board int8, winner)):
+ *   occ     uint32 [P][B]  bit c set = flat cell c (row-major) holds player p's mark
+ *   winner  int8   [B]     -1 = None (sticky once set)
+ *   to_move int8   [B]
+ */
+int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out);
+/* number of win lines and a HOST copy of them (for tests); lines may be NULL */
+int crl_ttt_lines(const crl_ctx *ctx, uint32_t *lines, int cap);
+int crl_ttt_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask,
+                  uint32_t *occ, int8_t *winner, int8_t *to_move, void *stream);
+/* replaces TicTacToe{2,3,4}PlayerEnv.next_state (tictactoe_2p_env.py:240-315).
+ *   action int8 [B]: flat cell index, or -1 for '' ; an occupied cell is a no-op that still passes the turn
+ *   reward int8 [B] (the mover's), terminal uint8 [B], winners int8 [B] (-1 = None, else the winner) */
+int crl_ttt_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, int8_t *winner, int8_t *to_move,
+                 const int8_t *action, int8_t *reward, uint8_t *terminal, int8_t *winners,
+                 uint32_t flags, void *stream);
+/* replaces TicTacToe*.valid_actions (tictactoe_2p_env.py:317-348): empties bitmask uint32 [B] */
+int crl_ttt_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, uint32_t *valid, void *stream);
+/* int8 [B][cells] board in the reference encoding (-1 empty), relative to `player` when player != NULL
+ * (reference _relative_player_id, tictactoe_2p_env.py:26-27, modulus given by rel_mod) */
+int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, int rel_mod,
+                  int8_t *board, void *stream);
+typedef struct {
+    uint32_t *episode, *tstep, *n_episodes;
+    uint32_t *win_count;   /* [P][B] */
+    uint32_t *draw_count;  /* [B] */
+    uint32_t *len_sum;     /* [B] */
+} crl_ttt_stats;
+/* random agent: r = mulhi32(Philox(ctr={g,e,t,0x54540000},seed)[0], n_empty); r-th empty cell in row-major order */
+int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                    uint32_t *occ, int8_t *winner, int8_t *to_move, crl_ttt_stats stats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

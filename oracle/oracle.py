@@ -1,0 +1,193 @@
+"""ctypes/numpy front end of liboracle.so -- TEST INFRASTRUCTURE (the checker, never the product).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+All arrays are host numpy arrays in the same SoA layout the HIP kernels use.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TAG_TRON, TAG_TTT, TAG_BLOKUS = 0x54520000, 0x54540000, 0x424C0000
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    srcs = [os.path.join(HERE, f) for f in ("crl_oracle.c", "blokus_oracle.c", "crl_oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(a, dtype, shape=None):
+    assert isinstance(a, np.ndarray) and a.dtype == np.dtype(dtype) and a.flags.c_contiguous, (a.dtype, dtype)
+    if shape is not None:
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
+    return a
+
+
+# ------------------------------------------------------------------ RNG
+def philox4x32(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32).copy()
+    k = np.asarray(key, dtype=np.uint32).copy()
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32(_p(c), _p(k), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ Tron
+def tron_start_positions(N, P, ring_offset=1, spawn_offset=2):
+    offs = np.asarray([spawn_offset] * P if np.isscalar(spawn_offset) else spawn_offset, dtype=np.int32)
+    heads = np.zeros(P, dtype=np.int16)
+    dirs = np.zeros(P, dtype=np.int8)
+    rc = lib().orc_tron_start_positions(C.c_int(N), C.c_int(P), C.c_int(ring_offset), _p(offs), _p(heads), _p(dirs))
+    if rc != 0:
+        raise ValueError("orc_tron_start_positions rc=%d" % rc)
+    return heads, dirs
+
+
+class TronState:
+    """SoA host buffers for B Tron games."""
+
+    def __init__(self, N, P, B):
+        self.N, self.P, self.B = N, P, B
+        self.board = np.zeros((B, N * N), dtype=np.int8)
+        self.heads = np.zeros((P, B), dtype=np.int16)
+        self.dirs = np.zeros((P, B), dtype=np.int8)
+        self.deaths = np.zeros((P, B), dtype=np.int8)
+        # rollout bookkeeping
+        self.episode = np.zeros(B, dtype=np.uint32)
+        self.tstep = np.zeros(B, dtype=np.uint32)
+        self.n_episodes = np.zeros(B, dtype=np.uint32)
+        self.win_count = np.zeros((P, B), dtype=np.uint32)
+        self.len_sum = np.zeros(B, dtype=np.uint32)
+        self.ret_sum = np.zeros((P, B), dtype=np.int32)
+        self.last_winners = np.zeros(B, dtype=np.uint8)
+        self.last_len = np.zeros(B, dtype=np.uint16)
+
+    def copy(self):
+        o = TronState(self.N, self.P, self.B)
+        for k, v in self.__dict__.items():
+            if isinstance(v, np.ndarray):
+                setattr(o, k, v.copy())
+        return o
+
+
+class _TronStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("episode", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
+
+
+def tron_reset(st, start_heads, start_dirs):
+    sh = _chk(np.ascontiguousarray(start_heads, dtype=np.int16), np.int16, (st.P,))
+    sd = _chk(np.ascontiguousarray(start_dirs, dtype=np.int8), np.int8, (st.P,))
+    lib().orc_tron_reset(C.c_int(st.N), C.c_int(st.P), C.c_int64(st.B), _p(sh), _p(sd),
+                         _p(st.board), _p(st.heads), _p(st.dirs), _p(st.deaths))
+
+
+def tron_step(st, actions):
+    a = _chk(np.ascontiguousarray(actions, dtype=np.int8), np.int8, (st.P, st.B))
+    rewards = np.zeros((st.P, st.B), dtype=np.int8)
+    terminal = np.zeros(st.B, dtype=np.uint8)
+    winners = np.zeros(st.B, dtype=np.uint8)
+    lib().orc_tron_step(C.c_int(st.N), C.c_int(st.P), C.c_int64(st.B),
+                        _p(st.board), _p(st.heads), _p(st.dirs), _p(st.deaths),
+                        _p(a), _p(rewards), _p(terminal), _p(winners))
+    return rewards, terminal, winners
+
+
+def tron_rollout(st, seed, first_env_id, T, start_heads, start_dirs, n_threads=1):
+    sh = np.ascontiguousarray(start_heads, dtype=np.int16)
+    sd = np.ascontiguousarray(start_dirs, dtype=np.int8)
+    stats = _TronStats(*[_p(getattr(st, n)) for n, _ in _TronStats._fields_])
+    f = lib().orc_tron_rollout
+    f.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _TronStats, C.c_int]
+    f.restype = None
+    f(st.N, st.P, st.B, seed, first_env_id, T, _p(sh), _p(sd),
+      _p(st.board), _p(st.heads), _p(st.dirs), _p(st.deaths), stats, n_threads)
+
+
+def tron_observe(st, player):
+    pl = _chk(np.ascontiguousarray(player, dtype=np.int8), np.int8, (st.B,))
+    ob = np.zeros_like(st.board)
+    oh = np.zeros_like(st.heads)
+    od = np.zeros_like(st.dirs)
+    ok = np.zeros_like(st.deaths)
+    lib().orc_tron_observe(C.c_int(st.N), C.c_int(st.P), C.c_int64(st.B), _p(st.board), _p(st.heads),
+                           _p(st.dirs), _p(st.deaths), _p(pl), _p(ob), _p(oh), _p(od), _p(ok))
+    return ob, oh, od, ok
+
+
+# ------------------------------------------------------------------ TicTacToe
+def ttt_lines(D0, D1, D2, K):
+    buf = np.zeros(256, dtype=np.uint32)
+    n = lib().orc_ttt_lines(C.c_int(D0), C.c_int(D1), C.c_int(D2), C.c_int(K), _p(buf))
+    if n < 0:
+        raise ValueError("orc_ttt_lines rc=%d" % n)
+    return buf[:n].copy()
+
+
+class TTTState:
+    def __init__(self, dims, K, P, B):
+        self.dims, self.K, self.P, self.B = tuple(dims), K, P, B
+        d = (1,) * (3 - len(dims)) + tuple(dims)
+        self.n_cells = int(np.prod(d))
+        self.lines = ttt_lines(d[0], d[1], d[2], K)
+        self.occ = np.zeros((P, B), dtype=np.uint32)
+        self.winner = np.full(B, -1, dtype=np.int8)
+        self.to_move = np.zeros(B, dtype=np.int8)
+        self.episode = np.zeros(B, dtype=np.uint32)
+        self.tstep = np.zeros(B, dtype=np.uint32)
+        self.n_episodes = np.zeros(B, dtype=np.uint32)
+        self.win_count = np.zeros((P, B), dtype=np.uint32)
+        self.draw_count = np.zeros(B, dtype=np.uint32)
+        self.len_sum = np.zeros(B, dtype=np.uint32)
+
+    def board(self):
+        """int8 [B, n_cells] board in the reference encoding (-1 empty, else player id)."""
+        bd = np.full((self.B, self.n_cells), -1, dtype=np.int8)
+        for p in range(self.P):
+            bits = (self.occ[p][:, None] >> np.arange(self.n_cells, dtype=np.uint32)[None, :]) & 1
+            bd[bits.astype(bool)] = p
+        return bd
+
+
+class _TTTStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
+
+
+def ttt_step(st, action):
+    a = _chk(np.ascontiguousarray(action, dtype=np.int8), np.int8, (st.B,))
+    reward = np.zeros(st.B, dtype=np.int8)
+    terminal = np.zeros(st.B, dtype=np.uint8)
+    winners = np.zeros(st.B, dtype=np.int8)
+    lib().orc_ttt_step(C.c_int(st.n_cells), C.c_int(st.P), C.c_int(len(st.lines)), _p(st.lines), C.c_int64(st.B),
+                       _p(st.occ), _p(st.winner), _p(st.to_move), _p(a), _p(reward), _p(terminal), _p(winners))
+    return reward, terminal, winners
+
+
+def ttt_rollout(st, seed, first_env_id, T, n_threads=1):
+    stats = _TTTStats(*[_p(getattr(st, n)) for n, _ in _TTTStats._fields_])
+    f = lib().orc_ttt_rollout
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p, _TTTStats, C.c_int]
+    f.restype = None
+    f(st.n_cells, st.P, len(st.lines), _p(st.lines), st.B, seed, first_env_id, T,
+      _p(st.occ), _p(st.winner), _p(st.to_move), stats, n_threads)

@@ -1,0 +1,179 @@
+"""HIP Tron kernels (through the C ABI) vs golden vectors from the reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from backends import HipTron, OracleTron
+from replay import replay_tron, replay_tron_fused_reset
+
+TRAJ = ["n20p4", "n40p4", "n20p2", "n21p3", "n20p6", "n7p5", "n20p4_noreset", "n9p8_noreset"]
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_traj_golden(golden, name):
+    assert replay_tron(golden("tron_traj_" + name), HipTron) > 0
+
+
+@pytest.mark.parametrize("name", ["n20p4", "n40p4", "n7p5", "n21p3"])
+def test_traj_golden_fused_reset(golden, name):
+    replay_tron_fused_reset(golden("tron_traj_" + name), HipTron)
+
+
+def test_edge_cases_golden(golden):
+    g = golden("tron_edge")
+    N, P = int(g["N"]), int(g["P"])
+    E = len(g["names"])
+    be = HipTron(N, P, E, [0, 1, 2], [0, 0, 0])
+    be.set_state(g["pre_board"], g["pre_heads"].T, g["pre_dirs"].T, g["pre_deaths"].T)
+    rew, term, win = be.step(np.ascontiguousarray(g["actions"].T))
+    s = be.state()
+    assert np.array_equal(s["board"], g["post_board"])
+    assert np.array_equal(s["heads"], g["post_heads"].T) and np.array_equal(s["dirs"], g["post_dirs"].T)
+    assert np.array_equal(s["deaths"], g["post_deaths"].T) and np.array_equal(rew, g["rewards"].T)
+    assert np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
+
+
+@pytest.mark.parametrize("name", ["n20p4", "n9p6"])
+def test_observe_golden(golden, name):
+    g = golden("tron_observe_" + name)
+    N, P = int(g["N"]), int(g["P"])
+    E = len(g["player"])
+    be = HipTron(N, P, E, list(range(P)), [0] * P)
+    be.set_state(g["board"], g["heads"].T, g["dirs"].T, g["deaths"].T)
+    ob, oh, od, ok = be.observe(g["player"])
+    assert np.array_equal(ob, g["obs_board"]) and np.array_equal(oh, g["obs_heads"].T)
+    assert np.array_equal(od, g["obs_dirs"].T) and np.array_equal(ok, g["obs_deaths"].T)
+
+
+@pytest.mark.parametrize("N,P,B,T", [(20, 4, 4096 + 37, 40), (40, 4, 1000, 60), (19, 3, 777, 40), (9, 8, 513, 30), (5, 2, 300, 20)])
+def test_step_vs_oracle_random(N, P, B, T):
+    """Seeded random actions, ragged batch sizes (not a multiple of the wave), odd boards (byte reset path)."""
+    rng = np.random.default_rng(N * 1000 + P)
+    sh, sd = O.tron_start_positions(N, P)
+    hip, orc = HipTron(N, P, B, sh, sd), OracleTron(N, P, B, sh, sd)
+    for t in range(T):
+        a = rng.integers(-1, 2, size=(P, B)).astype(np.int8)
+        auto = (t % 3) != 2
+        r1, t1, w1 = hip.step(a, auto_reset=auto)
+        r2, t2, w2 = orc.step(a, auto_reset=auto)
+        assert np.array_equal(r1, r2) and np.array_equal(t1, t2) and np.array_equal(w1, w2)
+        s1, s2 = hip.state(), orc.state()
+        for k in s1:
+            assert np.array_equal(s1[k], s2[k]), (k, t)
+
+
+def _rollout_pair(N, P, B, chunks, seed, first):
+    sh, sd = O.tron_start_positions(N, P)
+    hip = HipTron(N, P, B, sh, sd)
+    hip.tb.first_env_id = first
+    ost = O.TronState(N, P, B)
+    O.tron_reset(ost, sh, sd)
+    for T in chunks:
+        hip.tb.rollout(T, seed)
+        O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=8)
+    tb = hip.tb
+    got = dict(board=tb.board, heads=tb.heads, dirs=tb.dirs, deaths=tb.deaths, episode=tb.episode, tstep=tb.tstep,
+               n_episodes=tb.n_episodes, win_count=tb.win_count, len_sum=tb.len_sum, ret_sum=tb.ret_sum,
+               last_winners=tb.last_winners, last_len=tb.last_len)
+    for k, v in got.items():
+        want = getattr(ost, k)
+        have = v.cpu().numpy().view(want.dtype)
+        assert np.array_equal(have, want), k
+    return ost
+
+
+@pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 50)), (9, 8, 640, (40,))])
+def test_rollout_vs_oracle(N, P, B, chunks):
+    """Fused random-agent rollout == oracle rollout, bit for bit, including split launches (state carries over)."""
+    ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456)
+    assert ost.n_episodes.sum() > B
+
+
+def test_rollout_full_size_properties():
+    """BASELINE config 2 size (B=65536, N=20, P=4): size-independent properties of the fused rollout.
+    sum(len_sum)+sum(tstep) == B*T; wins <= episodes; board consistent with heads; shard invariance."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    B, T, seed = 65536, 128, 7
+    tb = TronBatch(20, 4, B)
+    tb.rollout(T, seed)
+    n_ep = tb.n_episodes.cpu().numpy().astype(np.int64)
+    assert int(tb.len_sum.sum().item()) + int(tb.tstep.sum().item()) == B * T
+    assert (tb.win_count.cpu().numpy().sum(axis=0) <= n_ep).all()
+    assert abs(tb.len_sum.sum().item() / max(1, n_ep.sum()) - 9.3) < 1.0          # mean episode 9.3
+    board = tb.board.cpu().numpy()
+    heads = tb.heads.cpu().numpy().astype(np.int64)
+    for p in range(4):
+        assert (board[np.arange(B), heads[p]] == p + 1).all()                      # every head sits on its own trail
+    assert (np.count_nonzero(board, axis=1) <= 4 * (tb.tstep.cpu().numpy() + 1)).all()
+    # shard invariance: envs [B/2, B) computed as their own shard give the same answer
+    half = TronBatch(20, 4, B // 2, first_env_id=B // 2)
+    half.rollout(T, seed)
+    assert torch.equal(half.board, tb.board[B // 2:]) and torch.equal(half.ret_sum, tb.ret_sum[:, B // 2:])
+    assert torch.equal(half.n_episodes, tb.n_episodes[B // 2:])
+
+
+def test_dropin_env_golden(golden):
+    """The BaseEnvironment drop-in (strings in, numpy tuples out) replays a golden game exactly."""
+    from colosseumrl_amd import get_environment
+    g = golden("tron_traj_n20p4")
+    env = get_environment("tron")("20;4")
+    names = {0: "forward", 1: "right", -1: "left"}
+    for e in range(3):
+        state, players = env.new_state()
+        assert state[0].dtype == np.int64 and state[1].tolist() == g["start_heads"].tolist()
+        for t in range(int(g["T"])):
+            acts = [names[int(a)] for a in g["actions"][t, :, e]]
+            state, players, rewards, terminal, winners = env.next_state(state, list(range(4)), acts)
+            assert state[1].tolist() == g["heads"][t, :, e].tolist()
+            assert state[3].tolist() == g["deaths"][t, :, e].tolist()
+            assert rewards.tolist() == g["rewards"][t, :, e].tolist() and rewards.dtype == np.int64
+            assert bool(terminal) == bool(g["terminal"][t, e])
+            assert players.tolist() == [p for p in range(4) if g["deaths"][t, p, e] == 0]
+            if terminal:
+                assert sum(1 << int(w) for w in winners) == g["winners"][t, e]
+                break
+            assert winners is None
+    assert env.valid_actions(state, 0) == ["forward", "right", "left"] and env.is_valid_action(state, 0, "x")
+    with pytest.raises(KeyError):
+        env.next_state(state, [0], ["up"])
+    # stale-move replay (reference :118,297-298): an omitted live player repeats its previous move
+    state, _ = env.new_state()
+    s1, *_ = env.next_state(state, [0, 1, 2, 3], ["left", "forward", "forward", "forward"])
+    s2, *_ = env.next_state(s1, [1, 2, 3], ["forward", "forward", "forward"])
+    s2b, *_ = env.next_state(s1, [0, 1, 2, 3], ["left", "forward", "forward", "forward"])
+    assert all(np.array_equal(a, b) for a, b in zip(s2, s2b))
+    obs = env.state_to_observation(s2, 2)
+    assert obs["board"].shape == (20, 20) and obs["heads"][0] == s2[1][2]
+
+
+def test_philox_device_kat():
+    import ctypes as C
+    import torch
+    from colosseumrl_amd import _native
+    lib = _native.require_gpu()
+    ctr = torch.tensor([[0, 0, 0, 0], [-1, -1, -1, -1], [0x243f6a88, 0x85a308d3 - 2**32, 0x13198a2e, 0x03707344]],
+                       dtype=torch.int32, device="cuda")
+    out = torch.zeros_like(ctr)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _native.check(lib.crl_philox4x32(C.c_void_p(ctr.data_ptr()), 0, 0, C.c_void_p(out.data_ptr()), 1, stream))
+    assert out[0].cpu().numpy().view(np.uint32).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    _native.check(lib.crl_philox4x32(C.c_void_p(ctr[1:].data_ptr()), 0xffffffff, 0xffffffff, C.c_void_p(out[1:].data_ptr()), 1, stream))
+    assert out[1].cpu().numpy().view(np.uint32).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    _native.check(lib.crl_philox4x32(C.c_void_p(ctr[2:].data_ptr()), 0xa4093822, 0x299f31d0, C.c_void_p(out[2:].data_ptr()), 1, stream))
+    assert out[2].cpu().numpy().view(np.uint32).tolist() == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_bad_arguments_fail_loudly():
+    import torch
+    from colosseumrl_amd import _native
+    from colosseumrl_amd.batched import TronBatch
+    tb = TronBatch(8, 2, 16)
+    with pytest.raises(ValueError):
+        tb.step(torch.zeros((2, 15), dtype=torch.int8, device="cuda"))
+    with pytest.raises(_native.NativeError):
+        TronBatch(8, 9, 4)
+    with pytest.raises(_native.NativeError):
+        TronBatch(200, 2, 4)

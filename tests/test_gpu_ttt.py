@@ -1,0 +1,119 @@
+"""HIP TicTacToe kernels vs golden vectors from the reference and vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from backends import HipTTT, OracleTTT
+from replay import replay_ttt
+from ttt_tree import count_games
+
+
+@pytest.mark.parametrize("name", ["2p_reset", "2p_noreset", "3p_reset", "3p_noreset", "4p_reset", "4p_noreset"])
+def test_traj_golden(golden, name):
+    assert replay_ttt(golden("ttt_traj_" + name), HipTTT) > 0
+
+
+def test_2p_exhaustive_tree_kat():
+    assert count_games(HipTTT) == (255168, 131184, 77904, 46080)
+
+
+@pytest.mark.parametrize("dims,K,P", [((3, 3), 3, 2), ((3, 5), 3, 3), ((3, 3, 3), 3, 4), ((5, 5), 4, 3), ((4, 8), 4, 5), ((2, 4, 4), 3, 8)])
+def test_lines_and_step_vs_oracle(dims, K, P):
+    B, T = 3001, 45
+    hip, orc = HipTTT(dims, K, P, B), OracleTTT(dims, K, P, B)
+    assert hip.lines() == orc.lines()
+    n_cells = int(np.prod(dims))
+    rng = np.random.default_rng(P * 100 + n_cells)
+    for t in range(T):
+        a = rng.integers(-1, n_cells, size=B).astype(np.int8)
+        # steer most moves to empty cells so games progress
+        v = orc.valid()
+        for e in range(0, B, 2):
+            cells = [c for c in range(n_cells) if (int(v[e]) >> c) & 1]
+            if cells:
+                a[e] = cells[int(rng.integers(0, len(cells)))]
+        auto = (t % 4) != 3
+        r1, t1, w1 = hip.step(a, auto_reset=auto)
+        r2, t2, w2 = orc.step(a, auto_reset=auto)
+        assert np.array_equal(r1, r2) and np.array_equal(t1, t2) and np.array_equal(w1, w2), t
+        assert np.array_equal(hip.board(), orc.board()) and np.array_equal(hip.winner(), orc.winner())
+        assert np.array_equal(hip.to_move(), orc.to_move()) and np.array_equal(hip.valid(), orc.valid())
+
+
+@pytest.mark.parametrize("dims,K,P,B,chunks", [((3, 3), 3, 2, 5000, (64, 13)), ((3, 5), 3, 3, 4099, (100,)),
+                                                ((3, 3, 3), 3, 4, 2048, (80,)), ((5, 5), 4, 3, 8192, (64, 64))])
+def test_rollout_vs_oracle(dims, K, P, B, chunks):
+    seed, first = 0xABCDEF0123, 555
+    hip = HipTTT(dims, K, P, B)
+    hip.tb.first_env_id = first
+    ost = O.TTTState(dims, K, P, B)
+    for T in chunks:
+        hip.tb.rollout(T, seed)
+        O.ttt_rollout(ost, seed, first, T, n_threads=8)
+    tb = hip.tb
+    for k in ("occ", "winner", "to_move", "episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
+    assert ost.n_episodes.sum() > B
+
+
+def test_rollout_full_size_properties():
+    """BASELINE config 3 size: 3-player 5x5 K=4, B=262144."""
+    import torch
+    from colosseumrl_amd.batched import TTTBatch
+    B, T, seed = 262144, 100, 3
+    tb = TTTBatch((5, 5), 4, 3, B)
+    tb.rollout(T, seed)
+    assert int(tb.len_sum.sum().item()) + int(tb.tstep.sum().item()) == B * T
+    n_ep = tb.n_episodes.cpu().numpy().astype(np.int64)
+    assert (tb.win_count.cpu().numpy().sum(axis=0) + tb.draw_count.cpu().numpy() == n_ep).all()
+    occ = tb.occ.cpu().numpy().view(np.uint32)
+    assert (occ[0] & occ[1]).max() == 0 and (occ[0] & occ[2]).max() == 0 and (occ[1] & occ[2]).max() == 0
+    half = TTTBatch((5, 5), 4, 3, B // 2, first_env_id=B // 2)
+    half.rollout(T, seed)
+    assert torch.equal(half.occ, tb.occ[:, B // 2:]) and torch.equal(half.win_count, tb.win_count[:, B // 2:])
+
+
+@pytest.mark.parametrize("name,env_name", [("2p", "tictactoe"), ("3p", "tictactoe_3p"), ("4p", "tictactoe_4p")])
+def test_dropin_env_golden(golden, name, env_name):
+    from colosseumrl_amd import get_environment
+    g = golden("ttt_traj_%s_noreset" % name)
+    shape = tuple(int(x) for x in g["shape"])
+    env = get_environment(env_name)()
+    for e in range(4):
+        state, players = env.new_state()
+        for t in range(int(g["T"])):
+            cell = int(g["action"][t, e])
+            astr = "" if cell < 0 else str(tuple(int(i) for i in np.unravel_index(cell, shape)))
+            va = env.valid_actions(state, players[0])
+            want = [str(tuple(int(i) for i in np.unravel_index(c, shape))) for c in range(int(np.prod(shape))) if (int(g["valid"][t, e]) >> c) & 1]
+            assert va == (want if want else [""])
+            if cell >= 0:
+                assert env.is_valid_action(state, players[0], astr) == ((int(g["valid"][t, e]) >> cell) & 1 == 1)
+            state, players, rewards, terminal, winners = env.next_state(state, players, [astr])
+            assert state[0].dtype == np.int8 and np.array_equal(state[0].ravel(), g["board"][t, e])
+            assert (state[1] is None and g["winner"][t, e] < 0) or state[1] == g["winner"][t, e]
+            assert players == [int(g["next_player"][t, e])] and rewards == [int(g["reward"][t, e])]
+            assert terminal == bool(g["terminal"][t, e])
+            assert (winners is None and g["winners"][t, e] < 0) or winners == [int(g["winners"][t, e])]
+    # python indexing semantics of the reference: negative indices wrap, out of range raises
+    state, players = env.new_state()
+    neg = "(" + ", ".join(["-1"] * len(shape)) + ")"
+    s2, *_ = env.next_state(state, [0], [neg])
+    assert s2[0].ravel()[-1] == 0
+    with pytest.raises(IndexError):
+        env.next_state(state, [0], ["(" + ", ".join(["7"] * len(shape)) + ")"])
+    assert env.is_valid_action(state, 0, "") is False
+
+
+@pytest.mark.parametrize("name,env_name", [("2p", "tictactoe"), ("3p", "tictactoe_3p"), ("4p", "tictactoe_4p")])
+def test_observation_golden(golden, name, env_name):
+    from colosseumrl_amd import get_environment
+    g = golden("ttt_observe_" + name)
+    env = get_environment(env_name)()
+    shape = tuple(int(x) for x in g["shape"])
+    for b, pl, want in list(zip(g["board"], g["player"], g["obs_board"]))[:24]:
+        obs = env.state_to_observation((b.reshape(shape), None), int(pl))
+        assert np.array_equal(obs["board"].ravel(), want)

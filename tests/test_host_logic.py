@@ -1,0 +1,103 @@
+"""CPU-only checks of the host layer: config parsing, spawn layout, registry, C-ABI symbols, loud failure."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import colosseumrl_amd
+from colosseumrl_amd import _native
+from colosseumrl_amd.BaseEnvironment import SimpleConfigParser
+from colosseumrl_amd.envs.tron import layout
+from colosseumrl_amd.envs.tron.TronGridEnvironment import TronGridEnvironment, create_tron_config, parse_tron_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_names():
+    names = colosseumrl_amd.available_environments()
+    for n in ("blokus", "tron", "tictactoe", "tictactoe_3p", "tictactoe_4p"):
+        assert n in names
+    assert colosseumrl_amd.get_environment("tron") is TronGridEnvironment
+    assert colosseumrl_amd.get_environment("tictactoe_3p")().observation_shape == {"board": (3, 5)}
+    with pytest.raises(KeyError):
+        colosseumrl_amd.get_environment("chess")
+
+
+def test_tron_config_strings():
+    assert tuple(parse_tron_config("")) == (19, 4, -1, False)
+    assert parse_tron_config("20") == [20, 4, -1, False]
+    assert parse_tron_config("20;6") == [20, 6, -1, False]
+    assert parse_tron_config("40;4;5;True") == [40, 4, 5, True]
+    assert parse_tron_config("40;4;-1;nope") == [40, 4, -1, False]
+    assert create_tron_config(20, 4, -1, False) == "20;4;-1;False"
+    env = TronGridEnvironment.create(21, 3)
+    assert (env.N, env.num_players, env.fully_observable) == (21, 3, True)
+    assert env.min_players == env.max_players == 3
+    assert env.observation_names() == ["board", "heads", "directions", "deaths"]
+    assert env.observation_shape["board"] == (21, 21)
+
+
+def test_spawn_layout_matches_reference_golden(golden):
+    g = golden("tron_reset")
+    for (N, P, ro, so), heads, dirs in zip(g["cfg"], g["heads"], g["dirs"]):
+        h, d = layout.start_positions(int(N), int(P), int(ro), [int(so)] * int(P))
+        assert h == heads[:P].tolist() and d == dirs[:P].tolist(), (N, P, ro, so)
+
+
+def test_spawn_layout_random_offsets_golden(golden):
+    """Tuple spawn offsets draw from numpy's global RNG seeded with int(time()) (reference :222-224,255)."""
+    g = golden("tron_reset_random")
+    for (N, P, ro, lo, hi, tval), heads, dirs in zip(g["cfg"], g["heads"], g["dirs"]):
+        env = TronGridEnvironment("%d;%d" % (N, P))
+        np.random.seed(int(tval))
+        h, d = env.generate_start_positions(int(ro), (int(lo), int(hi)))
+        assert h.tolist() == heads[:P].tolist() and d.tolist() == dirs[:P].tolist()
+
+
+def test_simple_config_parser():
+    p = SimpleConfigParser(int, (float, 0.5), (str, "x"))
+    assert p.parse("3") == [3, 0.5, "x"]
+    assert p.parse("3;1.5;None") == [3, 1.5, None]
+    with pytest.raises(ValueError):
+        SimpleConfigParser(int, int).parse("1")
+    assert p.store(7) == "7;0.5;x"
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads and exports exactly what include/colosseum_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "colosseum_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(crl_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 15
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    lib = C.CDLL(_native.LIB_PATH)
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_native.PROTOTYPES) == declared      # the ctypes table binds every one of them
+    _native.lib()
+    assert _native.lib().crl_version() >= 100
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must raise, not compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = TronGridEnvironment("20;4")
+    with pytest.raises(_native.NativeError):
+        env.new_state()
+    from colosseumrl_amd.batched import TTTBatch
+    with pytest.raises(_native.NativeError):
+        TTTBatch((3, 3), 3, 2, 4)
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under colosseumrl_amd/ may reference the oracle (test infrastructure)."""
+    pkg = os.path.join(ROOT, "colosseumrl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+                assert "/root/reference" not in text, f
