@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libcolosseum_hip.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 CRL_STEP_AUTO_RESET = 1
+CRL_ROLLOUT_NO_LDS = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -38,15 +39,15 @@ def build(force=False, verbose=False):
 
 class TronStats(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("episode", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
+                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
 
 
 class TTTStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
 
 
 class BlokusStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "len_sum", "score_sum", "tests")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum", "tests")]
 
 
 _VP, _I, _I64, _U32, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
@@ -61,7 +62,7 @@ PROTOTYPES = {
     "crl_tron_create": (_I, [_I, _I, _VP, _VP, C.POINTER(_VP)]),
     "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
-    "crl_tron_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, TronStats, _VP]),
+    "crl_tron_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, TronStats, _U32, _VP]),
     "crl_tron_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),
     "crl_ttt_lines": (_I, [_VP, _VP, _I]),

@@ -87,7 +87,7 @@ class TronBatch:
             self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
             self.winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
             # rollout bookkeeping
-            self.episode = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tcount = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.tstep = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.n_episodes = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.win_count = torch.zeros((P, B), dtype=torch.int32, device=dev)
@@ -106,7 +106,7 @@ class TronBatch:
                                            _ptr(self.dirs), _ptr(self.deaths), _stream()), "crl_tron_reset")
 
     def reset_stats(self):
-        for t in (self.episode, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.ret_sum,
+        for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.ret_sum,
                   self.last_winners, self.last_len):
             t.zero_()
 
@@ -121,15 +121,16 @@ class TronBatch:
         return self.rewards, self.terminal, self.winners
 
     def _stats(self):
-        return TronStats(*[t.data_ptr() for t in (self.episode, self.tstep, self.n_episodes, self.win_count,
+        return TronStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
                                                    self.len_sum, self.ret_sum, self.last_winners, self.last_len)])
 
     # -- T fused random-agent steps with auto-reset
-    def rollout(self, steps: int, seed: int = 0):
+    def rollout(self, steps: int, seed: int = 0, use_lds: bool = True):
         with torch.cuda.device(self.device):
             check(self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
                                              _ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths),
-                                             self._stats(), _stream()), "crl_tron_rollout")
+                                             self._stats(), 0 if use_lds else _native.CRL_ROLLOUT_NO_LDS, _stream()),
+                  "crl_tron_rollout")
 
     # -- state_to_observation for all games; player int8 [B]
     def observe(self, player: torch.Tensor):
@@ -182,7 +183,7 @@ class TTTBatch:
             self.reward = torch.zeros((B,), dtype=torch.int8, device=dev)
             self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
             self.winners = torch.zeros((B,), dtype=torch.int8, device=dev)
-            self.episode = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tcount = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.tstep = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.n_episodes = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.win_count = torch.zeros((P, B), dtype=torch.int32, device=dev)
@@ -225,7 +226,7 @@ class TTTBatch:
         return out
 
     def _stats(self):
-        return TTTStats(*[t.data_ptr() for t in (self.episode, self.tstep, self.n_episodes, self.win_count,
+        return TTTStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
                                                   self.draw_count, self.len_sum)])
 
     def rollout(self, steps: int, seed: int = 0):

@@ -9,69 +9,90 @@
 // Mapping: one lane per game (the <=P-player loop of a game is inherently serial: the result of
 // player i depends on what players j<i did in the same step); per-player state is
 // [P][B] struct-of-arrays so a wave's 64 lanes load 64 consecutive elements; the board is int8
-// [B][N*N], probed with P byte loads per step that are all issued up front (targets depend only on
-// the pre-step heads) and patched in registers for same-step interactions, so a step costs one
-// round of loads and one round of stores instead of P dependent round trips.
-// Resets are wave-cooperative: the wave ballots its terminal lanes and all 64 lanes clear each
-// such board with 16-byte stores.
+// [B][N*N].  A step issues its P byte probes together (the targets depend only on the pre-step
+// heads) and patches same-step interactions in registers, so it costs one round of loads and one
+// round of stores instead of P dependent round trips.
+//
+// Two rollout kernels (T fused steps, random agent, auto-reset):
+//   * LDS-resident (boards up to 25x25): every wave copies its 64 boards into LDS once, plays all T
+//     steps there (probe = ds_read_u8, a finished game clears its own 400-byte board with
+//     ds_write_b128), and writes the boards back once.  HBM sees 2*N*N bytes per game per LAUNCH.
+//   * global-memory (larger boards): boards stay in HBM/L2; resets are wave-cooperative 16-byte stores.
 #include "crl_common.hpp"
 
 namespace {
 
+struct TronGeom {
+    int N, NN;
+    uint32_t inv_n;    // floor(2^32 / N) + 1 : y = umulhi(h, inv_n) is exact for h < N*N <= 2^15
+};
+
 // ---- per-game step, everything in registers -------------------------------------------------
 template <int P>
 struct TronRegs {
-    int h[P];   // heads
+    int h[P];   // head (flat)
+    int x[P];   // head column
+    int y[P];   // head row
     int d[P];   // dirs
     int k[P];   // deaths
 };
 
 template <int P>
-__device__ __forceinline__ void tron_step_core(const int N, int8_t *__restrict__ bd, const bool valid,
+__device__ __forceinline__ void tron_split_heads(const TronGeom &g, TronRegs<P> &s)
+{
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        s.y[i] = (int)__umulhi((uint32_t)s.h[i], g.inv_n);
+        s.x[i] = s.h[i] - s.y[i] * g.N;
+    }
+}
+
+// BOARD is any byte-addressable view of this game's board (global or LDS pointer).
+// Straight-line code: every decision is a select, so a wave never diverges inside a step.
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_step_core(const TronGeom &g, BOARD bd, const bool valid,
                                                TronRegs<P> &s, const int (&act)[P],
                                                int (&rew)[P], int &term, int &wmask)
 {
-    int tgt[P], val[P], ndir[P];
+    const int N = g.N;
+    int tgt[P], val[P], ndir[P], nx[P], ny[P];
     bool oob[P], moved[P];
-    // phase 1: every live player's target cell, probes issued together (CyTronGrid.pyx:21-41)
+    // phase 1: every player's target cell, probes issued together (CyTronGrid.pyx:21-41).
+    // Probes of dead / out-of-board players read cell 0 and are ignored.
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int x0 = s.h[i] % N, y0 = s.h[i] / N;
         const int dir = (s.d[i] + act[i] + 4) & 3;
-        const int x = x0 + (dir == 1) - (dir == 3);
-        const int y = y0 + (dir == 2) - (dir == 0);
+        nx[i] = s.x[i] + (dir == 1) - (dir == 3);
+        ny[i] = s.y[i] + (dir == 2) - (dir == 0);
         ndir[i] = dir;
-        oob[i] = (x < 0) | (x >= N) | (y < 0) | (y >= N);
-        tgt[i] = y * N + x;
-        moved[i] = false;
-        val[i] = 0;
-        if (valid && s.k[i] == 0 && !oob[i]) val[i] = bd[tgt[i]];
+        oob[i] = ((unsigned)nx[i] >= (unsigned)N) | ((unsigned)ny[i] >= (unsigned)N);
+        tgt[i] = oob[i] ? 0 : ny[i] * N + nx[i];
+        val[i] = bd[tgt[i]];
     }
     // phase 2: the reference's sequential resolution, on registers (CyTronGrid.pyx:15-62)
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        if (s.k[i] > 0) continue;                       // :16 (may have been killed head-on by j < i)
+        const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
         int v = val[i];
 #pragma unroll
         for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
-            if (moved[j] && tgt[j] == tgt[i]) v = j + 1;
-        s.d[i] = ndir[i];                               // :44 direction is committed even if the move dies
-        if (oob[i]) {
-            s.k[i] = i + 1;                             // :47-48
-        } else if (v > 0) {
-            s.k[i] = v;                                 // :51-53
+            v = (moved[j] & (tgt[j] == tgt[i])) ? j + 1 : v;
+        const bool wall = run & oob[i];                 // :47-48
+        const bool crash = run & !oob[i] & (v > 0);     // :51-57
+        moved[i] = run & !oob[i] & (v <= 0);            // :60-62
+        s.d[i] = run ? ndir[i] : s.d[i];                // :44 direction is committed even if the move dies
+        s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
 #pragma unroll
-            for (int q = 0; q < P; ++q)                 // :56-57 owner's head is this very cell -> owner dies too
-                if (q == v - 1 && s.h[q] == tgt[i]) s.k[q] = i + 1;
-        } else {
-            moved[i] = true;                            // :60-62
-            s.h[i] = tgt[i];
-        }
+        for (int q = 0; q < P; ++q)                     // :56-57 owner's head is this very cell -> owner dies too
+            s.k[q] = (crash & (q == v - 1) & (s.h[q] == tgt[i])) ? i + 1 : s.k[q];
+        s.h[i] = moved[i] ? tgt[i] : s.h[i];
+        s.x[i] = moved[i] ? nx[i] : s.x[i];
+        s.y[i] = moved[i] ? ny[i] : s.y[i];
     }
     // phase 3: trail writes
 #pragma unroll
     for (int i = 0; i < P; ++i)
-        if (valid && moved[i]) bd[tgt[i]] = (int8_t)(i + 1);
+        if (valid & moved[i]) bd[tgt[i]] = (int8_t)(i + 1);
     // TronGridEnvironment.py:309-321
     int alive = 0;
     wmask = 0;
@@ -81,10 +102,66 @@ __device__ __forceinline__ void tron_step_core(const int N, int8_t *__restrict__
         wmask |= (s.k[i] == 0) << i;
     }
     term = alive <= 1;
-    if (!term) wmask = 0;
+    wmask = term ? wmask : 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) rew[i] = (s.k[i] > 0) ? -1 : (term ? 10 : 1);
 }
+
+// uniform random actions for step c of global env g (contract: include/colosseum_hip.h, crl_tron_rollout).
+// One Philox call = 4 words = 8 steps x 4 players: each word is a base-3 fraction giving 8 digits.
+// Scalars (no arrays) so the words stay in VGPRs; "current word" is w0, rotated every second step.
+struct TronRng4 {
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void refill(const uint32_t g, const uint32_t block, const uint32_t q,
+                                           const uint32_t k0, const uint32_t k1)
+    {
+        const philox_out r = philox4x32_10(g, block, q, CRL_TAG_TRON, k0, k1);
+        w0 = r.w[0]; w1 = r.w[1]; w2 = r.w[2]; w3 = r.w[3];
+    }
+    __device__ __forceinline__ void rotate() { w0 = w1; w1 = w2; w2 = w3; }
+    // position the stream at step c (kernel entry): drop the words of the (c & 7) >> 1 finished step pairs
+    __device__ __forceinline__ void seek(const uint32_t c)
+    {
+        const uint32_t pairs = (c & 7u) >> 1;
+        if (pairs >= 1) rotate();
+        if (pairs >= 2) rotate();
+        if (pairs >= 3) rotate();
+    }
+};
+
+template <int P>
+struct TronRng {
+    TronRng4 lo, hi;   // hi serves players 4..7 (unused when P <= 4)
+    __device__ __forceinline__ void start(const uint32_t g, const uint32_t c, const uint32_t k0, const uint32_t k1)
+    {
+        lo.refill(g, c >> 3, 0u, k0, k1);
+        lo.seek(c);
+        if (P > 4) { hi.refill(g, c >> 3, 1u, k0, k1); hi.seek(c); }
+    }
+    // actions of step c, then advance to step c+1
+    __device__ __forceinline__ void next(const uint32_t g, const uint32_t c, const uint32_t k0, const uint32_t k1, int (&act)[P])
+    {
+        const bool odd = c & 1u;
+        uint32_t v = lo.w0 * (odd ? 81u : 1u);          // 3^4: odd steps use digits 4..7 of the word
+        uint32_t u = (P > 4) ? hi.w0 * (odd ? 81u : 1u) : 0u;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            uint32_t &x = (i < 4) ? v : u;
+            const uint32_t a3 = __umulhi(x, 3u);        // next base-3 digit of the fraction x / 2^32
+            x *= 3u;
+            act[i] = (a3 == 0) ? 0 : ((a3 == 1) ? 1 : -1);
+        }
+        if (odd) {
+            if ((c & 7u) == 7u) {
+                lo.refill(g, (c + 1u) >> 3, 0u, k0, k1);
+                if (P > 4) hi.refill(g, (c + 1u) >> 3, 1u, k0, k1);
+            } else {
+                lo.rotate();
+                if (P > 4) hi.rotate();
+            }
+        }
+    }
+};
 
 // 16 bytes of a freshly reset board starting at byte offset `off` (heads stamped)
 template <int P>
@@ -106,7 +183,7 @@ __device__ __forceinline__ uint4 tron_fresh_chunk16(const crl_tron_cfg &cfg, con
     return make_uint4(v0, v1, v2, v3);
 }
 
-// all 64 lanes of the wave rewrite one board (wave-uniform pointer) to the start layout
+// all 64 lanes of the wave rewrite one board in global memory (wave-uniform pointer) to the start layout
 template <int P>
 __device__ __forceinline__ void tron_wave_reset_board(const crl_tron_cfg &cfg, int8_t *__restrict__ bd,
                                                       const int NN, const int lane)
@@ -122,6 +199,14 @@ __device__ __forceinline__ void tron_wave_reset_board(const crl_tron_cfg &cfg, i
             bd[c] = v;
         }
     }
+}
+
+template <int P>
+__device__ __forceinline__ void tron_regs_to_start(const crl_tron_cfg &cfg, const TronGeom &g, TronRegs<P> &s)
+{
+#pragma unroll
+    for (int p = 0; p < P; ++p) { s.h[p] = cfg.start_heads[p]; s.d[p] = cfg.start_dirs[p]; s.k[p] = 0; }
+    tron_split_heads<P>(g, s);
 }
 
 // ---- kernels ---------------------------------------------------------------------------------
@@ -168,13 +253,13 @@ tron_reset_players_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t
 
 template <int P>
 __global__ void __launch_bounds__(256)
-tron_step_kernel(const crl_tron_cfg cfg, const int64_t B,
+tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
                  int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
                  int8_t *__restrict__ deaths, const int8_t *__restrict__ actions,
                  int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
                  const uint32_t flags)
 {
-    const int N = cfg.N, NN = N * N;
+    const int NN = g.NN;
     const int lane = threadIdx.x & (CRL_WAVE - 1);
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = b < B;
@@ -188,9 +273,10 @@ tron_step_kernel(const crl_tron_cfg cfg, const int64_t B,
         s.k[p] = valid ? deaths[p * B + bb] : 1;
         act[p] = valid ? actions[p * B + bb] : 0;
     }
+    tron_split_heads<P>(g, s);
     int term, wm;
     int8_t *bd = board + bb * NN;
-    tron_step_core<P>(N, bd, valid, s, act, rew, term, wm);
+    tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
     if (valid) {
 #pragma unroll
         for (int p = 0; p < P; ++p) rewards[p * B + b] = (int8_t)rew[p];
@@ -206,10 +292,7 @@ tron_step_kernel(const crl_tron_cfg cfg, const int64_t B,
             m &= m - 1;
             tron_wave_reset_board<P>(cfg, board + (env0 + src) * NN, NN, lane);
         }
-        if (do_reset) {
-#pragma unroll
-            for (int p = 0; p < P; ++p) { s.h[p] = cfg.start_heads[p]; s.d[p] = cfg.start_dirs[p]; s.k[p] = 0; }
-        }
+        if (do_reset) tron_regs_to_start<P>(cfg, g, s);
     }
     if (valid) {
 #pragma unroll
@@ -221,53 +304,86 @@ tron_step_kernel(const crl_tron_cfg cfg, const int64_t B,
     }
 }
 
-// T fused steps, uniform random agent, auto-reset.  State lives in registers across the T steps;
-// boards stay in global memory (L2-resident at the benchmark sizes).
+// per-lane rollout bookkeeping shared by both rollout kernels
+template <int P>
+struct TronAcc {
+    int ret[P];
+    uint32_t wins[P];
+    uint32_t tc, ts, n_ep, len_sum;
+    int last_w, last_len;
+    __device__ __forceinline__ void load(const crl_tron_stats &st, const bool valid, const int64_t b)
+    {
+#pragma unroll
+        for (int p = 0; p < P; ++p) { ret[p] = 0; wins[p] = 0; }
+        tc = valid ? st.tcount[b] : 0;
+        ts = valid ? st.tstep[b] : 0;
+        n_ep = 0; len_sum = 0; last_w = -1; last_len = 0;
+    }
+    __device__ __forceinline__ void finish_episode(const int wm)
+    {
+        n_ep += 1;
+        len_sum += ts;
+        last_len = (int)ts;
+        last_w = wm;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wins[p] += (wm >> p) & 1;
+        ts = 0;
+    }
+    __device__ __forceinline__ void store(const crl_tron_stats &st, const int64_t B, const int64_t b) const
+    {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            st.ret_sum[p * B + b] += ret[p];
+            st.win_count[p * B + b] += wins[p];
+        }
+        st.tcount[b] = tc;
+        st.tstep[b] = ts;
+        st.n_episodes[b] += n_ep;
+        st.len_sum[b] += len_sum;
+        if (last_w >= 0) {
+            st.last_winners[b] = (uint8_t)last_w;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+    }
+};
+
+// T fused steps, boards in global memory (any board size)
 template <int P>
 __global__ void __launch_bounds__(256)
-tron_rollout_kernel(const crl_tron_cfg cfg, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
-                    const uint64_t first_env_id, const int T,
+tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, const uint32_t seed_lo,
+                    const uint32_t seed_hi, const uint64_t first_env_id, const int T,
                     int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
                     int8_t *__restrict__ deaths, const crl_tron_stats st)
 {
-    const int N = cfg.N, NN = N * N;
+    const int NN = g.NN;
     const int lane = threadIdx.x & (CRL_WAVE - 1);
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = b < B;
     const int64_t bb = valid ? b : 0;
     const int64_t env0 = b - lane;
     TronRegs<P> s;
-    int act[P], rew[P], ret[P];
-    uint32_t wins[P];
+    int act[P], rew[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         s.h[p] = valid ? heads[p * B + bb] : 0;
         s.d[p] = valid ? dirs[p * B + bb] : 0;
         s.k[p] = valid ? deaths[p * B + bb] : 1;
-        ret[p] = 0;
-        wins[p] = 0;
     }
-    uint32_t ep = valid ? st.episode[bb] : 0, ts = valid ? st.tstep[bb] : 0;
-    uint32_t n_ep = 0, len_sum = 0;
-    int last_w = -1, last_len = 0;
-    const uint32_t g = (uint32_t)(first_env_id + (uint64_t)bb);
+    tron_split_heads<P>(g, s);
+    TronAcc<P> acc;
+    acc.load(st, valid, bb);
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+    TronRng<P> rng;
+    rng.start(gid, acc.tc, seed_lo, seed_hi);
     int8_t *bd = board + bb * NN;
     for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int q = 0; q < (P + 3) / 4; ++q) {
-            const philox_out r = philox4x32_10(g, ep, ts, CRL_TAG_TRON | (uint32_t)q, seed_lo, seed_hi);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (q * 4 + j < P) {
-                    const uint32_t a3 = __umulhi(r.w[j], 3u);
-                    act[q * 4 + j] = (a3 == 0) ? 0 : ((a3 == 1) ? 1 : -1);
-                }
-        }
+        rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+        acc.tc += 1;
         int term, wm;
-        tron_step_core<P>(N, bd, valid, s, act, rew, term, wm);
-        ts += 1;
+        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        acc.ts += 1;
 #pragma unroll
-        for (int p = 0; p < P; ++p) ret[p] += rew[p];
+        for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
         const bool fin = valid && term;
         unsigned long long m = __ballot(fin);
         if (m) {
@@ -279,19 +395,8 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const int64_t B, const uint32_t seed
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (fin) {
-                n_ep += 1;
-                len_sum += ts;
-                last_len = (int)ts;
-                last_w = wm;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    wins[p] += (wm >> p) & 1;
-                    s.h[p] = cfg.start_heads[p];
-                    s.d[p] = cfg.start_dirs[p];
-                    s.k[p] = 0;
-                }
-                ep += 1;
-                ts = 0;
+                acc.finish_episode(wm);
+                tron_regs_to_start<P>(cfg, g, s);
             }
         }
     }
@@ -301,17 +406,95 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const int64_t B, const uint32_t seed
             heads[p * B + b] = (int16_t)s.h[p];
             dirs[p * B + b] = (int8_t)s.d[p];
             deaths[p * B + b] = (int8_t)s.k[p];
-            st.ret_sum[p * B + b] += ret[p];
-            st.win_count[p * B + b] += wins[p];
         }
-        st.episode[b] = ep;
-        st.tstep[b] = ts;
-        st.n_episodes[b] += n_ep;
-        st.len_sum[b] += len_sum;
-        if (last_w >= 0) {
-            st.last_winners[b] = (uint8_t)last_w;
-            st.last_len[b] = (uint16_t)last_len;
+        acc.store(st, B, b);
+    }
+}
+
+// T fused steps, boards resident in LDS.  256 threads = 4 independent waves; wave w owns the LDS slab
+// [w*64*stride, (w+1)*64*stride) holding its 64 boards (stride = N*N rounded up to 16).
+// No workgroup barrier is needed: a lane only ever touches its own board, and the copy in / copy out
+// of a wave's slab is done by that wave.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stride, const int64_t B,
+                        const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                        int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                        int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    const int NN = g.NN;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : 0;
+    const int64_t env0 = b - lane;                              // first game of this wave
+    const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
+    int8_t *slab = lds + (size_t)wave * CRL_WAVE * stride;
+    int8_t *gslab = board + env0 * NN;
+    // ---- copy in: HBM -> LDS, coalesced 16-byte pieces (stride == NN when NN % 16 == 0)
+    if (stride == NN) {
+        const int bytes = n_env * NN;
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16)
+            *reinterpret_cast<uint4 *>(slab + off) = *reinterpret_cast<const uint4 *>(gslab + off);
+    } else {
+        for (int e = 0; e < n_env; ++e)
+            for (int c = lane; c < NN; c += CRL_WAVE) slab[e * stride + c] = gslab[(int64_t)e * NN + c];
+    }
+    TronRegs<P> s;
+    int act[P], rew[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        s.h[p] = valid ? heads[p * B + bb] : 0;
+        s.d[p] = valid ? dirs[p * B + bb] : 0;
+        s.k[p] = valid ? deaths[p * B + bb] : 1;
+    }
+    tron_split_heads<P>(g, s);
+    TronAcc<P> acc;
+    acc.load(st, valid, bb);
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+    TronRng<P> rng;
+    rng.start(gid, acc.tc, seed_lo, seed_hi);
+    int8_t *bd = slab + lane * stride;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // slab written by other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = 0; t < T; ++t) {
+        rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+        acc.tc += 1;
+        int term, wm;
+        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        acc.ts += 1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
+        if (valid && term) {
+            // new_state for this game only: the lane clears its own board (ds_write_b128) and stamps the heads
+            for (int off = 0; off < stride; off += 16) *reinterpret_cast<uint4 *>(bd + off) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) bd[cfg.start_heads[p]] = (int8_t)(p + 1);
+            acc.finish_episode(wm);
+            tron_regs_to_start<P>(cfg, g, s);
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- copy out: LDS -> HBM
+    if (stride == NN) {
+        const int bytes = n_env * NN;
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16)
+            *reinterpret_cast<uint4 *>(gslab + off) = *reinterpret_cast<const uint4 *>(slab + off);
+    } else {
+        for (int e = 0; e < n_env; ++e)
+            for (int c = lane; c < NN; c += CRL_WAVE) gslab[(int64_t)e * NN + c] = slab[e * stride + c];
+    }
+    if (valid) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            heads[p * B + b] = (int16_t)s.h[p];
+            dirs[p * B + b] = (int8_t)s.d[p];
+            deaths[p * B + b] = (int8_t)s.k[p];
+        }
+        acc.store(st, B, b);
     }
 }
 
@@ -335,8 +518,9 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
 #pragma unroll
                 for (int s8 = 0; s8 < 32; s8 += 8) {
                     const int c = (int)((w[q] >> s8) & 0xffu);
-                    const int n = c > 0 ? ((c - pl + P) % P) + 1 : c;     // CyTronGrid.pyx:70-71
-                    r |= (uint32_t)(n & 0xff) << s8;
+                    int n = c - pl;                                        // CyTronGrid.pyx:70-71, c in 1..P
+                    n = n < 0 ? n + P : n;
+                    r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
                 }
                 o[q] = r;
             }
@@ -344,7 +528,9 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
         } else {
             const int pl = player[i / NN] + 1;
             const int c = board[i];
-            obs[i] = (int8_t)(c > 0 ? ((c - pl + P) % P) + 1 : c);
+            int n = c - pl;
+            n = n < 0 ? n + P : n;
+            obs[i] = (int8_t)(c > 0 ? n + 1 : c);
         }
     }
 }
@@ -364,7 +550,8 @@ tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, 
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         int hh = 0, dd = 0, kk = 0;
-        const int src = (i + pl) % P;                   // TronGridEnvironment.py:392-396
+        int src = i + pl;                                // TronGridEnvironment.py:392-396
+        src = src >= P ? src - P : src;
 #pragma unroll
         for (int q = 0; q < P; ++q) { hh = (q == src) ? h[q] : hh; dd = (q == src) ? d[q] : dd; kk = (q == src) ? k[q] : kk; }
         oh[i * B + b] = (int16_t)hh;
@@ -374,6 +561,17 @@ tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, 
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+inline TronGeom geom_of(const crl_tron_cfg &cfg)
+{
+    TronGeom g;
+    g.N = cfg.N;
+    g.NN = cfg.N * cfg.N;
+    g.inv_n = (uint32_t)(0x100000000ull / (uint64_t)cfg.N) + 1u;
+    return g;
+}
+
+constexpr int kLdsBudget = 160 * 1024;   // MI355X: 160 KiB LDS per CU, one 256-thread workgroup per CU
 
 } // namespace
 
@@ -452,8 +650,9 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
     CRL_REQUIRE(!(flags & CRL_STEP_AUTO_RESET) || ((cfg.N * cfg.N) % 16 != 0) || (((uintptr_t)board & 15) == 0),
                 "crl_tron_step: board must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    const TronGeom g = geom_of(cfg);
     TRON_DISPATCH_P(cfg.P, {
-        hipLaunchKernelGGL((tron_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B,
+        hipLaunchKernelGGL((tron_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
                            board, heads, dirs, deaths, actions, rewards, terminal, winners, flags);
     });
     CRL_LAUNCH_CHECK();
@@ -462,20 +661,33 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
 
 int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
-                     crl_tron_stats st, void *stream)
+                     crl_tron_stats st, uint32_t flags, void *stream)
 {
     TRON_CTX_CHECK("crl_tron_rollout");
     CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_rollout: NULL state pointer");
-    CRL_REQUIRE(st.episode && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
+    CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
+    CRL_REQUIRE((flags & ~CRL_ROLLOUT_NO_LDS) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
-    CRL_REQUIRE(((cfg.N * cfg.N) % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
+    const int NN = cfg.N * cfg.N;
+    CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
     if (T == 0) return CRL_OK;
     hipStream_t s = (hipStream_t)stream;
+    const TronGeom g = geom_of(cfg);
+    const int stride = (NN + 15) & ~15;
+    const size_t lds_bytes = (size_t)256 * stride;
+    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && lds_bytes <= (size_t)kLdsBudget && (((uintptr_t)board & 15) == 0);
     TRON_DISPATCH_P(cfg.P, {
-        hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+        if (use_lds) {
+            CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL((tron_rollout_lds_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), lds_bytes, s, cfg, g, stride, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+        } else {
+            hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+        }
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

@@ -115,16 +115,23 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
 #pragma unroll
     for (int p = 0; p < P; ++p) { o[p] = occ[p * B + b]; wins[p] = 0; }
     int w = winner[b], tm = to_move[b];
-    uint32_t ep = st.episode[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
+    uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
+    philox_out rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
     for (int t = 0; t < T; ++t) {
         uint32_t all = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) all |= o[p];
         const uint32_t empty = dd.full & ~all;
         const int n_empty = __popc(empty);
-        const philox_out rnd = philox4x32_10(g, ep, ts, CRL_TAG_TTT, seed_lo, seed_hi);
-        const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(rnd.w[0], (uint32_t)n_empty)) : -1;
+        const uint32_t sel = tc & 3u;                  // one Philox call serves 4 steps
+        uint32_t word = rnd.w[0];
+        word = (sel == 1) ? rnd.w[1] : word;
+        word = (sel == 2) ? rnd.w[2] : word;
+        word = (sel == 3) ? rnd.w[3] : word;
+        const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
+        tc += 1;
+        if ((tc & 3u) == 0) rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
         int r, term, ws;
         ttt_step_core<P>(dd, o, w, tm, action, r, term, ws);
         ts += 1;
@@ -134,14 +141,14 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             draws += (ws < 0);
 #pragma unroll
             for (int p = 0; p < P; ++p) { wins[p] += (ws == p); o[p] = 0; }
-            w = -1; tm = 0; ep += 1; ts = 0;
+            w = -1; tm = 0; ts = 0;
         }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) { occ[p * B + b] = o[p]; st.win_count[p * B + b] += wins[p]; }
     winner[b] = (int8_t)w;
     to_move[b] = (int8_t)tm;
-    st.episode[b] = ep;
+    st.tcount[b] = tc;
     st.tstep[b] = ts;
     st.n_episodes[b] += n_ep;
     st.draw_count[b] += draws;
@@ -338,7 +345,7 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 {
     TTT_CTX_CHECK("crl_ttt_rollout");
     CRL_REQUIRE(occ && winner && to_move, "crl_ttt_rollout: NULL state pointer");
-    CRL_REQUIRE(st.episode && st.tstep && st.n_episodes && st.win_count && st.draw_count && st.len_sum, "crl_ttt_rollout: NULL stats pointer");
+    CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.draw_count && st.len_sum, "crl_ttt_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_ttt_rollout: T=%d out of range", T);
     if (T == 0) return CRL_OK;
     const ttt_dirs dd = dirs_of(ctx);

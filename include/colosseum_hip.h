@@ -47,6 +47,8 @@ extern "C" {
 
 /* flags for *_step */
 #define CRL_STEP_AUTO_RESET 1u  /* after writing the step outputs, reset every env that just became terminal */
+/* flags for crl_tron_rollout */
+#define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
 
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 
@@ -89,8 +91,8 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
 
 /* per-env rollout bookkeeping, all DEVICE arrays (any may NOT be NULL) */
 typedef struct {
-    uint32_t *episode;      /* [B] episode index  = RNG counter word 1 */
-    uint32_t *tstep;        /* [B] steps taken in the current episode = RNG counter word 2 */
+    uint32_t *tcount;       /* [B] rollout steps this env has taken so far = the RNG counter */
+    uint32_t *tstep;        /* [B] steps taken in the current episode */
     uint32_t *n_episodes;   /* [B] episodes finished */
     uint32_t *win_count;    /* [P][B] */
     uint32_t *len_sum;      /* [B] */
@@ -101,12 +103,16 @@ typedef struct {
 
 /* T fused env-steps per env with a uniform random agent and auto-reset (the benchmark loop of
  * BASELINE.md section 3; no reference counterpart -- the reference steps one env per Python call).
- * action of player p at (global env g = first_env_id + b, episode e, step t):
- *   w = Philox4x32-10(ctr = {g, e, t, 0x54520000 | (p >> 2)}, key = {seed lo, seed hi})[p & 3]
- *   a = mulhi32(w, 3): 0 -> forward, 1 -> right, 2 -> left */
+ * RNG contract, keyed by (seed, global env g = first_env_id + b, the env's step count c = tcount, player p);
+ * one Philox call serves 8 consecutive steps of up to 4 players:
+ *   W = Philox4x32-10(ctr = {g, c >> 3, p >> 2, 0x54520000}, key = {seed lo, seed hi})
+ *   j = c & 7;  v = W[j >> 1] * 3^((j & 1) * 4 + (p & 3))  (mod 2^32)
+ *   a = mulhi32(v, 3): 0 -> forward, 1 -> right, 2 -> left        (base-3 digits of the fraction W/2^32)
+ * Boards up to 25x25 are played out of LDS (one copy in / one copy out per launch); larger boards, or
+ * flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  Both give identical results. */
 int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
-                     crl_tron_stats stats, void *stream);
+                     crl_tron_stats stats, uint32_t flags, void *stream);
 
 /* replaces CyTronGrid.relative_player_inplace (CyTronGrid.pyx:65-71) + the rolls of
  * TronGridEnvironment.state_to_observation (TronGridEnvironment.py:385-405), fully observable branch.
@@ -139,12 +145,13 @@ int crl_ttt_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, uint32_t *
 int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, int rel_mod,
                   int8_t *board, void *stream);
 typedef struct {
-    uint32_t *episode, *tstep, *n_episodes;
+    uint32_t *tcount, *tstep, *n_episodes;   /* tcount = the env's rollout step count (RNG counter) */
     uint32_t *win_count;   /* [P][B] */
     uint32_t *draw_count;  /* [B] */
     uint32_t *len_sum;     /* [B] */
 } crl_ttt_stats;
-/* random agent: r = mulhi32(Philox(ctr={g,e,t,0x54540000},seed)[0], n_empty); r-th empty cell in row-major order */
+/* random agent, one Philox call per 4 steps: with c = tcount,
+ *   r = mulhi32(Philox(ctr={g, c >> 2, 0, 0x54540000}, seed)[c & 3], n_empty); r-th empty cell in row-major order */
 int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                     uint32_t *occ, int8_t *winner, int8_t *to_move, crl_ttt_stats stats, void *stream);
 

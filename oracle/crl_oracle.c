@@ -192,17 +192,21 @@ void orc_tron_rollout(int N, int P, int64_t B, uint64_t seed, uint64_t first_env
         int8_t *bd = board + b * NN;
         int h[ORC_TRON_MAX_P], d[ORC_TRON_MAX_P], k[ORC_TRON_MAX_P], a[ORC_TRON_MAX_P], r[ORC_TRON_MAX_P];
         for (int p = 0; p < P; ++p) { h[p] = heads[p * B + b]; d[p] = dirs[p * B + b]; k[p] = deaths[p * B + b]; }
-        uint32_t ep = st.episode[b], ts = st.tstep[b];
+        uint32_t tc = st.tcount[b], ts = st.tstep[b];
         uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
+        static const uint32_t POW3[8] = { 1u, 3u, 9u, 27u, 81u, 243u, 729u, 2187u };
         for (int t = 0; t < T; ++t) {
             for (int q = 0; q < (P + 3) / 4; ++q) {
-                uint32_t ctr[4] = { g, ep, ts, ORC_TAG_TRON | (uint32_t)q }, w[4];
+                uint32_t ctr[4] = { g, tc >> 3, (uint32_t)q, ORC_TAG_TRON }, w[4];
                 orc_philox4x32(ctr, key, w);
-                for (int j = 0; j < 4 && q * 4 + j < P; ++j) {
-                    uint32_t a3 = mulhi32(w[j], 3u);
-                    a[q * 4 + j] = a3 == 0 ? 0 : (a3 == 1 ? 1 : -1);
+                uint32_t j = tc & 7u, word = w[j >> 1];
+                for (int i = 0; i < 4 && q * 4 + i < P; ++i) {
+                    uint32_t v = word * POW3[(j & 1u) * 4u + (uint32_t)i];
+                    uint32_t a3 = mulhi32(v, 3u);
+                    a[q * 4 + i] = a3 == 0 ? 0 : (a3 == 1 ? 1 : -1);
                 }
             }
+            tc += 1;
             int term, wm;
             tron_step_env(N, P, bd, h, d, k, a, r, &term, &wm);
             ts += 1;
@@ -218,13 +222,13 @@ void orc_tron_rollout(int N, int P, int64_t B, uint64_t seed, uint64_t first_env
                     h[p] = start_heads[p]; d[p] = start_dirs[p]; k[p] = 0;
                     bd[start_heads[p]] = (int8_t)(p + 1);
                 }
-                ep += 1; ts = 0;
+                ts = 0;
             }
         }
         for (int p = 0; p < P; ++p) {
             heads[p * B + b] = (int16_t)h[p]; dirs[p * B + b] = (int8_t)d[p]; deaths[p * B + b] = (int8_t)k[p];
         }
-        st.episode[b] = ep; st.tstep[b] = ts;
+        st.tcount[b] = tc; st.tstep[b] = ts;
     }
 }
 
@@ -344,16 +348,17 @@ void orc_ttt_rollout(int n_cells, int P, int n_lines, const uint32_t *lines, int
         uint32_t o[ORC_TTT_MAX_P];
         for (int p = 0; p < P; ++p) o[p] = occ[p * B + b];
         int w = winner[b], tm = to_move[b];
-        uint32_t ep = st.episode[b], ts = st.tstep[b];
+        uint32_t tc = st.tcount[b], ts = st.tstep[b];
         uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
         for (int t = 0; t < T; ++t) {
             uint32_t all = 0;
             for (int p = 0; p < P; ++p) all |= o[p];
             uint32_t empty = full & ~all;
             int n_empty = __builtin_popcount(empty);
-            uint32_t ctr[4] = { g, ep, ts, ORC_TAG_TTT }, rnd[4];
+            uint32_t ctr[4] = { g, tc >> 2, 0u, ORC_TAG_TTT }, rnd[4];
             orc_philox4x32(ctr, key, rnd);
-            int action = n_empty ? nth_set_bit(empty, (int)mulhi32(rnd[0], (uint32_t)n_empty)) : -1;
+            int action = n_empty ? nth_set_bit(empty, (int)mulhi32(rnd[tc & 3u], (uint32_t)n_empty)) : -1;
+            tc += 1;
             int r, term, ws;
             ttt_step_env(n_cells, P, n_lines, lines, o, &w, &tm, action, &r, &term, &ws);
             ts += 1;
@@ -362,11 +367,11 @@ void orc_ttt_rollout(int n_cells, int P, int n_lines, const uint32_t *lines, int
                 st.len_sum[b] += ts;
                 if (ws >= 0) st.win_count[ws * B + b] += 1; else st.draw_count[b] += 1;
                 for (int p = 0; p < P; ++p) o[p] = 0;
-                w = -1; tm = 0; ep += 1; ts = 0;
+                w = -1; tm = 0; ts = 0;
             }
         }
         for (int p = 0; p < P; ++p) occ[p * B + b] = o[p];
         winner[b] = (int8_t)w; to_move[b] = (int8_t)tm;
-        st.episode[b] = ep; st.tstep[b] = ts;
+        st.tcount[b] = tc; st.tstep[b] = ts;
     }
 }

@@ -72,7 +72,7 @@ class TronState:
         self.dirs = np.zeros((P, B), dtype=np.int8)
         self.deaths = np.zeros((P, B), dtype=np.int8)
         # rollout bookkeeping
-        self.episode = np.zeros(B, dtype=np.uint32)
+        self.tcount = np.zeros(B, dtype=np.uint32)
         self.tstep = np.zeros(B, dtype=np.uint32)
         self.n_episodes = np.zeros(B, dtype=np.uint32)
         self.win_count = np.zeros((P, B), dtype=np.uint32)
@@ -91,7 +91,7 @@ class TronState:
 
 class _TronStats(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("episode", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
+                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
 
 
 def tron_reset(st, start_heads, start_dirs):
@@ -153,7 +153,7 @@ class TTTState:
         self.occ = np.zeros((P, B), dtype=np.uint32)
         self.winner = np.full(B, -1, dtype=np.int8)
         self.to_move = np.zeros(B, dtype=np.int8)
-        self.episode = np.zeros(B, dtype=np.uint32)
+        self.tcount = np.zeros(B, dtype=np.uint32)
         self.tstep = np.zeros(B, dtype=np.uint32)
         self.n_episodes = np.zeros(B, dtype=np.uint32)
         self.win_count = np.zeros((P, B), dtype=np.uint32)
@@ -170,7 +170,7 @@ class TTTState:
 
 
 class _TTTStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
 
 
 def ttt_step(st, action):

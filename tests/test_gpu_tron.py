@@ -64,17 +64,17 @@ def test_step_vs_oracle_random(N, P, B, T):
             assert np.array_equal(s1[k], s2[k]), (k, t)
 
 
-def _rollout_pair(N, P, B, chunks, seed, first):
+def _rollout_pair(N, P, B, chunks, seed, first, use_lds=True):
     sh, sd = O.tron_start_positions(N, P)
     hip = HipTron(N, P, B, sh, sd)
     hip.tb.first_env_id = first
     ost = O.TronState(N, P, B)
     O.tron_reset(ost, sh, sd)
     for T in chunks:
-        hip.tb.rollout(T, seed)
+        hip.tb.rollout(T, seed, use_lds=use_lds)
         O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=8)
     tb = hip.tb
-    got = dict(board=tb.board, heads=tb.heads, dirs=tb.dirs, deaths=tb.deaths, episode=tb.episode, tstep=tb.tstep,
+    got = dict(board=tb.board, heads=tb.heads, dirs=tb.dirs, deaths=tb.deaths, tcount=tb.tcount, tstep=tb.tstep,
                n_episodes=tb.n_episodes, win_count=tb.win_count, len_sum=tb.len_sum, ret_sum=tb.ret_sum,
                last_winners=tb.last_winners, last_len=tb.last_len)
     for k, v in got.items():
@@ -84,10 +84,13 @@ def _rollout_pair(N, P, B, chunks, seed, first):
     return ost
 
 
-@pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 50)), (9, 8, 640, (40,))])
-def test_rollout_vs_oracle(N, P, B, chunks):
-    """Fused random-agent rollout == oracle rollout, bit for bit, including split launches (state carries over)."""
-    ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456)
+@pytest.mark.parametrize("use_lds", [True, False])
+@pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
+                                           (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,))])
+def test_rollout_vs_oracle(N, P, B, chunks, use_lds):
+    """Fused random-agent rollout == oracle rollout, bit for bit, for the LDS-resident and the global-memory
+    kernel, ragged batches, odd boards (byte copy path) and split launches (state and RNG position carry over)."""
+    ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, use_lds=use_lds)
     assert ost.n_episodes.sum() > B
 
 

@@ -53,7 +53,7 @@ def test_rollout_vs_oracle(dims, K, P, B, chunks):
         hip.tb.rollout(T, seed)
         O.ttt_rollout(ost, seed, first, T, n_threads=8)
     tb = hip.tb
-    for k in ("occ", "winner", "to_move", "episode", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
+    for k in ("occ", "winner", "to_move", "tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
         want = getattr(ost, k)
         assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
     assert ost.n_episodes.sum() > B

@@ -96,34 +96,53 @@ def test_observe(golden, name):
     assert np.array_equal(od, g["obs_dirs"].T) and np.array_equal(ok, g["obs_deaths"].T)
 
 
-def test_rollout_equals_stepwise():
-    """The fused rollout is the same computation as explicit Philox actions + step + reset."""
-    N, P, B, T, seed, first = 12, 4, 37, 50, 0x1234567890, 1000
+def tron_random_actions(seed, g, c, P):
+    """The documented RNG contract (include/colosseum_hip.h, crl_tron_rollout), restated in Python."""
+    acts = []
+    for p in range(P):
+        w = O.philox4x32([g, c >> 3, p >> 2, O.TAG_TRON], [seed & 0xffffffff, seed >> 32])
+        j = c & 7
+        v = (int(w[j >> 1]) * 3 ** ((j & 1) * 4 + (p & 3))) & 0xffffffff
+        acts.append([0, 1, -1][(v * 3) >> 32])
+    return acts
+
+
+@pytest.mark.parametrize("P,T0", [(4, 0), (6, 5)])
+def test_rollout_equals_stepwise(P, T0):
+    """The fused rollout is the same computation as explicit contract actions + step + reset
+    (also when it starts at a step count that is not a multiple of the 8-step Philox block)."""
+    N, B, T, seed, first = 12, 37, 50, 0x1234567890, 1000
     sh, sd = O.tron_start_positions(N, P)
     a = O.TronState(N, P, B)
     O.tron_reset(a, sh, sd)
+    a.tcount[:] = T0
     O.tron_rollout(a, seed, first, T, sh, sd)
     b = OracleTron(N, P, B, sh, sd)
-    ep = np.zeros(B, np.uint32)
     ts = np.zeros(B, np.uint32)
     n_ep = np.zeros(B, np.uint32)
     ret = np.zeros((P, B), np.int64)
     for t in range(T):
         acts = np.zeros((P, B), np.int8)
         for e in range(B):
-            w = O.philox4x32([first + e, ep[e], ts[e], O.TAG_TRON], [seed & 0xffffffff, seed >> 32])
-            for p in range(P):
-                a3 = (int(w[p]) * 3) >> 32
-                acts[p, e] = [0, 1, -1][a3]
+            acts[:, e] = tron_random_actions(seed, first + e, T0 + t, P)
         r, term, win = b.step(acts, auto_reset=True)
         ret += r
         ts += 1
         n_ep += term
-        ep += term
         ts[term.astype(bool)] = 0
     s = b.state()
     assert np.array_equal(a.board, s["board"]) and np.array_equal(a.heads, s["heads"])
     assert np.array_equal(a.deaths, s["deaths"]) and np.array_equal(a.dirs, s["dirs"])
-    assert np.array_equal(a.episode, ep) and np.array_equal(a.tstep, ts) and np.array_equal(a.n_episodes, n_ep)
+    assert (a.tcount == T0 + T).all() and np.array_equal(a.tstep, ts) and np.array_equal(a.n_episodes, n_ep)
     assert np.array_equal(a.ret_sum, ret) and n_ep.sum() > 0
     assert a.len_sum.sum() + a.tstep.sum() == B * T
+
+
+def test_random_agent_is_uniform():
+    """Base-3 digit extraction: every (step mod 8, player) slot is uniform over the three moves."""
+    counts = np.zeros((8, 4, 3), np.int64)
+    for g in range(1500):
+        for c in range(8):
+            for p, a in enumerate(tron_random_actions(42, g, c, 4)):
+                counts[c, p, a] += 1
+    assert (np.abs(counts / 1500.0 - 1 / 3) < 0.05).all()

@@ -48,7 +48,7 @@ def test_rollout_equals_stepwise():
     a = O.TTTState(dims, K, P, B)
     O.ttt_rollout(a, seed, first, T)
     b = OracleTTT(dims, K, P, B)
-    ep = np.zeros(B, np.uint32)
+    n_ep = 0
     ts = np.zeros(B, np.uint32)
     wins = np.zeros((P, B), np.uint32)
     draws = np.zeros(B, np.uint32)
@@ -58,17 +58,17 @@ def test_rollout_equals_stepwise():
         for e in range(B):
             cells = [c for c in range(15) if (int(valid[e]) >> c) & 1]
             if cells:
-                w = O.philox4x32([first + e, ep[e], ts[e], O.TAG_TTT], [seed, 0])
-                act[e] = cells[(int(w[0]) * len(cells)) >> 32]
+                w = O.philox4x32([first + e, t >> 2, 0, O.TAG_TTT], [seed, 0])
+                act[e] = cells[(int(w[t & 3]) * len(cells)) >> 32]
         r, term, win = b.step(act, auto_reset=True)
         ts += 1
         tm = term.astype(bool)
         for p in range(P):
             wins[p] += (tm & (win == p))
         draws += (tm & (win < 0))
-        ep += term
+        n_ep += int(term.sum())
         ts[tm] = 0
     assert np.array_equal(a.occ, b.st.occ) and np.array_equal(a.winner, b.st.winner)
     assert np.array_equal(a.to_move, b.st.to_move)
-    assert np.array_equal(a.episode, ep) and np.array_equal(a.tstep, ts)
-    assert np.array_equal(a.win_count, wins) and np.array_equal(a.draw_count, draws) and ep.sum() > 50
+    assert (a.tcount == T).all() and np.array_equal(a.tstep, ts) and a.n_episodes.sum() == n_ep
+    assert np.array_equal(a.win_count, wins) and np.array_equal(a.draw_count, draws) and n_ep > 50
