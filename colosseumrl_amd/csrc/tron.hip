@@ -47,10 +47,30 @@ __device__ __forceinline__ void tron_split_heads(const TronGeom &g, TronRegs<P> 
     }
 }
 
-// BOARD is any byte-addressable view of this game's board (global or LDS pointer).
+// Board views: how a step reads "who owns this cell" (0 = empty) and writes a trail cell.
+struct PlainBoard {                 // canonical int8 cells, global memory
+    int8_t *p;
+    __device__ __forceinline__ int owner(const int c) const { return p[c]; }
+    __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (int8_t)who; }
+};
+// LDS cells carry an episode tag: byte = tag << OB | owner.  A cell counts as occupied only when its
+// tag equals the game's current tag, so "new_state" is tag+1 instead of clearing N*N bytes; a real clear
+// happens once per 2^(8-OB) episodes.  Canonical HBM boards are tag 0, converted back on copy-out.
+template <int OB>
+struct TaggedBoard {
+    uint8_t *p;
+    uint32_t tagbits;               // tag << OB
+    __device__ __forceinline__ int owner(const int c) const
+    {
+        const uint32_t raw = p[c];
+        return ((raw ^ tagbits) >> OB) == 0 ? (int)(raw & ((1u << OB) - 1u)) : 0;
+    }
+    __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (uint8_t)(tagbits | (uint32_t)who); }
+};
+
 // Straight-line code: every decision is a select, so a wave never diverges inside a step.
 template <int P, typename BOARD>
-__device__ __forceinline__ void tron_step_core(const TronGeom &g, BOARD bd, const bool valid,
+__device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &bd, const bool valid,
                                                TronRegs<P> &s, const int (&act)[P],
                                                int (&rew)[P], int &term, int &wmask)
 {
@@ -67,7 +87,7 @@ __device__ __forceinline__ void tron_step_core(const TronGeom &g, BOARD bd, cons
         ndir[i] = dir;
         oob[i] = ((unsigned)nx[i] >= (unsigned)N) | ((unsigned)ny[i] >= (unsigned)N);
         tgt[i] = oob[i] ? 0 : ny[i] * N + nx[i];
-        val[i] = bd[tgt[i]];
+        val[i] = bd.owner(tgt[i]);
     }
     // phase 2: the reference's sequential resolution, on registers (CyTronGrid.pyx:15-62)
 #pragma unroll
@@ -92,7 +112,7 @@ __device__ __forceinline__ void tron_step_core(const TronGeom &g, BOARD bd, cons
     // phase 3: trail writes
 #pragma unroll
     for (int i = 0; i < P; ++i)
-        if (valid & moved[i]) bd[tgt[i]] = (int8_t)(i + 1);
+        if (valid & moved[i]) bd.put(tgt[i], i + 1);
     // TronGridEnvironment.py:309-321
     int alive = 0;
     wmask = 0;
@@ -275,7 +295,7 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
     }
     tron_split_heads<P>(g, s);
     int term, wm;
-    int8_t *bd = board + bb * NN;
+    const PlainBoard bd{board + bb * NN};
     tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
     if (valid) {
 #pragma unroll
@@ -375,7 +395,7 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
-    int8_t *bd = board + bb * NN;
+    const PlainBoard bd{board + bb * NN};
     for (int t = 0; t < T; ++t) {
         rng.next(gid, acc.tc, seed_lo, seed_hi, act);
         acc.tc += 1;
@@ -456,7 +476,9 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
-    int8_t *bd = slab + lane * stride;
+    constexpr int OB = (P <= 7) ? 3 : 4;                        // owner bits; 8 - OB tag bits
+    constexpr uint32_t kTags = 1u << (8 - OB);
+    TaggedBoard<OB> bd{reinterpret_cast<uint8_t *>(slab + lane * stride), 0u};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // slab written by other lanes of this wave
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int t = 0; t < T; ++t) {
@@ -468,24 +490,47 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
 #pragma unroll
         for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
         if (valid && term) {
-            // new_state for this game only: the lane clears its own board (ds_write_b128) and stamps the heads
-            for (int off = 0; off < stride; off += 16) *reinterpret_cast<uint4 *>(bd + off) = make_uint4(0, 0, 0, 0);
+            // new_state for this game only: bump the tag (every stale cell becomes empty) and stamp the heads
+            uint32_t tag = (bd.tagbits >> OB) + 1u;
+            if (tag == kTags) {                                 // tag space exhausted: one real clear
+                tag = 0;
+                for (int off = 0; off < stride; off += 16) *reinterpret_cast<uint4 *>(bd.p + off) = make_uint4(0, 0, 0, 0);
+            }
+            bd.tagbits = tag << OB;
 #pragma unroll
-            for (int p = 0; p < P; ++p) bd[cfg.start_heads[p]] = (int8_t)(p + 1);
+            for (int p = 0; p < P; ++p) bd.put(cfg.start_heads[p], p + 1);
             acc.finish_episode(wm);
             tron_regs_to_start<P>(cfg, g, s);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- copy out: LDS -> HBM
+    // ---- copy out: LDS -> HBM, dropping the tags (cells of older episodes become 0)
+    constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);    // owner bits of 4 cells
+    constexpr uint32_t TM = 0x01010101u * (kTags - 1u);         // tag bits of 4 cells, shifted down
     if (stride == NN) {
         const int bytes = n_env * NN;
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16)
-            *reinterpret_cast<uint4 *>(gslab + off) = *reinterpret_cast<const uint4 *>(slab + off);
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = off / NN;                             // game this 16-byte piece belongs to (NN % 16 == 0)
+            const uint32_t trep = (uint32_t)__shfl((int)(bd.tagbits >> OB), e, CRL_WAVE) * 0x01010101u;
+            const uint4 raw = *reinterpret_cast<const uint4 *>(slab + off);
+            uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t diff = ((w[q] >> OB) & TM) ^ trep;               // per byte: 0 iff tag matches
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
+                w[q] = w[q] & OM & ~(stale * 0xffu);
+            }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     } else {
-        for (int e = 0; e < n_env; ++e)
-            for (int c = lane; c < NN; c += CRL_WAVE) gslab[(int64_t)e * NN + c] = slab[e * stride + c];
+        for (int e = 0; e < n_env; ++e) {
+            const uint32_t tb = (uint32_t)__shfl((int)bd.tagbits, e, CRL_WAVE);
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const uint32_t raw = (uint8_t)slab[e * stride + c];
+                gslab[(int64_t)e * NN + c] = (int8_t)((((raw ^ tb) >> OB) == 0) ? (raw & ((1u << OB) - 1u)) : 0u);
+            }
+        }
     }
     if (valid) {
 #pragma unroll
@@ -680,8 +725,15 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && lds_bytes <= (size_t)kLdsBudget && (((uintptr_t)board & 15) == 0);
     TRON_DISPATCH_P(cfg.P, {
         if (use_lds) {
-            CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            // opt in to > 64 KiB of dynamic LDS once per kernel instance and device (not per launch)
+            static thread_local int opted_in[64] = {0};
+            int dev = 0;
+            CRL_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !opted_in[dev]) {
+                CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+                if (dev >= 0 && dev < 64) opted_in[dev] = 1;
+            }
             hipLaunchKernelGGL((tron_rollout_lds_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), lds_bytes, s, cfg, g, stride, B,
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         } else {

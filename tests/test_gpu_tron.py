@@ -86,10 +86,12 @@ def _rollout_pair(N, P, B, chunks, seed, first, use_lds=True):
 
 @pytest.mark.parametrize("use_lds", [True, False])
 @pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
-                                           (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,))])
+                                           (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,)),
+                                           (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,))])
 def test_rollout_vs_oracle(N, P, B, chunks, use_lds):
     """Fused random-agent rollout == oracle rollout, bit for bit, for the LDS-resident and the global-memory
-    kernel, ragged batches, odd boards (byte copy path) and split launches (state and RNG position carry over)."""
+    kernel, ragged batches, odd boards (byte copy path), split launches (state and RNG position carry over) and
+    launches long enough to wrap the LDS kernel's episode tags (32 episodes for P <= 7, 16 for P = 8)."""
     ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, use_lds=use_lds)
     assert ost.n_episodes.sum() > B
 
