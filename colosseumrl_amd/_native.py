@@ -47,7 +47,7 @@ class TTTStats(C.Structure):
 
 
 class BlokusStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum", "tests")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum")]
 
 
 _VP, _I, _I64, _U32, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
@@ -71,6 +71,13 @@ PROTOTYPES = {
     "crl_ttt_valid": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
+    "crl_blokus_create": (_I, [C.POINTER(_VP)]),
+    "crl_blokus_placement": (_I, [_I, _I, _I, _VP]),
+    "crl_blokus_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "crl_blokus_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
+    "crl_blokus_valid": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "crl_blokus_board": (_I, [_VP, _I64, _VP, _VP, _VP]),
+    "crl_blokus_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, _VP, BlokusStats, _VP]),
 }
 
 
@@ -83,6 +90,9 @@ def lib():
                 raise NativeError(
                     "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+            # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP
+            # runtime instance (streams and device pointers are shared with torch tensors)
+            import torch  # noqa: F401
             try:
                 handle = C.CDLL(LIB_PATH)
             except OSError as e:  # pragma: no cover

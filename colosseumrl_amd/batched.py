@@ -238,3 +238,94 @@ class TTTBatch:
     def results(self):
         cols = [self.n_episodes, self.len_sum, self.draw_count] + [self.win_count[p] for p in range(self.P)]
         return torch.stack(cols, dim=1).contiguous()
+
+
+class BlokusBatch:
+    """B games of 4-player 20x20 Blokus (reference: envs/blokus/*).
+
+    State tensors (device): occ int32 [B, 4, 20] row bitboards per colour; inv int32 [B, 4] piece masks;
+    score int32 [B, 4]; round int32 [B]; to_move int32 [B].  Actions are dense ids
+    ``((piece*400 + y*20 + x)*8 + orientation)*5 + shift`` (-1 = pass), see ``envs.blokus.actions``.
+    """
+    MASK_WORDS = 10500
+
+    def __init__(self, batch: int = 1, device="cuda", first_env_id: int = 0):
+        lib = _native.require_gpu()
+        self.B = int(batch)
+        self.P = 4
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.NativeError("BlokusBatch needs a ROCm device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.crl_blokus_create(C.byref(handle)), "crl_blokus_create")
+        self._ctx = _Ctx(handle)
+        self._lib = lib
+        self.first_env_id = int(first_env_id)
+        dev, B = self.device, self.B
+        with torch.cuda.device(dev):
+            self.occ = torch.zeros((B, 4, 20), dtype=torch.int32, device=dev)
+            self.inv = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+            self.score = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+            self.round = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.to_move = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.reward = torch.zeros((B,), dtype=torch.int8, device=dev)
+            self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self.tcount = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tstep = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.n_episodes = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.win_count = torch.zeros((4, B), dtype=torch.int32, device=dev)
+            self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.score_sum = torch.zeros((4, B), dtype=torch.int32, device=dev)
+        self.reset()
+
+    def _state(self):
+        return (_ptr(self.occ), _ptr(self.inv), _ptr(self.score), _ptr(self.round), _ptr(self.to_move))
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        if mask is not None:
+            _want(mask, torch.uint8, (self.B,), self.device, "mask")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_reset(self._ctx.handle, self.B, _ptr(mask), *self._state(), _stream()), "crl_blokus_reset")
+
+    def step(self, action: torch.Tensor, auto_reset: bool = False):
+        _want(action, torch.int32, (self.B,), self.device, "action")
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_step(self._ctx.handle, self.B, *self._state(), _ptr(action), _ptr(self.reward),
+                                            _ptr(self.terminal), _ptr(self.winners),
+                                            CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()), "crl_blokus_step")
+        return self.reward, self.terminal, self.winners
+
+    def valid(self, player: Optional[torch.Tensor] = None, want_mask: bool = False):
+        """Legal-action count int32 [B] of `player` (default: the player to move) and, on request, the dense
+        id bitmap int32 [B, 10500] (bit id set = legal; ascending ids = the reference's valid_actions order)."""
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        count = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        mask = torch.empty((self.B, self.MASK_WORDS), dtype=torch.int32, device=self.device) if want_mask else None
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_valid(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(count),
+                                             _ptr(mask), _stream()), "crl_blokus_valid")
+        return (count, mask) if want_mask else count
+
+    def board(self):
+        out = torch.empty((self.B, 20, 20), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_board(self._ctx.handle, self.B, _ptr(self.occ), _ptr(out), _stream()), "crl_blokus_board")
+        return out
+
+    def _stats(self):
+        return _native.BlokusStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
+                                                            self.len_sum, self.score_sum)])
+
+    def rollout(self, steps: int, seed: int = 0):
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
+                                               *self._state(), self._stats(), _stream()), "crl_blokus_rollout")
+
+    def results(self):
+        cols = [self.n_episodes, self.len_sum] + [self.win_count[p] for p in range(4)] + [self.score_sum[p] for p in range(4)]
+        return torch.stack(cols, dim=1).contiguous()

@@ -1,3 +1,738 @@
-// blokus.hip -- placeholder until the Blokus kernels land (see DESIGN.md build order)
+// blokus.hip -- batched Blokus (20x20, 4 players) for gfx950 (MI355X).  Hand-written HIP, wave64.
+//
+// Restates, for B independent games at once:
+//   colosseumrl/envs/blokus/board.py:170-193        get_all_valid_moves (order: piece -> anchor -> orientation -> shift)
+//   colosseumrl/envs/blokus/board.py:114-154        anchor ("corner") cells
+//   colosseumrl/envs/blokus/computation.py:122-246  cell legality, orientations, shift ids
+//   colosseumrl/envs/blokus/BlokusEnvironment.py:357-451  next_state (terminal test on the PRE-move board)
+//   colosseumrl/envs/blokus/ai.py:44-54             inventory / score / last-piece bonus
+//
+// Mapping: ONE WAVE PER GAME.  The board lives in LDS as 4 colours x 20 row words (bit x = column x).
+// For a player q two row bitboards are derived once per step,
+//     allowed_q = empty & ~orth(own_q)                 (a piece may only cover such cells)
+//     corner_q  = allowed_q & diag(own_q)              (anchors; round 0: the player's board corner)
+// and the reference's triple loop over (anchor, orientation, shift) collapses to whole-shape fitting:
+// for an oriented shape S with cells s_j, the origins where it fits are F = AND_j (allowed >> s_j)
+// (K-1 shift-ANDs per board row), and the number of reference actions it contributes is
+// sum_j popcount(F & (corner >> s_j)) -- one action per (cell of S lying on an anchor).
+// Lanes own (piece, orientation) pairs; 8 consecutive lanes make up one piece.  The random agent's
+// "r-th legal action in reference order" is found by a three-level search (piece totals -> anchors of
+// that piece, one lane per anchor, wave prefix scan -> the r-th (orientation, shift) bit of that anchor).
+// The 168 oriented shapes (21 pieces x 8 orientations, 5 packed cell bytes each) sit in LDS.
 #include "crl_common.hpp"
-void crl_blokus_free(void *tables) { (void)tables; }
+
+namespace {
+
+constexpr int BN = 20;
+constexpr int NPIECE = 21;
+constexpr int NSHAPE = NPIECE * 8;
+constexpr uint32_t ROWMASK = (1u << BN) - 1u;
+constexpr int ACTION_IDS = NPIECE * 400 * 8 * 5;          // 336,000 dense ids
+constexpr int MASK_WORDS = ACTION_IDS / 32;               // 10,500
+
+// (dx, dy) cell offsets, (0,0) first; order = inventory order = action order (board.py:24-44)
+const int8_t kPieces[NPIECE][5][2] = {
+    {{0, 0}},
+    {{0, 0}, {1, 0}},
+    {{0, 0}, {1, 0}, {1, 1}},
+    {{0, 0}, {1, 0}, {2, 0}},
+    {{0, 0}, {1, 0}, {0, 1}, {1, 1}},
+    {{0, 0}, {1, -1}, {1, 0}, {2, 0}},
+    {{0, 0}, {1, 0}, {2, 0}, {3, 0}},
+    {{0, 0}, {1, 0}, {2, 0}, {2, -1}},
+    {{0, 0}, {1, 0}, {1, -1}, {2, -1}},
+    {{0, 0}, {0, -1}, {1, 0}, {2, 0}, {3, 0}},
+    {{0, 0}, {0, -1}, {0, 1}, {1, 0}, {2, 0}},
+    {{0, 0}, {0, -1}, {0, -2}, {1, -2}, {2, -2}},
+    {{0, 0}, {1, 0}, {1, -1}, {2, -1}, {3, -1}},
+    {{0, 0}, {0, 1}, {1, 0}, {2, 0}, {2, -1}},
+    {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}},
+    {{0, 0}, {1, 0}, {2, 0}, {1, -1}, {2, -1}},
+    {{0, 0}, {0, 1}, {1, 0}, {1, -1}, {2, -1}},
+    {{0, 0}, {1, 0}, {0, 1}, {0, 2}, {1, 2}},
+    {{0, 0}, {1, 0}, {1, -1}, {1, 1}, {2, -1}},
+    {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}},
+    {{0, 0}, {1, 0}, {1, -1}, {2, 0}, {3, 0}},
+};
+const int8_t kPieceCells[NPIECE] = {1, 2, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+
+// device-resident tables, staged into LDS by every workgroup
+struct BlkTables {
+    uint8_t cells[NSHAPE][8];   // [piece*8+orient][j] = (dx+4) | (dy+4) << 4 ; entries j >= n repeat cell 0
+    uint8_t ncell[24];          // cells per piece (= its score value, ai.py:12-22)
+};
+
+// orientation o of offset (dx,dy): ORIENTATIONS order of board.py:47, maps of computation.py:54-86
+void orient_offset(int o, int dx, int dy, int &ox, int &oy)
+{
+    switch (o) {
+        case 0: ox = dy; oy = -dx; break;    // north      (270 deg)
+        case 1: ox = dx; oy = -dy; break;    // northeast  (flip y)
+        case 2: ox = dx; oy = dy; break;     // east       (identity)
+        case 3: ox = dy; oy = dx; break;     // southeast  (90 deg, flip x)
+        case 4: ox = -dy; oy = dx; break;    // south      (90 deg)
+        case 5: ox = -dx; oy = dy; break;    // southwest  (180 deg, flip y)
+        case 6: ox = -dx; oy = -dy; break;   // west       (180 deg)
+        default: ox = -dy; oy = -dx; break;  // northwest  (270 deg, flip x)
+    }
+}
+
+void build_tables(BlkTables &t)
+{
+    memset(&t, 0, sizeof(t));
+    for (int p = 0; p < NPIECE; ++p) {
+        t.ncell[p] = (uint8_t)kPieceCells[p];
+        for (int o = 0; o < 8; ++o)
+            for (int j = 0; j < 8; ++j) {
+                const int jj = j < kPieceCells[p] ? j : 0;
+                int ox, oy;
+                orient_offset(o, kPieces[p][jj][0], kPieces[p][jj][1], ox, oy);
+                t.cells[p * 8 + o][j] = (uint8_t)((ox + 4) | ((oy + 4) << 4));
+            }
+    }
+}
+
+// per-wave working set in LDS
+struct WaveLds {
+    uint32_t occ[4][BN];     // board rows per colour, bit x = column x
+    uint2 ac[4][32];         // per player, index y+4: {allowed << 8, corner << 8}; rows outside the board are 0
+    uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
+    uint32_t pcnt[32];       // legal-action count per inventory slot
+    uint32_t rowpre[32];     // inclusive prefix of anchors per row
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int nth_set_bit32(uint32_t m, int r)
+{
+    int pos = 0, c;
+    c = __popc(m & 0xffffu); if (r >= c) { r -= c; m >>= 16; pos += 16; }
+    c = __popc(m & 0xffu);   if (r >= c) { r -= c; m >>= 8;  pos += 8; }
+    c = __popc(m & 0xfu);    if (r >= c) { r -= c; m >>= 4;  pos += 4; }
+    c = __popc(m & 0x3u);    if (r >= c) { r -= c; m >>= 2;  pos += 2; }
+    c = (int)(m & 1u);       if (r >= c) { pos += 1; }
+    return pos;
+}
+
+__device__ __forceinline__ int nth_set_bit64(unsigned long long m, int r)
+{
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const int c = __popc(lo);
+    return r < c ? nth_set_bit32(lo, r) : 32 + nth_set_bit32(hi, r - c);
+}
+
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, d, 64);
+        v += (lane >= d) ? u : 0u;
+    }
+    return v;
+}
+
+// ---- derive allowed / corner rows of all four players from the board (lanes 0..79: player q, row y)
+__device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int round)
+{
+    if (lane < 4 * 32) {   // clear the padding rows too (two passes for 128 entries)
+    }
+    for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);
+    wave_sync();
+    for (int i = lane; i < 4 * BN; i += 64) {
+        const int q = i / BN, y = i - q * BN;
+        const uint32_t any = L.occ[0][y] | L.occ[1][y] | L.occ[2][y] | L.occ[3][y];
+        const uint32_t own = L.occ[q][y];
+        const uint32_t up = y > 0 ? L.occ[q][y - 1] : 0u, dn = y < BN - 1 ? L.occ[q][y + 1] : 0u;
+        const uint32_t orth = up | dn | (own << 1) | (own >> 1);           // computation.py:89-119
+        const uint32_t allowed = ~any & ~orth & ROWMASK;                  // computation.py:122-142
+        uint32_t corner;
+        if (round == 0) {                                                // board.py:177-179, corners of board.py:50
+            const int cx = (q & 1) ? BN - 1 : 0, cy = (q & 2) ? BN - 1 : 0;
+            corner = (y == cy) ? (allowed & (1u << cx)) : 0u;
+        } else {                                                         // board.py:114-154
+            const uint32_t ud = up | dn;
+            corner = allowed & ((ud << 1) | (ud >> 1)) & ROWMASK;
+        }
+        L.ac[q][y + 4] = make_uint2(allowed << 8, corner << 8);
+    }
+    wave_sync();
+}
+
+struct ShapeRegs {
+    int sh[5];      // dx + 4  (shift amounts)
+    int ro[5];      // dy + 4  (row offsets)
+    int n;
+};
+
+__device__ __forceinline__ ShapeRegs blk_load_shape(const BlkTables &T, const int piece, const int orient)
+{
+    ShapeRegs s;
+    const uint2 raw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + orient][0]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t b = (j < 4) ? (raw.x >> (8 * j)) & 0xffu : raw.y & 0xffu;
+        s.sh[j] = (int)(b & 15u);
+        s.ro[j] = (int)(b >> 4);
+    }
+    s.n = T.ncell[piece];
+    return s;
+}
+
+// actions contributed by one oriented shape when its origin lies in rows [y0, y1]; any_only: stop at the first hit
+template <bool ANY_ONLY>
+__device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const int q, const ShapeRegs &s, const bool active,
+                                                    const int y0, const int y1)
+{
+    uint32_t cnt = 0;
+    for (int y = y0; y <= y1; ++y) {
+        uint32_t F = 0xffffffffu, ct[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint2 ac = L.ac[q][y + s.ro[j]];
+            F &= ac.x >> s.sh[j];                       // bit x+4: cell j of the shape at origin (x, y) is allowed
+            ct[j] = ac.y >> s.sh[j];                    // bit x+4: cell j of the shape at origin (x, y) is an anchor
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) cnt += (j < s.n) ? __popc(F & ct[j]) : 0;
+        if (ANY_ONLY && __ballot(active && cnt > 0)) break;
+    }
+    return active ? cnt : 0u;
+}
+
+// rows that can hold the origin of a shape touching an anchor of player q (wave-uniform)
+__device__ __forceinline__ void blk_row_range(const WaveLds &L, const int q, const int lane, int &y0, int &y1)
+{
+    const bool has = lane < BN && L.ac[q][lane + 4].y != 0u;
+    const unsigned long long m = __ballot(has);
+    if (m == 0) { y0 = 0; y1 = -1; return; }
+    const int lo = __builtin_ctzll(m), hi = 63 - __builtin_clzll(m);
+    y0 = lo - 4 < 0 ? 0 : lo - 4;
+    y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4;
+}
+
+// does player q have any legal action with inventory inv? (board.py:170-193 non-empty)
+__device__ __forceinline__ bool blk_exists(const BlkTables &T, const WaveLds &L, const int q, const uint32_t inv, const int lane)
+{
+    int y0, y1;
+    blk_row_range(L, q, lane, y0, y1);
+    if (y1 < y0 || inv == 0) return false;
+    if (inv & 1u) return true;                          // the monomino fits on any anchor (anchors are allowed cells)
+    const int items = __popc(inv) * 8;
+    for (int base = 0; base < items; base += 64) {
+        const int i = base + lane;
+        const bool active = i < items;
+        const int piece = nth_set_bit32(inv, active ? i >> 3 : 0);
+        const ShapeRegs s = blk_load_shape(T, piece, i & 7);
+        const uint32_t c = blk_shape_count<true>(L, q, s, active, y0, y1);
+        if (__ballot(c > 0)) return true;
+    }
+    return false;
+}
+
+// legal-action count per inventory slot of player q into L.pcnt[], returns the total (valid_actions length)
+__device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane)
+{
+    int y0, y1;
+    blk_row_range(L, q, lane, y0, y1);
+    const int slots = __popc(inv);
+    if (lane < 32) L.pcnt[lane] = 0;
+    wave_sync();
+    if (y1 < y0) return 0;
+    uint32_t total = 0;
+    for (int base = 0; base < slots * 8; base += 64) {
+        const int i = base + lane;
+        const bool active = i < slots * 8;
+        const int piece = nth_set_bit32(inv, active ? i >> 3 : 0);
+        const ShapeRegs s = blk_load_shape(T, piece, i & 7);
+        uint32_t c = blk_shape_count<false>(L, q, s, active, y0, y1);
+        c += (uint32_t)__shfl_xor((int)c, 1, 64);       // the 8 orientations of a piece sit in 8 consecutive lanes
+        c += (uint32_t)__shfl_xor((int)c, 2, 64);
+        c += (uint32_t)__shfl_xor((int)c, 4, 64);
+        if (active && (lane & 7) == 0) L.pcnt[i >> 3] = c;
+    }
+    wave_sync();
+    const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
+    total = wave_scan_incl(mine, lane);
+    total = (uint32_t)__shfl((int)total, 63, 64);
+    return total;
+}
+
+struct BlkMove { int piece, x, y, orient, shift; };
+
+// the r-th (0-based) legal action of player q in reference order; blk_count() must have filled L.pcnt
+__device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, uint32_t r, const int lane)
+{
+    // level 1: inventory slot
+    const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
+    const uint32_t incl = wave_scan_incl(mine, lane);
+    const unsigned long long hit = __ballot(r < incl);
+    const int slot = __builtin_ctzll(hit);
+    r -= (uint32_t)__shfl((int)(incl - mine), slot, 64);
+    const int piece = nth_set_bit32(inv, slot);
+    const int n = T.ncell[piece];
+    // fit masks of the 8 orientations of that piece, all 20 origin rows
+    for (int i = lane; i < 8 * 32; i += 64) L.fit[i >> 5][i & 31] = 0u;
+    wave_sync();
+    for (int i = lane; i < 8 * BN; i += 64) {
+        const int o = i / BN, y = i - o * BN;
+        const ShapeRegs s = blk_load_shape(T, piece, o);
+        uint32_t F = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro[j]].x >> s.sh[j];
+        L.fit[o][y + 4] = F;                             // bit x+4
+    }
+    // level 2: anchors in row-major order, one lane per anchor
+    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
+    const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
+    if (lane < 32) L.rowpre[lane] = rinc;
+    wave_sync();
+    const int n_anchor = (int)L.rowpre[BN - 1];
+    BlkMove mv = {piece, 0, 0, 0, 0};
+    uint32_t carried = 0;
+    for (int base = 0; base < n_anchor; base += 64) {
+        const int a = base + lane;
+        const bool active = a < n_anchor;
+        int ay = 0;
+        for (int y = 0; y < BN; ++y) ay += (L.rowpre[y] <= (uint32_t)a) ? 1 : 0;
+        ay = active ? ay : 0;
+        const uint32_t before = ay > 0 ? L.rowpre[ay - 1] : 0u;
+        const int ax = nth_set_bit32(L.ac[q][ay + 4].y >> 8, active ? a - (int)before : 0);
+        uint32_t cnt = 0;
+        unsigned long long vm = 0;
+        for (int o = 0; o < 8; ++o) {                    // wave-uniform loops over (orientation, shift)
+            const ShapeRegs s = blk_load_shape(T, piece, o);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                // shift j puts cell j on the anchor: origin = anchor - s_j
+                const int ty = ay - (s.ro[j] - 4), tx = ax - (s.sh[j] - 4);
+                const bool ok = active && j < n && ty >= -4 && ty < BN + 4 && tx >= -4 && tx < 28 &&
+                                ((L.fit[o][ty + 4] >> (tx + 4)) & 1u);
+                cnt += ok ? 1u : 0u;
+                vm |= ok ? (1ull << (o * 5 + j)) : 0ull;
+            }
+        }
+        const uint32_t inc = wave_scan_incl(cnt, lane);
+        const unsigned long long h2 = __ballot(active && r < carried + inc);
+        if (h2) {
+            const int src = __builtin_ctzll(h2);
+            const uint32_t r2 = r - carried - (uint32_t)__shfl((int)(inc - cnt), src, 64);
+            const int bit = nth_set_bit64(vm, (int)r2);  // level 3: (orientation, shift) in order
+            mv.x = __shfl(ax, src, 64);
+            mv.y = __shfl(ay, src, 64);
+            const int b = __shfl(bit, src, 64);
+            mv.orient = b / 5;
+            mv.shift = b - mv.orient * 5;
+            return mv;
+        }
+        carried += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    return mv;   // unreachable when r < total
+}
+
+// place the piece (board.py:87-103; no legality check there) and update inventory / score (ai.py:44-54)
+__device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv,
+                                          uint32_t (&inv)[4], int (&score)[4], const int lane)
+{
+    const ShapeRegs s = blk_load_shape(T, mv.piece, mv.orient);
+    int ox = 0, oy = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh[j] : ox; oy = (j == mv.shift) ? s.ro[j] : oy; }
+    if (lane < s.n) {
+        int cx = 0, cy = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh[j] : cx; cy = (j == lane) ? s.ro[j] : cy; }
+        const int x = mv.x + cx - ox, y = mv.y + cy - oy;
+        if (x >= 0 && x < BN && y >= 0 && y < BN) {
+            for (int c = 0; c < 4; ++c) {
+                if (c == q) atomicOr(&L.occ[c][y], 1u << x);
+                else atomicAnd(&L.occ[c][y], ~(1u << x));    // an (illegal) overlap overwrites, like the reference
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c == q) {
+            inv[c] &= ~(1u << mv.piece);
+            score[c] += s.n + ((inv[c] == 0) ? (mv.piece == 0 ? 20 : 15) : 0);
+        }
+    }
+    wave_sync();
+}
+
+struct BlkOutcome { int reward, terminal, winners; };
+
+// BlokusEnvironment.py:424-447 once `any_move` is known
+__device__ __forceinline__ BlkOutcome blk_outcome(const bool any_move, const int pl, const int (&score)[4])
+{
+    BlkOutcome o = {0, 0, 0};
+    if (!any_move) {
+        o.terminal = 1;
+        int best = 0, mine = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { best = score[c] > best ? score[c] : best; mine = (c == pl) ? score[c] : mine; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            o.winners |= (score[c] == best) << c;
+            o.reward += (score[c] < mine || (score[c] == mine && c < pl)) ? 1 : 0;
+        }
+    }
+    return o;
+}
+
+__device__ __forceinline__ void blk_load_state(WaveLds &L, const int64_t b, const int lane, const uint32_t *occ,
+                                               const uint32_t *inv_g, const int32_t *score_g, uint32_t (&inv)[4], int (&score)[4])
+{
+    for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = occ[b * 4 * BN + i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { inv[c] = inv_g[b * 4 + c]; score[c] = score_g[b * 4 + c]; }
+    wave_sync();
+}
+
+__device__ __forceinline__ void blk_store_state(const WaveLds &L, const int64_t b, const int lane, uint32_t *occ,
+                                                uint32_t *inv_g, int32_t *score_g, const uint32_t (&inv)[4], const int (&score)[4])
+{
+    wave_sync();
+    for (int i = lane; i < 4 * BN; i += 64) occ[b * 4 * BN + i] = L.occ[i / BN][i % BN];
+    if (lane < 4) {
+        uint32_t iv = 0;
+        int sc = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { iv = (c == lane) ? inv[c] : iv; sc = (c == lane) ? score[c] : sc; }
+        inv_g[b * 4 + lane] = iv;
+        score_g[b * 4 + lane] = sc;
+    }
+}
+
+__device__ __forceinline__ void blk_fresh(WaveLds &L, const int lane, uint32_t (&inv)[4], int (&score)[4])
+{
+    for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { inv[c] = (1u << NPIECE) - 1u; score[c] = 0; }
+    wave_sync();
+}
+
+__device__ __forceinline__ BlkMove blk_decode(const int id)
+{
+    BlkMove mv;
+    mv.shift = id % 5;
+    mv.orient = (id / 5) & 7;
+    const int cell = (id / 40) % 400;
+    mv.piece = id / 16000;
+    mv.x = cell % BN;
+    mv.y = cell / BN;
+    return mv;
+}
+
+#define BLK_SHARED_SETUP()                                                                        \
+    __shared__ BlkTables T;                                                                       \
+    __shared__ WaveLds Lw[4];                                                                     \
+    for (int i = threadIdx.x; i < (int)(sizeof(BlkTables) / 4); i += blockDim.x)                  \
+        reinterpret_cast<uint32_t *>(&T)[i] = reinterpret_cast<const uint32_t *>(tables)[i];      \
+    __syncthreads();                                                                              \
+    const int lane = threadIdx.x & 63;                                                            \
+    WaveLds &L = Lw[threadIdx.x >> 6];                                                            \
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);                               \
+    if (b >= B) return;
+
+// ---- kernels (one wave per game, 4 games per workgroup) ---------------------------------------------
+
+__global__ void __launch_bounds__(256)
+blokus_step_kernel(const BlkTables *__restrict__ tables, const int64_t B, uint32_t *__restrict__ occ,
+                   uint32_t *__restrict__ inv_g, int32_t *__restrict__ score_g, int32_t *__restrict__ round_g,
+                   int32_t *__restrict__ to_move_g, const int32_t *__restrict__ action, int8_t *__restrict__ reward,
+                   uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners, const uint32_t flags)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    int round = round_g[b], pl = to_move_g[b] & 3;
+    blk_prep(L, lane, round);                                    // allowed / corner rows of the PRE-move board (:424)
+    const int id = action[b];
+    if (id >= 0 && id < ACTION_IDS) {                            // '' (pass) otherwise (:418)
+        const BlkMove mv = blk_decode(id);
+        blk_apply(T, L, pl, mv, inv, score, lane);
+    }
+    bool any_move = false;
+    for (int q = 0; q < 4 && !any_move; ++q) {                   // old board, old round, NEW inventories (:424)
+        uint32_t iq = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+        any_move = blk_exists(T, L, q, iq, lane);
+    }
+    const BlkOutcome out = blk_outcome(any_move, pl, score);
+    round += (pl == 3) ? 1 : 0;                                  // :446-447
+    pl = (pl + 1) & 3;
+    if (lane == 0) {
+        reward[b] = (int8_t)out.reward;
+        terminal[b] = (uint8_t)out.terminal;
+        winners[b] = (uint8_t)out.winners;
+    }
+    if (out.terminal && (flags & CRL_STEP_AUTO_RESET)) {
+        blk_fresh(L, lane, inv, score);
+        round = 0;
+        pl = 0;
+    }
+    blk_store_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    if (lane == 0) { round_g[b] = round; to_move_g[b] = pl; }
+}
+
+// valid_actions: count, and optionally the dense id bitmap (bit id set = action id is legal)
+__global__ void __launch_bounds__(256)
+blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
+                    const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
+                    const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
+                    const int8_t *__restrict__ player, int32_t *__restrict__ count, uint32_t *__restrict__ mask)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    const int q = (player ? player[b] : to_move_g[b]) & 3;
+    blk_prep(L, lane, round_g[b]);
+    uint32_t iq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    const uint32_t total = blk_count(T, L, q, iq, lane);
+    if (lane == 0 && count) count[b] = (int32_t)total;
+    if (mask && total) {
+        uint32_t *m = mask + b * (int64_t)MASK_WORDS;
+        const int items = __popc(iq) * 8;
+        for (int i = lane; i < items; i += 64) {
+            const int piece = nth_set_bit32(iq, i >> 3), o = i & 7;
+            const ShapeRegs s = blk_load_shape(T, piece, o);
+            for (int y = 0; y < BN; ++y) {
+                uint32_t F = 0xffffffffu, ct[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint2 ac = L.ac[q][y + s.ro[j]];
+                    F &= ac.x >> s.sh[j];
+                    ct[j] = ac.y >> s.sh[j];
+                }
+                for (int j = 0; j < s.n; ++j) {
+                    uint32_t hits = (F & ct[j]) >> 4;                // origin columns x with cell j on an anchor
+                    while (hits) {
+                        const int x = __builtin_ctz(hits);
+                        hits &= hits - 1;
+                        const int ax = x + s.sh[j] - 4, ay = y + s.ro[j] - 4;     // the anchor
+                        const int id = ((piece * 400 + ay * BN + ax) * 8 + o) * 5 + j;
+                        atomicOr(&m[id >> 5], 1u << (id & 31));
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                      const uint64_t first_env_id, const int T_steps, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv_g,
+                      int32_t *__restrict__ score_g, int32_t *__restrict__ round_g, int32_t *__restrict__ to_move_g,
+                      const crl_blokus_stats st)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    int round = round_g[b], pl = to_move_g[b] & 3;
+    uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, len_sum = 0, wins[4] = {0, 0, 0, 0};
+    int ssum[4] = {0, 0, 0, 0};
+    const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
+    for (int t = 0; t < T_steps; ++t) {
+        blk_prep(L, lane, round);
+        uint32_t ip = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
+        const uint32_t total = blk_count(T, L, pl, ip, lane);       // len(valid_actions) of the mover
+        const philox_out rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
+        const uint32_t sel = tc & 3u;
+        uint32_t word = rnd.w[0];
+        word = (sel == 1) ? rnd.w[1] : word;
+        word = (sel == 2) ? rnd.w[2] : word;
+        word = (sel == 3) ? rnd.w[3] : word;
+        tc += 1;
+        bool any_move = false;
+        if (total > 0) {
+            const uint32_t r = __umulhi(word, total);
+            const BlkMove mv = blk_select(T, L, pl, ip, r, lane);
+            // the mover keeps a move iff some OTHER piece of its inventory had one (new inventory, old board)
+            const int slot = __popc(ip & ((1u << mv.piece) - 1u));
+            any_move = total > L.pcnt[slot];
+            blk_apply(T, L, pl, mv, inv, score, lane);
+        }
+        for (int q = 0; q < 4 && !any_move; ++q) {
+            if (q == pl) continue;
+            uint32_t iq = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+            any_move = blk_exists(T, L, q, iq, lane);
+        }
+        const BlkOutcome out = blk_outcome(any_move, pl, score);
+        round += (pl == 3) ? 1 : 0;
+        pl = (pl + 1) & 3;
+        ts += 1;
+        if (out.terminal) {
+            n_ep += 1;
+            len_sum += ts;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { wins[c] += (out.winners >> c) & 1; ssum[c] += score[c]; }
+            blk_fresh(L, lane, inv, score);
+            round = 0; pl = 0; ts = 0;
+        }
+    }
+    blk_store_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    if (lane == 0) {
+        round_g[b] = round; to_move_g[b] = pl;
+        st.tcount[b] = tc; st.tstep[b] = ts;
+        st.n_episodes[b] += n_ep; st.len_sum[b] += len_sum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { st.win_count[c * B + b] += wins[c]; st.score_sum[c * B + b] += ssum[c]; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+blokus_reset_kernel(const int64_t B, const uint8_t *__restrict__ mask, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv,
+                    int32_t *__restrict__ score, int32_t *__restrict__ round, int32_t *__restrict__ to_move)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 4 * BN) return;
+    const int64_t b = i / (4 * BN);
+    if (mask && !mask[b]) return;
+    occ[i] = 0u;
+    const int k = (int)(i - b * 4 * BN);
+    if (k < 4) { inv[b * 4 + k] = (1u << NPIECE) - 1u; score[b * 4 + k] = 0; }
+    if (k == 0) { round[b] = 0; to_move[b] = 0; }
+}
+
+// board_contents export: int8 [B][20][20], 0 empty else colour (board.py:85), one thread per cell
+__global__ void __launch_bounds__(256)
+blokus_board_kernel(const int64_t B, const uint32_t *__restrict__ occ, int8_t *__restrict__ board)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * BN * BN) return;
+    const int64_t b = i / (BN * BN);
+    const int cell = (int)(i - b * BN * BN), y = cell / BN, x = cell - y * BN;
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = ((occ[(b * 4 + c) * BN + y] >> x) & 1u) ? c + 1 : v;
+    board[i] = (int8_t)v;
+}
+
+} // namespace
+
+void crl_blokus_free(void *tables)
+{
+    if (tables) (void)hipFree(tables);
+}
+
+#define BLK_CTX_CHECK(fn)                                                                       \
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_BLOKUS && ctx->blokus, fn ": ctx is not a blokus context"); \
+    CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 28), fn ": B=%lld out of range", (long long)B)
+
+extern "C" {
+
+int crl_blokus_create(crl_ctx **out)
+{
+    CRL_REQUIRE(out != nullptr, "crl_blokus_create: out is NULL");
+    BlkTables host;
+    build_tables(host);
+    void *dev = nullptr;
+    CRL_HIP(hipMalloc(&dev, sizeof(BlkTables)));
+    hipError_t e = hipMemcpy(dev, &host, sizeof(BlkTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(dev);
+        crl_set_error("crl_blokus_create: hipMemcpy failed: %s", hipGetErrorString(e));
+        return CRL_EHIP;
+    }
+    crl_ctx *c = new crl_ctx();
+    memset(c, 0, sizeof(*c));
+    c->game = CRL_GAME_BLOKUS;
+    c->blokus = dev;
+    *out = c;
+    return CRL_OK;
+}
+
+int crl_blokus_placement(int piece, int orient, int shift, int8_t *cells_xy)
+{
+    CRL_REQUIRE(piece >= 0 && piece < NPIECE && orient >= 0 && orient < 8 && cells_xy, "crl_blokus_placement: bad argument");
+    CRL_REQUIRE(shift >= 0 && shift < kPieceCells[piece], "crl_blokus_placement: shift %d out of range for piece %d", shift, piece);
+    BlkTables t;
+    build_tables(t);
+    const uint8_t *c = t.cells[piece * 8 + orient];
+    for (int j = 0; j < kPieceCells[piece]; ++j) {
+        cells_xy[2 * j] = (int8_t)((c[j] & 15) - (c[shift] & 15));
+        cells_xy[2 * j + 1] = (int8_t)((c[j] >> 4) - (c[shift] >> 4));
+    }
+    return kPieceCells[piece];
+}
+
+int crl_blokus_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask, uint32_t *occ, uint32_t *inv, int32_t *score,
+                     int32_t *round, int32_t *to_move, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_reset");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_reset: NULL state pointer");
+    const int64_t n = B * 4 * BN;
+    hipLaunchKernelGGL(blokus_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, mask, occ, inv, score, round, to_move);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                    const int32_t *action, int8_t *reward, uint8_t *terminal, uint8_t *winners, uint32_t flags, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_step");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_step: NULL state pointer");
+    CRL_REQUIRE(action && reward && terminal && winners, "crl_blokus_step: NULL action/output pointer");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_blokus_step: unknown flags 0x%x", flags);
+    hipLaunchKernelGGL(blokus_step_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, action, reward, terminal, winners, flags);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                     const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *count, uint32_t *mask, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_valid");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_valid: NULL state pointer");
+    CRL_REQUIRE(count || mask, "crl_blokus_valid: nothing to compute (count and mask are NULL)");
+    if (mask) CRL_HIP(hipMemsetAsync(mask, 0, (size_t)B * MASK_WORDS * 4, (hipStream_t)stream));
+    hipLaunchKernelGGL(blokus_valid_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, count, mask);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t *board, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_board");
+    CRL_REQUIRE(occ && board, "crl_blokus_board: NULL pointer");
+    const int64_t n = B * BN * BN;
+    hipLaunchKernelGGL(blokus_board_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, occ, board);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                       uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                       crl_blokus_stats st, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_rollout");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_rollout: NULL state pointer");
+    CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.score_sum, "crl_blokus_rollout: NULL stats pointer");
+    CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_blokus_rollout: T=%d out of range", T);
+    if (T == 0) return CRL_OK;
+    hipLaunchKernelGGL(blokus_rollout_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T,
+                       occ, inv, score, round, to_move, st);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+} // extern "C"

@@ -155,6 +155,50 @@ typedef struct {
 int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                     uint32_t *occ, int8_t *winner, int8_t *to_move, crl_ttt_stats stats, void *stream);
 
+/* ------------------------------------------------------------------ Blokus (20 x 20, 4 players)
+ * State (reference BlokusEnvironment.py:283-289: (Board, round_count, [AI x 4])):
+ *   occ     uint32 [B][4][20]  bit x of occ[b][c][y] set = cell (x, y) holds colour c+1 (Board.board_contents[y][x])
+ *   inv     uint32 [B][4]      bit i set = piece i (inventory order of ai.py:12-22) still held by that player
+ *   score   int32  [B][4]      AI.player_score
+ *   round   int32  [B]         round_count
+ *   to_move int32  [B]
+ * Action id = ((piece*400 + y*20 + x)*8 + orientation)*5 + shift for the reference string
+ * "{piece};({x}, {y});{orientation}{shift}" (BlokusEnvironment.py:55-80; orientation order board.py:47);
+ * ascending ids are exactly the order of BlokusEnvironment.valid_actions; -1 = '' (pass).            */
+#define CRL_BLOKUS_ACTION_IDS 336000
+#define CRL_BLOKUS_MASK_WORDS 10500
+int crl_blokus_create(crl_ctx **out);
+/* HOST helper: cells (dx,dy pairs, 2*n int8) of (piece, orientation, shift) relative to the anchor; returns n.
+ * Restates computation.py:184-246 (rotate_default_piece / shift_offsets). */
+int crl_blokus_placement(int piece, int orient, int shift, int8_t *cells_xy);
+/* replaces BlokusEnvironment.new_state (BlokusEnvironment.py:248-289); mask as for crl_tron_reset */
+int crl_blokus_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask, uint32_t *occ, uint32_t *inv, int32_t *score,
+                     int32_t *round, int32_t *to_move, void *stream);
+/* replaces BlokusEnvironment.next_state (BlokusEnvironment.py:357-451).  No legality check (the reference
+ * leaves that to its caller, match_server.py:193).  reward int8 [B]: the mover's rank in the ascending score
+ * order at terminal, else 0; terminal uint8 [B]: no player has a move on the PRE-move board with the
+ * post-move inventories; winners uint8 [B]: bitmask of players whose score equals max(0, best), 0 unless terminal */
+int crl_blokus_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                    const int32_t *action, int8_t *reward, uint8_t *terminal, uint8_t *winners, uint32_t flags, void *stream);
+/* replaces BlokusEnvironment.valid_actions / board.get_all_valid_moves (BlokusEnvironment.py:453-500, board.py:170-193)
+ * for `player` (int8 [B]; NULL = the player to move): count int32 [B] (may be NULL) and/or the dense id bitmap
+ * mask uint32 [B][CRL_BLOKUS_MASK_WORDS] (may be NULL; 42 KB per game, meant for small B). */
+int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                     const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *count, uint32_t *mask, void *stream);
+/* Board.board_contents as int8 [B][20][20] (0 empty, else colour) */
+int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t *board, void *stream);
+typedef struct {
+    uint32_t *tcount, *tstep, *n_episodes;
+    uint32_t *win_count;   /* [4][B] */
+    uint32_t *len_sum;     /* [B] */
+    int32_t  *score_sum;   /* [4][B] final scores summed over finished episodes */
+} crl_blokus_stats;
+/* random agent: the mover plays the r-th action of valid_actions() (reference order), r = mulhi32(w, n), '' if n = 0;
+ * w = Philox(ctr={g, c >> 2, 0, 0x424c0000}, seed)[c & 3] with c = tcount; auto-reset on terminal */
+int crl_blokus_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                       uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                       crl_blokus_stats stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

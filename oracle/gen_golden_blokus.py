@@ -1,0 +1,125 @@
+"""Blokus golden vectors from the REFERENCE (run in the build container only) -- TEST INFRASTRUCTURE.
+
+Full random games through ``BlokusEnvironment.valid_actions`` / ``next_state`` of the reference
+(numba absent here, so its helpers run as plain Python: ~30 s per game; games run in parallel
+processes).  Stored per step: the chosen action (encoded), the number of legal actions, a 64-bit
+hash of the ordered legal-action id list, the full ordered list for every 4th step, and the state
+after the step (board, inventories, scores, round, next player, reward, terminal, winners).
+Plus scripted inventory-exhaustion states for the +15 / +20 bonuses (ai.py:49-52).
+"""
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+PIECES = ["monomino1", "domino1", "trominoe1", "trominoe2", "tetrominoes1", "tetrominoes2", "tetrominoes3",
+          "tetrominoes4", "tetrominoes5", "pentominoe1", "pentominoe2", "pentominoe3", "pentominoe4",
+          "pentominoe5", "pentominoe6", "pentominoe7", "pentominoe8", "pentominoe9", "pentominoe10",
+          "pentominoe11", "pentominoe12"]
+ORIENT = ["north", "northeast", "east", "southeast", "south", "southwest", "west", "northwest"]
+MAX_STEPS = 100
+LIST_EVERY = 4
+LIST_CAP = 2048
+
+
+def encode(s):
+    if s == "":
+        return -1
+    name, idx, orient = s.split(";")
+    x, y = [int(v) for v in idx.replace("(", "").replace(")", "").split(",")]
+    return ((PIECES.index(name) * 400 + y * 20 + x) * 8 + ORIENT.index(orient[:-1])) * 5 + int(orient[-1])
+
+
+def list_hash(ids):
+    h = np.uint64(1469598103934665603)
+    for v in ids:
+        h = (h ^ np.uint64(int(v) & 0xFFFFFFFF)) * np.uint64(1099511628211)
+    return h
+
+
+def inv_mask(ai):
+    return sum(1 << PIECES.index(p) for p in ai.current_pieces)
+
+
+def play_game(seed):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_loader
+    R = ref_loader.load()
+    env = R["blokus"]()
+    rng = np.random.default_rng(seed)
+    state, players = env.new_state()
+    rec = dict(action=[], n_valid=[], valid_hash=[], board=[], inv=[], score=[], round=[], next_player=[],
+               reward=[], terminal=[], winners=[], lists=[], list_step=[])
+    with np.errstate(over="ignore"):
+        for t in range(MAX_STEPS):
+            pl = players[0]
+            va = env.valid_actions(state, pl)
+            ids = [encode(s) for s in va if s != ""]
+            assert ids == sorted(ids), "reference order is ascending in the dense id"
+            a = ids[int(rng.integers(0, len(ids)))] if ids else -1
+            astr = va[ids.index(a)] if ids else ""
+            if ids:
+                assert env.is_valid_action(state, pl, astr)
+            state, players, rewards, terminal, winners = env.next_state(state, [pl], [astr])
+            rec["action"].append(a)
+            rec["n_valid"].append(len(ids))
+            rec["valid_hash"].append(list_hash(ids))
+            if t % LIST_EVERY == 0 or len(ids) < 6:
+                row = np.full(LIST_CAP, -1, np.int32)
+                row[:len(ids)] = ids
+                rec["lists"].append(row)
+                rec["list_step"].append(t)
+            rec["board"].append(state[0].board_contents.astype(np.int8).copy())
+            rec["inv"].append([inv_mask(p) for p in state[2]])
+            rec["score"].append([p.player_score for p in state[2]])
+            rec["round"].append(state[1])
+            rec["next_player"].append(players[0])
+            rec["reward"].append(rewards[0])
+            rec["terminal"].append(bool(terminal))
+            rec["winners"].append(0 if winners is None else sum(1 << w for w in winners))
+            if terminal:
+                break
+    return seed, rec
+
+
+def bonus_cases(R):
+    """Last-piece bonuses: +20 when the final piece is the monomino, +15 otherwise (ai.py:49-52),
+    and a pass ('') on a finished inventory."""
+    env = R["blokus"]()
+    out = []
+    for last, action in (("monomino1", "monomino1;(5, 5);east0"), ("domino1", "domino1;(5, 5);east0")):
+        state, players = env.new_state()
+        board, rnd, ais = state
+        board.board_contents[4, 4] = 1            # own cell diagonal to (5,5)
+        ais[0].current_pieces = [last]
+        ais[0].player_score = 80
+        st = (board, 3, ais)
+        before = board.board_contents.astype(np.int8).copy()
+        ns, npl, rew, term, win = env.next_state(st, [0], [action])
+        out.append(dict(before=before, inv_before=[inv_mask(p) for p in ais], score_before=[80, 0, 0, 0], round=3,
+                        action=encode(action), board=ns[0].board_contents.astype(np.int8).copy(),
+                        inv=[inv_mask(p) for p in ns[2]], score=[p.player_score for p in ns[2]],
+                        reward=rew[0], terminal=bool(term), winners=0 if win is None else sum(1 << w for w in win),
+                        next_round=ns[1], next_player=npl[0]))
+    return out
+
+
+def gen(R, out_dir, n_games=8):
+    with Pool(min(8, n_games)) as pool:
+        games = pool.map(play_game, list(range(1, n_games + 1)))
+    for seed, rec in games:
+        T = len(rec["action"])
+        np.savez_compressed(os.path.join(out_dir, "blokus_game_%d.npz" % seed),
+                            action=np.array(rec["action"], np.int32), n_valid=np.array(rec["n_valid"], np.int32),
+                            valid_hash=np.array(rec["valid_hash"], np.uint64), board=np.array(rec["board"], np.int8),
+                            inv=np.array(rec["inv"], np.uint32), score=np.array(rec["score"], np.int32),
+                            round=np.array(rec["round"], np.int32), next_player=np.array(rec["next_player"], np.int32),
+                            reward=np.array(rec["reward"], np.int8), terminal=np.array(rec["terminal"], np.uint8),
+                            winners=np.array(rec["winners"], np.uint8), lists=np.array(rec["lists"], np.int32),
+                            list_step=np.array(rec["list_step"], np.int32))
+        print("blokus game", seed, "steps", T, "max legal", max(rec["n_valid"]), "final scores", rec["score"][-1],
+              "winners", rec["winners"][-1], "terminal", rec["terminal"][-1])
+    cases = bonus_cases(R)
+    np.savez_compressed(os.path.join(out_dir, "blokus_bonus.npz"),
+                        **{k: np.array([c[k] for c in cases]) for k in cases[0]})

@@ -191,3 +191,110 @@ def ttt_rollout(st, seed, first_env_id, T, n_threads=1):
     f.restype = None
     f(st.n_cells, st.P, len(st.lines), _p(st.lines), st.B, seed, first_env_id, T,
       _p(st.occ), _p(st.winner), _p(st.to_move), stats, n_threads)
+
+
+# ------------------------------------------------------------------ Blokus
+BLOKUS_PIECES = ["monomino1", "domino1", "trominoe1", "trominoe2", "tetrominoes1", "tetrominoes2", "tetrominoes3",
+                 "tetrominoes4", "tetrominoes5", "pentominoe1", "pentominoe2", "pentominoe3", "pentominoe4",
+                 "pentominoe5", "pentominoe6", "pentominoe7", "pentominoe8", "pentominoe9", "pentominoe10",
+                 "pentominoe11", "pentominoe12"]
+BLOKUS_ORIENTATIONS = ["north", "northeast", "east", "southeast", "south", "southwest", "west", "northwest"]
+
+
+def blokus_encode(piece, x, y, orient, shift):
+    return ((piece * 400 + y * 20 + x) * 8 + orient) * 5 + shift
+
+
+def blokus_decode(aid):
+    shift, o, cell, piece = aid % 5, (aid // 5) % 8, (aid // 40) % 400, aid // 16000
+    return piece, cell % 20, cell // 20, o, shift
+
+
+def blokus_action_string(aid):
+    if aid < 0:
+        return ""
+    piece, x, y, o, shift = blokus_decode(int(aid))
+    return "%s;(%d, %d);%s%d" % (BLOKUS_PIECES[piece], x, y, BLOKUS_ORIENTATIONS[o], shift)
+
+
+def blokus_action_id(s):
+    if s == "":
+        return -1
+    name, idx, orient = s.split(";")
+    x, y = [int(v) for v in idx.replace("(", "").replace(")", "").split(",")]
+    return blokus_encode(BLOKUS_PIECES.index(name), x, y, BLOKUS_ORIENTATIONS.index(orient[:-1]), int(orient[-1]))
+
+
+def blokus_placement(piece, orient, shift):
+    cells = np.zeros((5, 2), dtype=np.int8)
+    lib().orc_blokus_placement(C.c_int(piece), C.c_int(orient), C.c_int(shift), _p(cells))
+    return cells[:lib().orc_blokus_piece_cells(C.c_int(piece))]
+
+
+class BlokusState:
+    def __init__(self, B):
+        self.B = B
+        self.occ = np.zeros((B, 4, 20), dtype=np.uint32)
+        self.inv = np.zeros((B, 4), dtype=np.uint32)
+        self.score = np.zeros((B, 4), dtype=np.int32)
+        self.round = np.zeros(B, dtype=np.int32)
+        self.to_move = np.zeros(B, dtype=np.int32)
+        self.tcount = np.zeros(B, dtype=np.uint32)
+        self.tstep = np.zeros(B, dtype=np.uint32)
+        self.n_episodes = np.zeros(B, dtype=np.uint32)
+        self.win_count = np.zeros((4, B), dtype=np.uint32)
+        self.len_sum = np.zeros(B, dtype=np.uint32)
+        self.score_sum = np.zeros((4, B), dtype=np.int32)
+        blokus_reset(self)
+
+    @property
+    def board(self):
+        out = np.zeros((self.B, 20, 20), dtype=np.int8)
+        lib().orc_blokus_board(C.c_int64(self.B), _p(self.occ), _p(out))
+        return out
+
+    def set_board(self, board):
+        """board int [B,20,20] with 0 empty / colour 1..4 -> bitboards"""
+        board = np.asarray(board)
+        self.occ[:] = 0
+        for c in range(4):
+            bits = (board == c + 1).astype(np.uint32) << np.arange(20, dtype=np.uint32)[None, None, :]
+            self.occ[:, c, :] = bits.sum(axis=2).astype(np.uint32)
+
+
+class _BlokusStats(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum")]
+
+
+def blokus_reset(st):
+    lib().orc_blokus_reset(C.c_int64(st.B), _p(st.occ), _p(st.inv), _p(st.score), _p(st.round), _p(st.to_move))
+
+
+def blokus_valid(st, player=None, cap=0, n_threads=1):
+    """(count[B], ids[B, cap] or None) for the player to move (or player[b])."""
+    count = np.zeros(st.B, dtype=np.int32)
+    ids = np.full((st.B, cap), -1, dtype=np.int32) if cap > 0 else None
+    pl = None if player is None else np.ascontiguousarray(player, dtype=np.int8)
+    lib().orc_blokus_valid(C.c_int64(st.B), _p(st.occ), _p(st.inv), _p(st.score), _p(st.round), _p(st.to_move),
+                           None if pl is None else _p(pl), _p(count), None if ids is None else _p(ids),
+                           C.c_int(cap), C.c_int(n_threads))
+    return count, ids
+
+
+def blokus_step(st, action, n_threads=1):
+    a = _chk(np.ascontiguousarray(action, dtype=np.int32), np.int32, (st.B,))
+    reward = np.zeros(st.B, dtype=np.int8)
+    terminal = np.zeros(st.B, dtype=np.uint8)
+    winners = np.zeros(st.B, dtype=np.uint8)
+    lib().orc_blokus_step(C.c_int64(st.B), _p(st.occ), _p(st.inv), _p(st.score), _p(st.round), _p(st.to_move),
+                          _p(a), _p(reward), _p(terminal), _p(winners), C.c_int(n_threads))
+    return reward, terminal, winners
+
+
+def blokus_rollout(st, seed, first_env_id, T, n_threads=1):
+    stats = _BlokusStats(*[_p(getattr(st, n)) for n, _ in _BlokusStats._fields_])
+    f = lib().orc_blokus_rollout
+    f.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  _BlokusStats, C.c_int]
+    f.restype = None
+    f(st.B, seed, first_env_id, T, _p(st.occ), _p(st.inv), _p(st.score), _p(st.round), _p(st.to_move), stats, n_threads)

@@ -156,3 +156,76 @@ class HipTTT:
 
     def lines(self):
         return sorted(self.tb.lines())
+
+
+# ------------------------------------------------------------------ Blokus
+class OracleBlokus:
+    name = "oracle"
+
+    def __init__(self, B):
+        self.B = B
+        self.st = O.BlokusState(B)
+
+    def set_state(self, board, inv, score, rnd, to_move):
+        self.st.set_board(board)
+        self.st.inv[:] = inv
+        self.st.score[:] = score
+        self.st.round[:] = rnd
+        self.st.to_move[:] = to_move
+
+    def valid(self, cap, player=None):
+        return O.blokus_valid(self.st, player=player, cap=cap, n_threads=8)
+
+    def step(self, action):
+        return O.blokus_step(self.st, action, n_threads=8)
+
+    def state(self):
+        s = self.st
+        return dict(board=s.board, inv=s.inv.copy(), score=s.score.copy(), round=s.round.copy(), to_move=s.to_move.copy())
+
+
+class HipBlokus:
+    name = "hip"
+
+    def __init__(self, B):
+        import torch
+        from colosseumrl_amd.batched import BlokusBatch
+        self.torch = torch
+        self.B = B
+        self.bb = BlokusBatch(B)
+
+    def set_state(self, board, inv, score, rnd, to_move):
+        t = self.torch
+        board = np.asarray(board)
+        occ = np.zeros((self.B, 4, 20), np.uint32)
+        for c in range(4):
+            occ[:, c, :] = ((board == c + 1).astype(np.uint32) << np.arange(20, dtype=np.uint32)[None, None, :]).sum(axis=2)
+        dev = self.bb.device
+        self.bb.occ.copy_(t.from_numpy(occ.view(np.int32)).to(dev))
+        self.bb.inv.copy_(t.from_numpy(np.asarray(inv, np.uint32).view(np.int32).reshape(self.B, 4).copy()).to(dev))
+        self.bb.score.copy_(t.from_numpy(np.asarray(score, np.int32).reshape(self.B, 4).copy()).to(dev))
+        self.bb.round.copy_(t.from_numpy(np.asarray(rnd, np.int32).reshape(self.B).copy()).to(dev))
+        self.bb.to_move.copy_(t.from_numpy(np.asarray(to_move, np.int32).reshape(self.B).copy()).to(dev))
+
+    def valid(self, cap, player=None):
+        pl = None if player is None else self.torch.from_numpy(np.ascontiguousarray(player, np.int8)).to(self.bb.device)
+        count, mask = self.bb.valid(player=pl, want_mask=True)
+        count = count.cpu().numpy()
+        mask = mask.cpu().numpy().view(np.uint32)
+        ids = np.full((self.B, cap), -1, np.int32)
+        for e in range(self.B):
+            bits = np.unpackbits(mask[e].view(np.uint8), bitorder="little")
+            nz = np.nonzero(bits)[0]
+            assert len(nz) == count[e], (len(nz), count[e])
+            ids[e, :len(nz)] = nz[:cap]
+        return count, ids
+
+    def step(self, action):
+        a = self.torch.from_numpy(np.ascontiguousarray(action, np.int32)).to(self.bb.device)
+        r, t, w = self.bb.step(a)
+        return r.cpu().numpy(), t.cpu().numpy(), w.cpu().numpy()
+
+    def state(self):
+        bb = self.bb
+        return dict(board=bb.board().cpu().numpy(), inv=bb.inv.cpu().numpy().view(np.uint32), score=bb.score.cpu().numpy(),
+                    round=bb.round.cpu().numpy(), to_move=bb.to_move.cpu().numpy())

@@ -1,0 +1,61 @@
+"""Replay the reference's Blokus games (tests/golden/blokus_game_*.npz) through a backend."""
+import numpy as np
+
+GAMES = list(range(1, 9))
+
+
+def list_hash(ids):
+    h = np.uint64(1469598103934665603)
+    with np.errstate(over="ignore"):
+        for v in ids:
+            h = (h ^ np.uint64(int(v) & 0xFFFFFFFF)) * np.uint64(1099511628211)
+    return h
+
+
+def replay_games(golden, be):
+    """be: backend over len(GAMES) envs with methods valid(cap)->(count, ids), step(action)->(r,t,w), state()."""
+    games = [golden("blokus_game_%d" % g) for g in GAMES]
+    T = max(len(g["action"]) for g in games)
+    E = len(games)
+    alive = np.ones(E, bool)
+    n_lists = 0
+    for t in range(T):
+        count, ids = be.valid(2048)
+        action = np.full(E, -1, np.int32)
+        for e, g in enumerate(games):
+            if t >= len(g["action"]):
+                alive[e] = False
+                continue
+            assert count[e] == g["n_valid"][t], ("n_valid", e, t, count[e], g["n_valid"][t])
+            row = ids[e, :count[e]]
+            assert list_hash(row) == g["valid_hash"][t], ("valid list order", e, t)
+            where = np.nonzero(g["list_step"] == t)[0]
+            if len(where):
+                assert np.array_equal(g["lists"][where[0]][:count[e]], row)
+                n_lists += 1
+            action[e] = g["action"][t]
+        r, term, win = be.step(action)
+        s = be.state()
+        for e, g in enumerate(games):
+            if not alive[e] or t >= len(g["action"]):
+                continue
+            assert np.array_equal(s["board"][e], g["board"][t]), ("board", e, t)
+            assert np.array_equal(s["inv"][e], g["inv"][t]), ("inventory", e, t)
+            assert np.array_equal(s["score"][e], g["score"][t]), ("score", e, t)
+            assert s["round"][e] == g["round"][t] and s["to_move"][e] == g["next_player"][t], ("turn", e, t)
+            assert r[e] == g["reward"][t] and term[e] == g["terminal"][t] and win[e] == g["winners"][t], ("outcome", e, t)
+    assert n_lists > 100
+    return T
+
+
+def check_bonus(golden, make_backend):
+    g = golden("blokus_bonus")
+    n = len(g["action"])
+    be = make_backend(n)
+    be.set_state(g["before"], g["inv_before"], g["score_before"], g["round"], np.zeros(n, np.int32))
+    r, term, win = be.step(g["action"].astype(np.int32))
+    s = be.state()
+    assert np.array_equal(s["board"], g["board"]) and np.array_equal(s["inv"], g["inv"])
+    assert np.array_equal(s["score"], g["score"]) and s["score"][0, 0] == 101 and s["score"][1, 0] == 97   # +20 / +15
+    assert np.array_equal(r, g["reward"]) and np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
+    assert np.array_equal(s["round"], g["next_round"]) and np.array_equal(s["to_move"], g["next_player"])
