@@ -123,3 +123,55 @@ def gen(R, out_dir, n_games=8):
     cases = bonus_cases(R)
     np.savez_compressed(os.path.join(out_dir, "blokus_bonus.npz"),
                         **{k: np.array([c[k] for c in cases]) for k in cases[0]})
+    gen_observe(R, out_dir)
+
+
+def gen_observe(R, out_dir, n_steps=28):
+    """state_to_observation + perspective conversions along the first steps of golden game 1 (replayed
+    through the reference's own next_state)."""
+    import re
+    g = np.load(os.path.join(out_dir, "blokus_game_1.npz"))
+    env = R["blokus"]()
+    state, players = env.new_state()
+    nums = re.compile(r"-?\d+")
+    rec = dict(board=[], inv=[], score=[], round=[], player=[], obs_board=[], obs_pieces=[], obs_score=[],
+               conv_in=[], conv_player=[], conv_out=[], conv_back=[])
+
+    def dec(aid):
+        shift, o, cell, piece = aid % 5, (aid // 5) % 8, (aid // 40) % 400, aid // 16000
+        return "%s;(%d, %d);%s%d" % (PIECES[piece], cell % 20, cell // 20, ORIENT[o], shift)
+
+    def enc_tolerant(s):
+        # the reference emits 'np.int32(17)' inside the tuple under numpy 2 (SURVEY Appendix B)
+        name, idx, orient = s.split(";")
+        x, y = [int(v) for v in nums.findall(idx.replace("int32", ""))]
+        return ((PIECES.index(name) * 400 + y * 20 + x) * 8 + ORIENT.index(orient[:-1])) * 5 + int(orient[-1])
+
+    for t in range(n_steps):
+        aid = int(g["action"][t])
+        state, players, _, term, _ = env.next_state(state, players, [dec(aid) if aid >= 0 else ""])
+        for pl in range(4):
+            o = env.state_to_observation(state, pl)
+            rec["board"].append(state[0].board_contents.astype(np.int8).copy())
+            rec["inv"].append([inv_mask(p) for p in state[2]])
+            rec["score"].append([p.player_score for p in state[2]])
+            rec["round"].append(state[1])
+            rec["player"].append(pl)
+            rec["obs_board"].append(np.asarray(o["board"]).astype(np.int8))
+            rec["obs_pieces"].append(o["pieces"].copy())
+            rec["obs_score"].append(np.asarray(o["score"]).astype(np.int32))
+            if aid >= 0:
+                conv = env.convert_real_action_to_player_perspective_action(dec(aid), pl)
+                rec["conv_in"].append(aid)
+                rec["conv_player"].append(pl)
+                rec["conv_out"].append(enc_tolerant(conv))
+                back = env.convert_player_perspective_action_to_real_action(dec(enc_tolerant(conv)), pl)
+                rec["conv_back"].append(enc_tolerant(back))
+    np.savez_compressed(os.path.join(out_dir, "blokus_observe.npz"), **{k: np.array(v) for k, v in rec.items()})
+    print("blokus observe fixtures", len(rec["player"]))
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_loader
+    gen_observe(ref_loader.load(), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))

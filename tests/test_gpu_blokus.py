@@ -99,3 +99,36 @@ def test_rollout_full_size_properties():
     half = BlokusBatch(B // 2, first_env_id=B // 2)
     half.rollout(T, seed)
     assert torch.equal(half.occ, bb.occ[B // 2:]) and torch.equal(half.score, bb.score[B // 2:])
+
+
+def test_dropin_env_golden(golden):
+    """BlokusEnvironment drop-in: strings in, (Board, round, [AI]) out, replaying a reference game."""
+    from colosseumrl_amd import get_environment
+    from colosseumrl_amd.envs.blokus import actions as A
+    g = golden("blokus_game_4")
+    env = get_environment("blokus")()
+    state, players = env.new_state()
+    T = len(g["action"])
+    for t in range(T):
+        va = env.valid_actions(state, players[0])
+        assert len([a for a in va if a]) == g["n_valid"][t]
+        where = np.nonzero(g["list_step"] == t)[0]
+        if len(where) and t % 12 == 0:
+            assert va == [A.id_to_string(i) for i in g["lists"][where[0]][:g["n_valid"][t]]] or (va == [""] and g["n_valid"][t] == 0)
+        astr = A.id_to_string(int(g["action"][t]))
+        if astr and t % 9 == 0:
+            assert env.is_valid_action(state, players[0], astr)
+            d = env.valid_actions_dict(state, players[0])
+            piece, idx, orient = A.string_to_action(astr)
+            assert orient in d[piece][idx]
+        state, players, rewards, terminal, winners = env.next_state(state, players, [astr])
+        assert np.array_equal(state[0].board_contents, g["board"][t]) and state[0].board_contents.dtype == np.int64
+        assert [p.player_score for p in state[2]] == g["score"][t].tolist() and state[1] == g["round"][t]
+        assert [p.inventory_mask() for p in state[2]] == g["inv"][t].tolist()
+        assert players == [int(g["next_player"][t])] and rewards == [int(g["reward"][t])] and terminal == bool(g["terminal"][t])
+        assert (winners is None and not terminal) or sum(1 << w for w in winners) == g["winners"][t]
+    assert terminal
+    assert env.is_valid_action(state, 0, "") is False
+    assert env.is_valid_action(env.new_state()[0], 0, "monomino1;(5, 5);north0") is False
+    with pytest.raises(ValueError):
+        env.next_state(state, [0], [A.id_to_string(int(g["action"][0]))])      # piece already played
