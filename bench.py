@@ -10,7 +10,8 @@ agent drawn from the counter-based RNG, auto-reset on terminal.  State is reside
 timed region; the timed region is W untimed + exactly K timed steps, issued as fused launches of
 --chunk steps, bracketed by barrier + synchronize; the time is the max over ranks.  With N > 1 each
 rank owns the games [rank*B, (rank+1)*B) (weak scaling, no data-path collective) and the per-game
-results are gathered once with a single RCCL all_gather at the end (inside the timed region).
+results are gathered once with a single RCCL all_gather at the end (inside the timed region);
+the sharding / gather code is colosseumrl_amd.parallel.ShardedRollout (gloo-tested on CPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -70,18 +71,6 @@ def make_stepper(game, kw, batch, device, first_env_id):
     if game == "blokus":
         return batched.BlokusBatch(batch=batch, device=device, first_env_id=first_env_id, **kw)
     raise ValueError(game)
-
-
-def run_steps(stepper, steps, chunk, seed):
-    """Issue exactly `steps` env-steps as fused launches of <= chunk steps.  Returns the number of launches."""
-    n = 0
-    left = steps
-    while left > 0:
-        t = min(chunk, left)
-        stepper.rollout(t, seed)
-        left -= t
-        n += 1
-    return n
 
 
 def cpu_baseline(game, kw, seconds=12.0):
@@ -156,7 +145,9 @@ def main():
     game, kw, batch = WORKLOADS[args.workload]
     if args.batch > 0:
         batch = args.batch
-    stepper = make_stepper(game, kw, batch, device, first_env_id=rank * batch)
+    from colosseumrl_amd.parallel import ShardedRollout
+    # weak scaling: every rank owns `batch` games; global ids rank*batch .. (rank+1)*batch - 1
+    sr = ShardedRollout(lambda batch, first_env_id: make_stepper(game, kw, batch, device, first_env_id), world * batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,24 +155,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(stepper, args.warmup, args.chunk, args.seed)
-    # the rollout epilogue (result packing + the gather) is warmed up too: torch loads its kernels lazily
-    warm = stepper.results()
-    if world > 1:
-        dist.all_gather_into_tensor(torch.empty((world,) + tuple(warm.shape), dtype=warm.dtype, device=device), warm)
-    del warm
+    sr.rollout(args.warmup, args.seed, args.chunk)
+    sr.gather()   # the rollout epilogue (result packing + the gather) is warmed up too: torch loads kernels lazily
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()                                           # same stream the kernels are launched on
-    launches = run_steps(stepper, args.steps, args.chunk, args.seed)
+    launches = sr.rollout(args.steps, args.seed, args.chunk)
     ev1.record()
-    results = stepper.results()
-    if world > 1:                                          # the one collective: per-game results to every rank
-        gathered = torch.empty((world,) + tuple(results.shape), dtype=results.dtype, device=device)
-        dist.all_gather_into_tensor(gathered, results)
-    else:
-        gathered = results.unsqueeze(0)
+    gathered = sr.gather()                                 # the one collective: per-game results to every rank
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)

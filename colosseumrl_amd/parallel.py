@@ -1,0 +1,84 @@
+"""Multi-GPU sharding of the batched steppers: one process per GPU, games split by global id.
+
+Every game is independent, so the only parallelism is over the batch axis: rank r of W
+owns the contiguous block of global game ids ``shard_bounds(G, r, W)`` and runs the same kernels on
+it; the random agent's RNG is keyed by the GLOBAL game id, so results do not depend on W.  There is
+no data-path collective while stepping.  The single exchange is at the end of a rollout: the per-game
+result records are concatenated across ranks with ONE ``all_gather`` (RCCL over xGMI with the
+``nccl`` backend; ~13-44 bytes per game, latency-bound).  The reference has no counterpart (it has no
+device code at all).
+
+The collective layer is backend-agnostic (``gloo`` on CPU tensors in the tests).
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of the games owned by `rank`: contiguous blocks, the first total % world ranks get one extra."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_results(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Concatenate per-game result rows [n_local, k] of all ranks, in global game order, on every rank.
+
+    One collective: shards are padded to the largest shard so a single ``all_gather_into_tensor`` moves
+    everything (a ring over the 7 xGMI links per GPU is ample for a few MB)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(total, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], hi - lo))
+    widest = -(-total // world)
+    padded = local
+    if local.shape[0] != widest:
+        padded = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if total == world * widest:
+        return out
+    pieces = []
+    for r in range(world):
+        a, b = shard_bounds(total, r, world)
+        pieces.append(out[r * widest: r * widest + (b - a)])
+    return torch.cat(pieces, dim=0)
+
+
+class ShardedRollout:
+    """Random-agent rollouts of `global_batch` games spread over the ranks of the default process group.
+
+    make_stepper(batch=n, first_env_id=lo) must return an object with ``rollout(steps, seed)`` and
+    ``results() -> tensor [n, k]`` (``TronBatch`` / ``TTTBatch`` / ``BlokusBatch`` partials).
+    """
+
+    def __init__(self, make_stepper: Callable, global_batch: int, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.total = int(global_batch)
+        if dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.lo, self.hi = shard_bounds(self.total, self.rank, self.world)
+        self.stepper = make_stepper(batch=self.hi - self.lo, first_env_id=self.lo)
+
+    def rollout(self, steps: int, seed: int = 0, chunk: int = 512) -> int:
+        """Exactly `steps` env-steps for every local game, as fused launches of <= chunk steps."""
+        launches, left = 0, int(steps)
+        while left > 0:
+            t = min(int(chunk), left)
+            self.stepper.rollout(t, seed)
+            left -= t
+            launches += 1
+        return launches
+
+    def gather(self) -> torch.Tensor:
+        """Per-game results of ALL games on every rank (the one collective of a rollout)."""
+        return gather_results(self.stepper.results(), self.total, self.group)
