@@ -50,7 +50,8 @@ __device__ __forceinline__ void tron_split_heads(const TronGeom &g, TronRegs<P> 
 // Board views: how a step reads "who owns this cell" (0 = empty) and writes a trail cell.
 struct PlainBoard {                 // canonical int8 cells, global memory
     int8_t *p;
-    __device__ __forceinline__ int owner(const int c) const { return p[c]; }
+    __device__ __forceinline__ int raw(const int c) const { return p[c]; }
+    __device__ __forceinline__ int owner(const int r) const { return r; }
     __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (int8_t)who; }
 };
 // LDS cells carry an episode tag: byte = tag << OB | owner.  A cell counts as occupied only when its
@@ -60,60 +61,70 @@ template <int OB>
 struct TaggedBoard {
     uint8_t *p;
     uint32_t tagbits;               // tag << OB
-    __device__ __forceinline__ int owner(const int c) const
+    __device__ __forceinline__ int raw(const int c) const { return p[c]; }
+    __device__ __forceinline__ int owner(const int r) const
     {
-        const uint32_t raw = p[c];
-        return ((raw ^ tagbits) >> OB) == 0 ? (int)(raw & ((1u << OB) - 1u)) : 0;
+        return (((uint32_t)r ^ tagbits) >> OB) == 0 ? (int)((uint32_t)r & ((1u << OB) - 1u)) : 0;
     }
     __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (uint8_t)(tagbits | (uint32_t)who); }
 };
 
-// Straight-line code: every decision is a select, so a wave never diverges inside a step.
+// phase 1 of a step: every player's target cell and the raw probe of it (CyTronGrid.pyx:21-41).
+// All P probes are issued back to back; probes of dead / out-of-board players read cell 0 and are ignored.
+template <int P>
+struct TronProbe {
+    int tgt[P], raw[P], ndir[P], nx[P], ny[P];
+    bool oob[P];
+};
+
 template <int P, typename BOARD>
-__device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &bd, const bool valid,
-                                               TronRegs<P> &s, const int (&act)[P],
-                                               int (&rew)[P], int &term, int &wmask)
+__device__ __forceinline__ void tron_probe(const TronGeom &g, const BOARD &bd, const TronRegs<P> &s,
+                                           const int (&act)[P], TronProbe<P> &pr)
 {
     const int N = g.N;
-    int tgt[P], val[P], ndir[P], nx[P], ny[P];
-    bool oob[P], moved[P];
-    // phase 1: every player's target cell, probes issued together (CyTronGrid.pyx:21-41).
-    // Probes of dead / out-of-board players read cell 0 and are ignored.
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int dir = (s.d[i] + act[i] + 4) & 3;
-        nx[i] = s.x[i] + (dir == 1) - (dir == 3);
-        ny[i] = s.y[i] + (dir == 2) - (dir == 0);
-        ndir[i] = dir;
-        oob[i] = ((unsigned)nx[i] >= (unsigned)N) | ((unsigned)ny[i] >= (unsigned)N);
-        tgt[i] = oob[i] ? 0 : ny[i] * N + nx[i];
-        val[i] = bd.owner(tgt[i]);
+        const int dir = (s.d[i] + act[i]) & 3;          // act in {0, 1, 3}: forward, right, left (= -1 mod 4)
+        pr.nx[i] = s.x[i] + (dir == 1) - (dir == 3);
+        pr.ny[i] = s.y[i] + (dir == 2) - (dir == 0);
+        pr.ndir[i] = dir;
+        pr.oob[i] = ((unsigned)pr.nx[i] >= (unsigned)N) | ((unsigned)pr.ny[i] >= (unsigned)N);
+        pr.tgt[i] = pr.oob[i] ? 0 : pr.ny[i] * N + pr.nx[i];
     }
-    // phase 2: the reference's sequential resolution, on registers (CyTronGrid.pyx:15-62)
+#pragma unroll
+    for (int i = 0; i < P; ++i) pr.raw[i] = bd.raw(pr.tgt[i]);
+}
+
+// phases 2+3: the reference's sequential resolution on registers (CyTronGrid.pyx:15-62), trail writes, and the
+// reward / terminal / winners tail (TronGridEnvironment.py:309-321).  Straight-line code: every decision is a
+// select, so a wave never diverges inside a step.
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, TronRegs<P> &s, const TronProbe<P> &pr,
+                                             int (&rew)[P], int &term, int &wmask)
+{
+    bool moved[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
-        int v = val[i];
+        int v = bd.owner(pr.raw[i]);
 #pragma unroll
         for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
-            v = (moved[j] & (tgt[j] == tgt[i])) ? j + 1 : v;
-        const bool wall = run & oob[i];                 // :47-48
-        const bool crash = run & !oob[i] & (v > 0);     // :51-57
-        moved[i] = run & !oob[i] & (v <= 0);            // :60-62
-        s.d[i] = run ? ndir[i] : s.d[i];                // :44 direction is committed even if the move dies
+            v = (moved[j] & (pr.tgt[j] == pr.tgt[i])) ? j + 1 : v;
+        const bool wall = run & pr.oob[i];              // :47-48
+        const bool crash = run & !pr.oob[i] & (v > 0);  // :51-57
+        moved[i] = run & !pr.oob[i] & (v <= 0);         // :60-62
+        s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
         s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
 #pragma unroll
         for (int q = 0; q < P; ++q)                     // :56-57 owner's head is this very cell -> owner dies too
-            s.k[q] = (crash & (q == v - 1) & (s.h[q] == tgt[i])) ? i + 1 : s.k[q];
-        s.h[i] = moved[i] ? tgt[i] : s.h[i];
-        s.x[i] = moved[i] ? nx[i] : s.x[i];
-        s.y[i] = moved[i] ? ny[i] : s.y[i];
+            s.k[q] = (crash & (q == v - 1) & (s.h[q] == pr.tgt[i])) ? i + 1 : s.k[q];
+        s.h[i] = moved[i] ? pr.tgt[i] : s.h[i];
+        s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
+        s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
     }
-    // phase 3: trail writes
 #pragma unroll
     for (int i = 0; i < P; ++i)
-        if (valid & moved[i]) bd.put(tgt[i], i + 1);
-    // TronGridEnvironment.py:309-321
+        if (valid & moved[i]) bd.put(pr.tgt[i], i + 1);
     int alive = 0;
     wmask = 0;
 #pragma unroll
@@ -125,6 +136,16 @@ __device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &b
     wmask = term ? wmask : 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) rew[i] = (s.k[i] > 0) ? -1 : (term ? 10 : 1);
+}
+
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &bd, const bool valid,
+                                               TronRegs<P> &s, const int (&act)[P],
+                                               int (&rew)[P], int &term, int &wmask)
+{
+    TronProbe<P> pr;
+    tron_probe<P>(g, bd, s, act, pr);
+    tron_resolve<P>(bd, valid, s, pr, rew, term, wmask);
 }
 
 // uniform random actions for step c of global env g (contract: include/colosseum_hip.h, crl_tron_rollout).
@@ -169,7 +190,7 @@ struct TronRng {
             uint32_t &x = (i < 4) ? v : u;
             const uint32_t a3 = __umulhi(x, 3u);        // next base-3 digit of the fraction x / 2^32
             x *= 3u;
-            act[i] = (a3 == 0) ? 0 : ((a3 == 1) ? 1 : -1);
+            act[i] = (int)(a3 + (a3 >> 1));             // 0, 1, 3 == forward, right, left (-1 mod 4)
         }
         if (odd) {
             if ((c & 7u) == 7u) {
@@ -432,7 +453,9 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
 }
 
 // T fused steps, boards resident in LDS.  256 threads = 4 independent waves; wave w owns the LDS slab
-// [w*64*stride, (w+1)*64*stride) holding its 64 boards (stride = N*N rounded up to 16).
+// [w*64*stride, (w+1)*64*stride) holding its 64 boards.  stride = N*N rounded up to a multiple of 4 whose
+// dword count is ODD: lane l's board starts at dword l*stride/4, so the 32 lanes of a half-wave that probe the
+// same cell of their boards (every game right after a reset!) hit 32 different LDS banks instead of 8.
 // No workgroup barrier is needed: a lane only ever touches its own board, and the copy in / copy out
 // of a wave's slab is done by that wave.
 template <int P>
@@ -453,16 +476,21 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
     const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
     int8_t *slab = lds + (size_t)wave * CRL_WAVE * stride;
     int8_t *gslab = board + env0 * NN;
-    // ---- copy in: HBM -> LDS, coalesced 16-byte pieces (stride == NN when NN % 16 == 0)
-    if (stride == NN) {
+    const bool wide = (NN & 15) == 0;                           // 16-byte pieces never straddle two boards
+    // ---- copy in: HBM -> LDS (coalesced 16-byte loads, 4 dword stores into the padded slab)
+    if (wide) {
         const int bytes = n_env * NN;
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16)
-            *reinterpret_cast<uint4 *>(slab + off) = *reinterpret_cast<const uint4 *>(gslab + off);
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = off / NN, c = off - e * NN;
+            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(slab + e * stride + c);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
     } else {
         for (int e = 0; e < n_env; ++e)
             for (int c = lane; c < NN; c += CRL_WAVE) slab[e * stride + c] = gslab[(int64_t)e * NN + c];
     }
-    TronRegs<P> s;
+    TronRegs<P> s, fresh;                                       // fresh = the start layout, kept in VGPRs for resets
     int act[P], rew[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -471,6 +499,11 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
         s.k[p] = valid ? deaths[p * B + bb] : 1;
     }
     tron_split_heads<P>(g, s);
+    tron_regs_to_start<P>(cfg, g, fresh);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        asm volatile("" : "+v"(fresh.h[p]), "+v"(fresh.x[p]), "+v"(fresh.y[p]), "+v"(fresh.d[p]));
+    }
     TronAcc<P> acc;
     acc.load(st, valid, bb);
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
@@ -481,11 +514,14 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
     TaggedBoard<OB> bd{reinterpret_cast<uint8_t *>(slab + lane * stride), 0u};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // slab written by other lanes of this wave
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rng.next(gid, acc.tc, seed_lo, seed_hi, act);
     for (int t = 0; t < T; ++t) {
-        rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+        TronProbe<P> pr;
+        tron_probe<P>(g, bd, s, act, pr);                       // P ds_read_u8 in flight ...
         acc.tc += 1;
+        rng.next(gid, acc.tc, seed_lo, seed_hi, act);           // ... while the NEXT step's actions are drawn
         int term, wm;
-        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        tron_resolve<P>(bd, valid, s, pr, rew, term, wm);
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
@@ -494,13 +530,13 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
             uint32_t tag = (bd.tagbits >> OB) + 1u;
             if (tag == kTags) {                                 // tag space exhausted: one real clear
                 tag = 0;
-                for (int off = 0; off < stride; off += 16) *reinterpret_cast<uint4 *>(bd.p + off) = make_uint4(0, 0, 0, 0);
+                for (int off = 0; off < stride; off += 4) *reinterpret_cast<uint32_t *>(bd.p + off) = 0u;
             }
             bd.tagbits = tag << OB;
 #pragma unroll
-            for (int p = 0; p < P; ++p) bd.put(cfg.start_heads[p], p + 1);
+            for (int p = 0; p < P; ++p) bd.put(fresh.h[p], p + 1);
             acc.finish_episode(wm);
-            tron_regs_to_start<P>(cfg, g, s);
+            s = fresh;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -508,13 +544,13 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
     // ---- copy out: LDS -> HBM, dropping the tags (cells of older episodes become 0)
     constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);    // owner bits of 4 cells
     constexpr uint32_t TM = 0x01010101u * (kTags - 1u);         // tag bits of 4 cells, shifted down
-    if (stride == NN) {
+    if (wide) {
         const int bytes = n_env * NN;
         for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-            const int e = off / NN;                             // game this 16-byte piece belongs to (NN % 16 == 0)
+            const int e = off / NN, c = off - e * NN;           // game this 16-byte piece belongs to
             const uint32_t trep = (uint32_t)__shfl((int)(bd.tagbits >> OB), e, CRL_WAVE) * 0x01010101u;
-            const uint4 raw = *reinterpret_cast<const uint4 *>(slab + off);
-            uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(slab + e * stride + c);
+            uint32_t w[4] = {src[0], src[1], src[2], src[3]};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t diff = ((w[q] >> OB) & TM) ^ trep;               // per byte: 0 iff tag matches
@@ -720,7 +756,8 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     if (T == 0) return CRL_OK;
     hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
-    const int stride = (NN + 15) & ~15;
+    int stride = (NN + 3) & ~3;                       // bytes per board in LDS: a whole, ODD number of dwords
+    if (((stride >> 2) & 1) == 0) stride += 4;
     const size_t lds_bytes = (size_t)256 * stride;
     const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && lds_bytes <= (size_t)kLdsBudget && (((uintptr_t)board & 15) == 0);
     TRON_DISPATCH_P(cfg.P, {
