@@ -73,6 +73,7 @@ PROTOTYPES = {
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
     "crl_blokus_create": (_I, [C.POINTER(_VP)]),
     "crl_blokus_placement": (_I, [_I, _I, _I, _VP]),
+    "crl_blokus_stamps": (_I, [_VP, _I]),
     "crl_blokus_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "crl_blokus_valid": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -23,6 +23,13 @@
 
 namespace {
 
+// waves per SIMD the register allocator must leave room for.  Left alone it takes 256 VGPRs (1 wave/SIMD, the
+// 16,384 one-wave games of BASELINE config 4 then run in 16 rounds).  Measured on MI355X (tools/blokus_occ_sweep.sh):
+// 4/5/6/8 waves per SIMD -> 244/237/256/265 M env-steps/s; 8 (64 VGPRs + 96 B of spills) wins.
+#ifndef BLK_WAVES_PER_SIMD
+#define BLK_WAVES_PER_SIMD 8
+#endif
+
 constexpr int BN = 20;
 constexpr int NPIECE = 21;
 constexpr int NSHAPE = NPIECE * 8;
@@ -60,6 +67,10 @@ const int8_t kPieceCells[NPIECE] = {1, 2, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5,
 struct BlkTables {
     uint8_t cells[NSHAPE][8];   // [piece*8+orient][j] = (dx+4) | (dy+4) << 4 ; entries j >= n repeat cell 0
     uint8_t ncell[24];          // cells per piece (= its score value, ai.py:12-22)
+    uint8_t nuniq[24];          // distinct oriented shapes of the piece (1..8; 91 over all 21 pieces)
+    uint8_t uniq[NPIECE][8];    // k-th distinct orientation: orient | multiplicity << 4.  Orientations that give the
+                                // same cell set (symmetric pieces) yield the same NUMBER of legal actions, so the
+                                // count pass fits each distinct shape once and multiplies.
 };
 
 // orientation o of offset (dx,dy): ORIENTATIONS order of board.py:47, maps of computation.py:54-86
@@ -89,6 +100,30 @@ void build_tables(BlkTables &t)
                 orient_offset(o, kPieces[p][jj][0], kPieces[p][jj][1], ox, oy);
                 t.cells[p * 8 + o][j] = (uint8_t)((ox + 4) | ((oy + 4) << 4));
             }
+        // group the 8 orientations by their cell set (translation-normalised, order-independent)
+        uint32_t key[8][5];
+        for (int o = 0; o < 8; ++o) {
+            int xs[5], ys[5], mx = 99, my = 99;
+            const int n = kPieceCells[p];
+            for (int j = 0; j < n; ++j) {
+                orient_offset(o, kPieces[p][j][0], kPieces[p][j][1], xs[j], ys[j]);
+                mx = xs[j] < mx ? xs[j] : mx;
+                my = ys[j] < my ? ys[j] : my;
+            }
+            for (int j = 0; j < 5; ++j) key[o][j] = j < n ? (uint32_t)((ys[j] - my) * 16 + (xs[j] - mx)) : 999u;
+            for (int a = 0; a < 5; ++a)
+                for (int b2 = a + 1; b2 < 5; ++b2)
+                    if (key[o][b2] < key[o][a]) { const uint32_t tmp = key[o][a]; key[o][a] = key[o][b2]; key[o][b2] = tmp; }
+        }
+        int nu = 0;
+        for (int o = 0; o < 8; ++o) {
+            int same = -1;
+            for (int k = 0; k < nu && same < 0; ++k)
+                if (memcmp(key[t.uniq[p][k] & 7], key[o], sizeof(key[o])) == 0) same = k;
+            if (same >= 0) t.uniq[p][same] = (uint8_t)(t.uniq[p][same] + 16);
+            else t.uniq[p][nu++] = (uint8_t)(o | (1 << 4));
+        }
+        t.nuniq[p] = (uint8_t)nu;
     }
 }
 
@@ -97,8 +132,9 @@ struct WaveLds {
     uint32_t occ[4][BN];     // board rows per colour, bit x = column x
     uint2 ac[4][32];         // per player, index y+4: {allowed << 8, corner << 8}; rows outside the board are 0
     uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
-    uint32_t pcnt[32];       // legal-action count per inventory slot
-    uint32_t rowpre[32];     // inclusive prefix of anchors per row
+    uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
+    uint8_t items[NSHAPE];   // work list of a count / existence pass: piece << 3 | k  (k-th distinct orientation)
+    uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -140,10 +176,6 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane)
 // ---- derive allowed / corner rows of all four players from the board (lanes 0..79: player q, row y)
 __device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int round)
 {
-    if (lane < 4 * 32) {   // clear the padding rows too (two passes for 128 entries)
-    }
-    for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);
-    wave_sync();
     for (int i = lane; i < 4 * BN; i += 64) {
         const int q = i / BN, y = i - q * BN;
         const uint32_t any = L.occ[0][y] | L.occ[1][y] | L.occ[2][y] | L.occ[3][y];
@@ -190,6 +222,7 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const int 
                                                     const int y0, const int y1)
 {
     uint32_t cnt = 0;
+#pragma nounroll
     for (int y = y0; y <= y1; ++y) {
         uint32_t F = 0xffffffffu, ct[5];
 #pragma unroll
@@ -216,51 +249,60 @@ __device__ __forceinline__ void blk_row_range(const WaveLds &L, const int q, con
     y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4;
 }
 
+// work list of the distinct oriented shapes of the pieces in `inv` (piece-major); returns its length
+__device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, const uint32_t inv, const int lane)
+{
+    const bool held = lane < NPIECE && ((inv >> lane) & 1u);
+    const uint32_t nu = held ? T.nuniq[lane] : 0u;
+    const uint32_t incl = wave_scan_incl(nu, lane);
+    int pos = (int)(incl - nu);
+    for (uint32_t k = 0; k < nu; ++k) L.items[pos++] = (uint8_t)((lane << 3) | (int)k);
+    wave_sync();
+    return __builtin_amdgcn_readfirstlane(__shfl((int)incl, NPIECE - 1, 64));
+}
+
 // does player q have any legal action with inventory inv? (board.py:170-193 non-empty)
-__device__ __forceinline__ bool blk_exists(const BlkTables &T, const WaveLds &L, const int q, const uint32_t inv, const int lane)
+__device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane)
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
     if (y1 < y0 || inv == 0) return false;
     if (inv & 1u) return true;                          // the monomino fits on any anchor (anchors are allowed cells)
-    const int items = __popc(inv) * 8;
+    const int items = blk_build_items(T, L, inv, lane);
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
         const bool active = i < items;
-        const int piece = nth_set_bit32(inv, active ? i >> 3 : 0);
-        const ShapeRegs s = blk_load_shape(T, piece, i & 7);
+        const int it = active ? L.items[i] : 0;
+        const int piece = it >> 3;
+        const ShapeRegs s = blk_load_shape(T, piece, T.uniq[piece][it & 7] & 7);
         const uint32_t c = blk_shape_count<true>(L, q, s, active, y0, y1);
         if (__ballot(c > 0)) return true;
     }
     return false;
 }
 
-// legal-action count per inventory slot of player q into L.pcnt[], returns the total (valid_actions length)
+// legal-action count per piece of player q into L.pcnt[], returns the total (valid_actions length)
 __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane)
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
-    const int slots = __popc(inv);
     if (lane < 32) L.pcnt[lane] = 0;
-    wave_sync();
-    if (y1 < y0) return 0;
-    uint32_t total = 0;
-    for (int base = 0; base < slots * 8; base += 64) {
+    if (y1 < y0) { wave_sync(); return 0; }
+    const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
+    for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
-        const bool active = i < slots * 8;
-        const int piece = nth_set_bit32(inv, active ? i >> 3 : 0);
-        const ShapeRegs s = blk_load_shape(T, piece, i & 7);
-        uint32_t c = blk_shape_count<false>(L, q, s, active, y0, y1);
-        c += (uint32_t)__shfl_xor((int)c, 1, 64);       // the 8 orientations of a piece sit in 8 consecutive lanes
-        c += (uint32_t)__shfl_xor((int)c, 2, 64);
-        c += (uint32_t)__shfl_xor((int)c, 4, 64);
-        if (active && (lane & 7) == 0) L.pcnt[i >> 3] = c;
+        const bool active = i < items;
+        const int it = active ? L.items[i] : 0;
+        const int piece = it >> 3;
+        const int om = T.uniq[piece][it & 7];
+        const ShapeRegs s = blk_load_shape(T, piece, om & 7);
+        const uint32_t c = blk_shape_count<false>(L, q, s, active, y0, y1) * (uint32_t)(om >> 4);
+        if (c) atomicAdd(&L.pcnt[piece], c);
     }
     wave_sync();
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
-    total = wave_scan_incl(mine, lane);
-    total = (uint32_t)__shfl((int)total, 63, 64);
-    return total;
+    const uint32_t total = wave_scan_incl(mine, lane);
+    return (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)total, 63, 64));
 }
 
 struct BlkMove { int piece, x, y, orient, shift; };
@@ -268,17 +310,14 @@ struct BlkMove { int piece, x, y, orient, shift; };
 // the r-th (0-based) legal action of player q in reference order; blk_count() must have filled L.pcnt
 __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, uint32_t r, const int lane)
 {
-    // level 1: inventory slot
+    // level 1: the piece (pcnt is indexed by piece id; pieces not held count 0)
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
     const uint32_t incl = wave_scan_incl(mine, lane);
     const unsigned long long hit = __ballot(r < incl);
-    const int slot = __builtin_ctzll(hit);
-    r -= (uint32_t)__shfl((int)(incl - mine), slot, 64);
-    const int piece = nth_set_bit32(inv, slot);
-    const int n = T.ncell[piece];
-    // fit masks of the 8 orientations of that piece, all 20 origin rows
-    for (int i = lane; i < 8 * 32; i += 64) L.fit[i >> 5][i & 31] = 0u;
-    wave_sync();
+    const int piece = __builtin_ctzll(hit);
+    r -= (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(incl - mine), piece, 64));
+    const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
+    // fit masks of the 8 orientations of that piece, all 20 origin rows (rows outside the board stay 0)
     for (int i = lane; i < 8 * BN; i += 64) {
         const int o = i / BN, y = i - o * BN;
         const ShapeRegs s = blk_load_shape(T, piece, o);
@@ -287,50 +326,64 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro[j]].x >> s.sh[j];
         L.fit[o][y + 4] = F;                             // bit x+4
     }
-    // level 2: anchors in row-major order, one lane per anchor
+    // level 2: the anchors in row-major order.  Row lanes scatter their set bits into a list ...
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
     const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
-    if (lane < 32) L.rowpre[lane] = rinc;
+    const int n_anchor = __builtin_amdgcn_readfirstlane(__shfl((int)rinc, BN - 1, 64));
+    {
+        uint32_t m = crow;
+        int pos = (int)rinc - __popc(crow);
+        while (m) {
+            const int x = __builtin_ctz(m);
+            m &= m - 1;
+            L.alist[pos++] = (uint16_t)((lane << 8) | x);
+        }
+    }
     wave_sync();
-    const int n_anchor = (int)L.rowpre[BN - 1];
+    // ... and every lane takes one anchor: how many (orientation, shift) pairs of the piece are legal there?
+    // Shift j puts cell j on the anchor, so the shape's origin is anchor - s_j: one bit of the fit table.
+    // (origin row in [-4, 23], column in [-4, 23]: always inside the padded table, no bounds checks.)
     BlkMove mv = {piece, 0, 0, 0, 0};
     uint32_t carried = 0;
     for (int base = 0; base < n_anchor; base += 64) {
         const int a = base + lane;
         const bool active = a < n_anchor;
-        int ay = 0;
-        for (int y = 0; y < BN; ++y) ay += (L.rowpre[y] <= (uint32_t)a) ? 1 : 0;
-        ay = active ? ay : 0;
-        const uint32_t before = ay > 0 ? L.rowpre[ay - 1] : 0u;
-        const int ax = nth_set_bit32(L.ac[q][ay + 4].y >> 8, active ? a - (int)before : 0);
-        uint32_t cnt = 0;
-        unsigned long long vm = 0;
-        for (int o = 0; o < 8; ++o) {                    // wave-uniform loops over (orientation, shift)
-            const ShapeRegs s = blk_load_shape(T, piece, o);
+        const int packed = active ? (int)L.alist[a] : 0;
+        const int ay = packed >> 8, ax = packed & 0xff;
+        uint32_t cnt = 0, vlo = 0, vhi = 0;              // valid (orientation, shift) pairs: bit o*5+j
+#pragma nounroll
+        for (int o = 0; o < 8; ++o) {                    // wave-uniform loops; shape data via scalar registers
+            const uint2 raw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + o][0]);
+            const uint32_t c03 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x);
+            const uint32_t c4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
+            const uint32_t *frow = &L.fit[o][0];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                // shift j puts cell j on the anchor: origin = anchor - s_j
-                const int ty = ay - (s.ro[j] - 4), tx = ax - (s.sh[j] - 4);
-                const bool ok = active && j < n && ty >= -4 && ty < BN + 4 && tx >= -4 && tx < 28 &&
-                                ((L.fit[o][ty + 4] >> (tx + 4)) & 1u);
-                cnt += ok ? 1u : 0u;
-                vm |= ok ? (1ull << (o * 5 + j)) : 0ull;
+                if (j < n) {
+                    const uint32_t cb = (j < 4) ? (c03 >> (8 * j)) & 0xffu : c4 & 0xffu;
+                    const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);          // dx + 4, dy + 4
+                    const uint32_t bit = (frow[ay + 8 - dy4] >> (ax + 8 - dx4)) & 1u;   // fit[o][ty + 4] bit tx + 4
+                    cnt += bit;
+                    const int idx = o * 5 + j;
+                    if (idx < 32) vlo |= bit << idx; else vhi |= bit << (idx - 32);
+                }
             }
         }
+        cnt = active ? cnt : 0u;
         const uint32_t inc = wave_scan_incl(cnt, lane);
         const unsigned long long h2 = __ballot(active && r < carried + inc);
         if (h2) {
             const int src = __builtin_ctzll(h2);
             const uint32_t r2 = r - carried - (uint32_t)__shfl((int)(inc - cnt), src, 64);
-            const int bit = nth_set_bit64(vm, (int)r2);  // level 3: (orientation, shift) in order
-            mv.x = __shfl(ax, src, 64);
-            mv.y = __shfl(ay, src, 64);
-            const int b = __shfl(bit, src, 64);
+            const int bit = nth_set_bit64(((unsigned long long)vhi << 32) | vlo, (int)r2);   // level 3, in order
+            mv.x = __builtin_amdgcn_readfirstlane(__shfl(ax, src, 64));
+            mv.y = __builtin_amdgcn_readfirstlane(__shfl(ay, src, 64));
+            const int b = __builtin_amdgcn_readfirstlane(__shfl(bit, src, 64));
             mv.orient = b / 5;
             mv.shift = b - mv.orient * 5;
             return mv;
         }
-        carried += (uint32_t)__shfl((int)inc, 63, 64);
+        carried += (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)inc, 63, 64));
     }
     return mv;   // unreachable when r < total
 }
@@ -390,7 +443,10 @@ __device__ __forceinline__ void blk_load_state(WaveLds &L, const int64_t b, cons
 {
     for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = occ[b * 4 * BN + i];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { inv[c] = inv_g[b * 4 + c]; score[c] = score_g[b * 4 + c]; }
+    for (int c = 0; c < 4; ++c) {                      // wave-uniform: keep them in SGPRs
+        inv[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv_g[b * 4 + c]);
+        score[c] = __builtin_amdgcn_readfirstlane(score_g[b * 4 + c]);
+    }
     wave_sync();
 }
 
@@ -437,12 +493,29 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
     __syncthreads();                                                                              \
     const int lane = threadIdx.x & 63;                                                            \
     WaveLds &L = Lw[threadIdx.x >> 6];                                                            \
+    /* rows -4..-1 and 20..27 of the padded row tables are zero for the whole launch (only 0..19 are rewritten) */ \
+    for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);            \
+    for (int i = lane; i < 8 * 32; i += 64) L.fit[i >> 5][i & 31] = 0u;                           \
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);                               \
     if (b >= B) return;
 
+// ---- diagnostic build only (-DBLK_STAMPS): where a rollout step spends its cycles.  Stamp values leave the
+// kernel through g_blk_stamps alone; no output depends on them.  The shipped build compiles none of this.
+#ifdef BLK_STAMPS
+__device__ unsigned long long g_blk_stamps[8];
+#define BLK_STAMP(slot)                                                                      \
+    do {                                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
+        stamp_acc[slot] += now_ - stamp_prev;                                                \
+        stamp_prev = __builtin_amdgcn_s_memtime();                                           \
+    } while (0)
+#else
+#define BLK_STAMP(slot) do { } while (0)
+#endif
+
 // ---- kernels (one wave per game, 4 games per workgroup) ---------------------------------------------
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_step_kernel(const BlkTables *__restrict__ tables, const int64_t B, uint32_t *__restrict__ occ,
                    uint32_t *__restrict__ inv_g, int32_t *__restrict__ score_g, int32_t *__restrict__ round_g,
                    int32_t *__restrict__ to_move_g, const int32_t *__restrict__ action, int8_t *__restrict__ reward,
@@ -452,9 +525,9 @@ blokus_step_kernel(const BlkTables *__restrict__ tables, const int64_t B, uint32
     uint32_t inv[4];
     int score[4];
     blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
-    int round = round_g[b], pl = to_move_g[b] & 3;
+    int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
     blk_prep(L, lane, round);                                    // allowed / corner rows of the PRE-move board (:424)
-    const int id = action[b];
+    const int id = __builtin_amdgcn_readfirstlane(action[b]);
     if (id >= 0 && id < ACTION_IDS) {                            // '' (pass) otherwise (:418)
         const BlkMove mv = blk_decode(id);
         blk_apply(T, L, pl, mv, inv, score, lane);
@@ -484,7 +557,7 @@ blokus_step_kernel(const BlkTables *__restrict__ tables, const int64_t B, uint32
 }
 
 // valid_actions: count, and optionally the dense id bitmap (bit id set = action id is legal)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
                     const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
                     const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
@@ -494,8 +567,8 @@ blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const
     uint32_t inv[4];
     int score[4];
     blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
-    const int q = (player ? player[b] : to_move_g[b]) & 3;
-    blk_prep(L, lane, round_g[b]);
+    const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
     uint32_t iq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
@@ -530,7 +603,7 @@ blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
                       const uint64_t first_env_id, const int T_steps, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv_g,
                       int32_t *__restrict__ score_g, int32_t *__restrict__ round_g, int32_t *__restrict__ to_move_g,
@@ -540,16 +613,29 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     uint32_t inv[4];
     int score[4];
     blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
-    int round = round_g[b], pl = to_move_g[b] & 3;
-    uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, len_sum = 0, wins[4] = {0, 0, 0, 0};
+    int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
+    uint32_t tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tcount[b]);
+    uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tstep[b]), n_ep = 0, len_sum = 0, wins[4] = {0, 0, 0, 0};
     int ssum[4] = {0, 0, 0, 0};
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
+    // bit q: player q is known to be out of moves for the rest of this game.  Once a player has no legal move in
+    // a round >= 1 it can only pass, so its own cells and inventory stay fixed while `allowed` only shrinks:
+    // the condition is permanent (round 0 is excluded: its single-corner anchor rule is not).  Purely a cache of
+    // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
+    uint32_t dead = 0;
+#ifdef BLK_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t < T_steps; ++t) {
+        BLK_STAMP(0);
         blk_prep(L, lane, round);
+        BLK_STAMP(1);
         uint32_t ip = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
-        const uint32_t total = blk_count(T, L, pl, ip, lane);       // len(valid_actions) of the mover
+        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane);   // len(valid_actions) of the mover
+        if (total == 0 && round >= 1) dead |= 1u << pl;
+        BLK_STAMP(2);
         const philox_out rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
         const uint32_t sel = tc & 3u;
         uint32_t word = rnd.w[0];
@@ -561,23 +647,27 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         if (total > 0) {
             const uint32_t r = __umulhi(word, total);
             const BlkMove mv = blk_select(T, L, pl, ip, r, lane);
+            BLK_STAMP(3);
             // the mover keeps a move iff some OTHER piece of its inventory had one (new inventory, old board)
-            const int slot = __popc(ip & ((1u << mv.piece) - 1u));
-            any_move = total > L.pcnt[slot];
+            any_move = total > (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[mv.piece]);
             blk_apply(T, L, pl, mv, inv, score, lane);
+            BLK_STAMP(4);
         }
         for (int q = 0; q < 4 && !any_move; ++q) {
-            if (q == pl) continue;
+            if (q == pl || ((dead >> q) & 1u)) continue;
             uint32_t iq = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
             any_move = blk_exists(T, L, q, iq, lane);
+            if (!any_move && round >= 1) dead |= 1u << q;
         }
+        BLK_STAMP(5);
         const BlkOutcome out = blk_outcome(any_move, pl, score);
         round += (pl == 3) ? 1 : 0;
         pl = (pl + 1) & 3;
         ts += 1;
         if (out.terminal) {
+            dead = 0;
             n_ep += 1;
             len_sum += ts;
 #pragma unroll
@@ -586,6 +676,11 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
             round = 0; pl = 0; ts = 0;
         }
     }
+    BLK_STAMP(6);
+#ifdef BLK_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_blk_stamps[i], stamp_acc[i]);
+#endif
     blk_store_state(L, b, lane, occ, inv_g, score_g, inv, score);
     if (lane == 0) {
         round_g[b] = round; to_move_g[b] = pl;
@@ -656,6 +751,24 @@ int crl_blokus_create(crl_ctx **out)
     c->blokus = dev;
     *out = c;
     return CRL_OK;
+}
+
+int crl_blokus_stamps(uint64_t *out8, int reset)
+{
+    CRL_REQUIRE(out8 != nullptr, "crl_blokus_stamps: out8 is NULL");
+#ifdef BLK_STAMPS
+    CRL_HIP(hipDeviceSynchronize());
+    CRL_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blk_stamps), 8 * sizeof(uint64_t)));
+    if (reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CRL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stamps), zero, sizeof(zero)));
+    }
+    return 1;
+#else
+    (void)reset;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    return 0;
+#endif
 }
 
 int crl_blokus_placement(int piece, int orient, int shift, int8_t *cells_xy)

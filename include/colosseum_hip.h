@@ -168,6 +168,9 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 #define CRL_BLOKUS_ACTION_IDS 336000
 #define CRL_BLOKUS_MASK_WORDS 10500
 int crl_blokus_create(crl_ctx **out);
+/* DIAGNOSTIC: per-phase shader-cycle sums of crl_blokus_rollout (prep, count, rng, select, apply, exists, rest, -).
+ * Returns 1 and the sums only in a library built with -DBLK_STAMPS, else 0 and zeros (the shipped build). */
+int crl_blokus_stamps(uint64_t *out8, int reset);
 /* HOST helper: cells (dx,dy pairs, 2*n int8) of (piece, orientation, shift) relative to the anchor; returns n.
  * Restates computation.py:184-246 (rotate_default_piece / shift_offsets). */
 int crl_blokus_placement(int piece, int orient, int shift, int8_t *cells_xy);

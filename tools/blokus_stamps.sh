@@ -1,0 +1,24 @@
+#!/bin/bash
+# Diagnostic (GPU box): build blokus.hip with -DBLK_STAMPS, run a rollout, print per-phase cycle shares.
+set -e
+cd colosseumrl_amd/csrc
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DBLK_STAMPS -c blokus.hip -o blokus.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libcolosseum_hip.so capi.o tron.o ttt.o blokus.o
+cd ../..
+python - <<'PY'
+import ctypes as C, torch
+from colosseumrl_amd import _native
+from colosseumrl_amd.batched import BlokusBatch
+bb = BlokusBatch(16384)
+bb.rollout(32, 1)
+buf = (C.c_uint64 * 8)()
+_native.lib().crl_blokus_stamps(buf, 1)
+bb.rollout(256, 1)
+torch.cuda.synchronize()
+_native.lib().crl_blokus_stamps(buf, 1)
+names = ["loop/outcome", "prep", "count", "rng", "select", "apply", "exists", "-"]
+tot = sum(buf)
+for n, v in zip(names, buf):
+    print("%-14s %6.1f %%   %8.0f cycles/wave-step" % (n, 100.0 * v / tot, v / 16384 / 256))
+print("total cycles/wave-step %.0f" % (tot / 16384 / 256))
+PY
