@@ -196,22 +196,24 @@ __device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int r
     wave_sync();
 }
 
+// one oriented shape in two registers: 5 cell bytes (dx+4 | dy+4 << 4), cells j >= n repeat cell 0.
+// Fields are extracted where used (v_bfe): the kernels are latency-bound, registers are the scarcer resource.
 struct ShapeRegs {
-    int sh[5];      // dx + 4  (shift amounts)
-    int ro[5];      // dy + 4  (row offsets)
+    uint32_t c03, c4;
     int n;
+    __device__ __forceinline__ uint32_t cell(const int j) const { return j < 4 ? (c03 >> (8 * j)) & 0xffu : c4 & 0xffu; }
+    __device__ __forceinline__ int sh(const int j) const { return (int)(cell(j) & 15u); }       // dx + 4: shift amount
+    __device__ __forceinline__ int ro(const int j) const { return (int)(cell(j) >> 4); }        // dy + 4: row offset
+    // shift for the anchor test: real cells use sh, padding cells 31 (every row shifts to 0)
+    __device__ __forceinline__ int shc(const int j) const { return j < n ? sh(j) : 31; }
 };
 
 __device__ __forceinline__ ShapeRegs blk_load_shape(const BlkTables &T, const int piece, const int orient)
 {
     ShapeRegs s;
     const uint2 raw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + orient][0]);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const uint32_t b = (j < 4) ? (raw.x >> (8 * j)) & 0xffu : raw.y & 0xffu;
-        s.sh[j] = (int)(b & 15u);
-        s.ro[j] = (int)(b >> 4);
-    }
+    s.c03 = raw.x;
+    s.c4 = raw.y;
     s.n = T.ncell[piece];
     return s;
 }
@@ -227,12 +229,12 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const int 
         uint32_t F = 0xffffffffu, ct[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const uint2 ac = L.ac[q][y + s.ro[j]];
-            F &= ac.x >> s.sh[j];                       // bit x+4: cell j of the shape at origin (x, y) is allowed
-            ct[j] = ac.y >> s.sh[j];                    // bit x+4: cell j of the shape at origin (x, y) is an anchor
+            const uint2 ac = L.ac[q][y + s.ro(j)];
+            F &= ac.x >> s.sh(j);                       // bit x+4: cell j of the shape at origin (x, y) is allowed
+            ct[j] = ac.y >> s.shc(j);                   // bit x+4: cell j of the shape at origin (x, y) is an anchor
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) cnt += (j < s.n) ? __popc(F & ct[j]) : 0;
+        for (int j = 0; j < 5; ++j) cnt += __popc(F & ct[j]);
         if (ANY_ONLY && __ballot(active && cnt > 0)) break;
     }
     return active ? cnt : 0u;
@@ -323,7 +325,7 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         const ShapeRegs s = blk_load_shape(T, piece, o);
         uint32_t F = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro[j]].x >> s.sh[j];
+        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
         L.fit[o][y + 4] = F;                             // bit x+4
     }
     // level 2: the anchors in row-major order.  Row lanes scatter their set bits into a list ...
@@ -395,11 +397,11 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
     const ShapeRegs s = blk_load_shape(T, mv.piece, mv.orient);
     int ox = 0, oy = 0;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh[j] : ox; oy = (j == mv.shift) ? s.ro[j] : oy; }
+    for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh(j) : ox; oy = (j == mv.shift) ? s.ro(j) : oy; }
     if (lane < s.n) {
         int cx = 0, cy = 0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh[j] : cx; cy = (j == lane) ? s.ro[j] : cy; }
+        for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh(j) : cx; cy = (j == lane) ? s.ro(j) : cy; }
         const int x = mv.x + cx - ox, y = mv.y + cy - oy;
         if (x >= 0 && x < BN && y >= 0 && y < BN) {
             for (int c = 0; c < 4; ++c) {
@@ -492,11 +494,12 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
         reinterpret_cast<uint32_t *>(&T)[i] = reinterpret_cast<const uint32_t *>(tables)[i];      \
     __syncthreads();                                                                              \
     const int lane = threadIdx.x & 63;                                                            \
-    WaveLds &L = Lw[threadIdx.x >> 6];                                                            \
+    const int wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* wave-uniform: SGPR addressing */ \
+    WaveLds &L = Lw[wave_];                                                                       \
     /* rows -4..-1 and 20..27 of the padded row tables are zero for the whole launch (only 0..19 are rewritten) */ \
     for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);            \
     for (int i = lane; i < 8 * 32; i += 64) L.fit[i >> 5][i & 31] = 0u;                           \
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);                               \
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_;                                            \
     if (b >= B) return;
 
 // ---- diagnostic build only (-DBLK_STAMPS): where a rollout step spends its cycles.  Stamp values leave the
@@ -584,16 +587,17 @@ blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const
                 uint32_t F = 0xffffffffu, ct[5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    const uint2 ac = L.ac[q][y + s.ro[j]];
-                    F &= ac.x >> s.sh[j];
-                    ct[j] = ac.y >> s.sh[j];
+                    const uint2 ac = L.ac[q][y + s.ro(j)];
+                    F &= ac.x >> s.sh(j);
+                    ct[j] = ac.y >> s.sh(j);
                 }
-                for (int j = 0; j < s.n; ++j) {
-                    uint32_t hits = (F & ct[j]) >> 4;                // origin columns x with cell j on an anchor
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    uint32_t hits = j < s.n ? (F & ct[j]) >> 4 : 0u;    // origin columns x with cell j on an anchor
                     while (hits) {
                         const int x = __builtin_ctz(hits);
                         hits &= hits - 1;
-                        const int ax = x + s.sh[j] - 4, ay = y + s.ro[j] - 4;     // the anchor
+                        const int ax = x + s.sh(j) - 4, ay = y + s.ro(j) - 4;     // the anchor
                         const int id = ((piece * 400 + ay * BN + ax) * 8 + o) * 5 + j;
                         atomicOr(&m[id >> 5], 1u << (id & 31));
                     }
@@ -615,8 +619,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
     int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
     uint32_t tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tcount[b]);
-    uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tstep[b]), n_ep = 0, len_sum = 0, wins[4] = {0, 0, 0, 0};
-    int ssum[4] = {0, 0, 0, 0};
+    uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tstep[b]);
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
     // bit q: player q is known to be out of moves for the rest of this game.  Once a player has no legal move in
     // a round >= 1 it can only pass, so its own cells and inventory stay fixed while `allowed` only shrinks:
@@ -668,10 +671,15 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         ts += 1;
         if (out.terminal) {
             dead = 0;
-            n_ep += 1;
-            len_sum += ts;
+            if (lane == 0) {        // episode statistics go straight to memory (this wave owns game b): nothing to carry
+                st.n_episodes[b] += 1;
+                st.len_sum[b] += ts;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { wins[c] += (out.winners >> c) & 1; ssum[c] += score[c]; }
+                for (int c = 0; c < 4; ++c) {
+                    st.win_count[c * B + b] += (uint32_t)((out.winners >> c) & 1);
+                    st.score_sum[c * B + b] += score[c];
+                }
+            }
             blk_fresh(L, lane, inv, score);
             round = 0; pl = 0; ts = 0;
         }
@@ -685,9 +693,6 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     if (lane == 0) {
         round_g[b] = round; to_move_g[b] = pl;
         st.tcount[b] = tc; st.tstep[b] = ts;
-        st.n_episodes[b] += n_ep; st.len_sum[b] += len_sum;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { st.win_count[c * B + b] += wins[c]; st.score_sum[c * B + b] += ssum[c]; }
     }
 }
 
