@@ -145,6 +145,14 @@ class TronBatch:
                                              _stream()), "crl_tron_observe")
         return {"board": ob.view(self.B, self.N, self.N), "heads": oh, "directions": od, "deaths": ok}
 
+    # -- compute_ranking for all games: int8 [P, B], 0 = best
+    def ranking(self):
+        out = torch.empty((self.P, self.B), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_ranking(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.deaths), _ptr(out),
+                                             _stream()), "crl_tron_ranking")
+        return out
+
     def results(self):
         """Per-game episode results packed for the end-of-rollout gather: int32 [B, 3+2P]."""
         cols = [self.n_episodes, self.len_sum, self.last_winners.to(torch.int32)]
@@ -224,6 +232,10 @@ class TTTBatch:
             check(self._lib.crl_ttt_board(self._ctx.handle, self.B, _ptr(self.occ), _ptr(player),
                                           int(rel_mod if rel_mod else self.P), _ptr(out), _stream()), "crl_ttt_board")
         return out
+
+    def observe(self, player: torch.Tensor, rel_mod: Optional[int] = None):
+        """state_to_observation for all games: board with ids relative to player[b] (reference 2p:382-407)."""
+        return {"board": self.board(player, rel_mod)}
 
     def _stats(self):
         return TTTStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
@@ -310,6 +322,17 @@ class BlokusBatch:
             check(self._lib.crl_blokus_valid(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(count),
                                              _ptr(mask), _stream()), "crl_blokus_valid")
         return (count, mask) if want_mask else count
+
+    def observe(self, player: torch.Tensor):
+        """state_to_observation for all games; player int8 [B] is the observer of each game."""
+        _want(player, torch.int8, (self.B,), self.device, "player")
+        ob = torch.empty((self.B, 20, 20), dtype=torch.int8, device=self.device)
+        op = torch.empty((self.B, 4, 21), dtype=torch.uint8, device=self.device)
+        osc = torch.empty((self.B, 4), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_observe(self._ctx.handle, self.B, _ptr(self.occ), _ptr(self.inv), _ptr(self.score),
+                                               _ptr(player), _ptr(ob), _ptr(op), _ptr(osc), _stream()), "crl_blokus_observe")
+        return {"board": ob, "pieces": op, "score": osc, "player": player.view(self.B, 1)}
 
     def board(self):
         out = torch.empty((self.B, 20, 20), dtype=torch.int8, device=self.device)

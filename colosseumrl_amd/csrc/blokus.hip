@@ -724,6 +724,36 @@ blokus_board_kernel(const int64_t B, const uint32_t *__restrict__ occ, int8_t *_
     board[i] = (int8_t)v;
 }
 
+// state_to_observation (BlokusEnvironment.py:721-768) for every game: one thread per output board cell, plus
+// the (4, 21) inventory matrix and the rolled scores written by the first threads of each game's slice.
+__global__ void __launch_bounds__(256)
+blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const uint32_t *__restrict__ inv,
+                      const int32_t *__restrict__ score, const int8_t *__restrict__ player, int8_t *__restrict__ obs_board,
+                      uint8_t *__restrict__ obs_pieces, int32_t *__restrict__ obs_score)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * BN * BN) return;
+    const int64_t b = t / (BN * BN);
+    const int cell = (int)(t - b * BN * BN), i = cell / BN, j = cell - i * BN;
+    const int pl = player[b] & 3;
+    int y, x;                                               // source cell of np.rot90(m, k=-pl)[i][j]
+    switch (pl) {
+        case 0: y = i; x = j; break;
+        case 1: y = BN - 1 - j; x = i; break;
+        case 2: y = BN - 1 - i; x = BN - 1 - j; break;
+        default: y = j; x = BN - 1 - i; break;
+    }
+    int v = -1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v = ((occ[(b * 4 + c) * BN + y] >> x) & 1u) ? ((c - pl) & 3) : v;
+    obs_board[t] = (int8_t)v;
+    if (cell < 4 * NPIECE) {                                // pieces[r][piece] of player (r + observer) % 4
+        const int r = cell / NPIECE, piece = cell - r * NPIECE;
+        obs_pieces[b * 4 * NPIECE + cell] = (uint8_t)((inv[b * 4 + ((r + pl) & 3)] >> piece) & 1u);
+    }
+    if (cell < 4) obs_score[b * 4 + cell] = score[b * 4 + ((cell + pl) & 3)];   // np.roll(score, -observer)
+}
+
 } // namespace
 
 void crl_blokus_free(void *tables)
@@ -833,6 +863,19 @@ int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t 
     CRL_REQUIRE(occ && board, "crl_blokus_board: NULL pointer");
     const int64_t n = B * BN * BN;
     hipLaunchKernelGGL(blokus_board_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, occ, board);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                       const int8_t *player, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_observe");
+    CRL_REQUIRE(occ && inv && score && player, "crl_blokus_observe: NULL input pointer");
+    CRL_REQUIRE(obs_board && obs_pieces && obs_score, "crl_blokus_observe: NULL output pointer");
+    const int64_t n = B * BN * BN;
+    hipLaunchKernelGGL(blokus_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       B, occ, inv, score, player, obs_board, obs_pieces, obs_score);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -641,6 +641,56 @@ tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, 
     }
 }
 
+// compute_ranking (TronGridEnvironment.py:483-508): one wave per game.  Lanes count the cells of every player
+// in a strided sweep of the board, a wave reduction gives the trail lengths, then the mutual-kill tie rule
+// (including its read of deaths[-1] for alive players and the missing-Counter-key 0) and competition ranks.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_ranking_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, const int8_t *__restrict__ deaths,
+                    int8_t *__restrict__ rank)
+{
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / CRL_WAVE) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int cnt[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) cnt[p] = 0;
+    for (int c = lane; c < NN; c += CRL_WAVE) {
+        const int v = board[b * NN + c];
+#pragma unroll
+        for (int p = 0; p < P; ++p) cnt[p] += (v == p + 1);
+    }
+    int score[P], k[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int v = cnt[p];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, CRL_WAVE);
+        score[p] = v;
+        k[p] = deaths[p * B + b];
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                // :492-495, ascending like np.where
+        const int via = k[i] > 0 ? k[i] - 1 : P - 1;            // python index -1 = the last player
+        int kvia = 0, other = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            kvia = (q == via) ? k[q] : kvia;
+            other = (k[i] > 0 && q == k[i] - 1) ? score[q] : other;   // alive: scores[-1] is a missing key -> 0
+        }
+        if (kvia == i + 1 && other < score[i]) score[i] = other;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {                            // :497-506 competition ranking
+            int higher = 0;
+#pragma unroll
+            for (int q = 0; q < P; ++q) higher += score[q] > score[i];
+            rank[i * B + b] = (int8_t)higher;
+        }
+    }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 inline TronGeom geom_of(const crl_tron_cfg &cfg)
@@ -799,6 +849,19 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, player, obs_heads, obs_dirs, obs_deaths);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *deaths, int8_t *rank, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_ranking");
+    CRL_REQUIRE(board && deaths && rank, "crl_tron_ranking: NULL pointer");
+    const crl_tron_cfg &cfg = ctx->tron;
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_ranking_kernel<PP>), dim3(blocks_for(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                           cfg.N * cfg.N, B, board, deaths, rank);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

@@ -207,14 +207,12 @@ class BlokusEnvironment(BaseEnvironment):
 
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
         """Relative player ids (-1 empty), board rotated into the observer's viewpoint, inventories as a
-        (4, 21) uint8 matrix in relative player order, scores rolled (reference :721-768)."""
-        board, round_count, players = state
-        cells = np.asarray(board.board_contents).astype(np.int64)
-        rel = np.where(cells == 0, -1, (cells - 1 - player) % 4)
-        pieces = np.zeros((4, 21), dtype=np.uint8)
-        for p in players:
-            row = (COLOR_TO_PLAYER[p.player_color] - player) % 4
-            for name in p.current_pieces:
-                pieces[row, PIECE_NAME_TO_INDEX[name]] = 1
-        score = np.roll(np.array([p.player_score for p in players]), -player)
-        return {"board": np.rot90(rel, k=-player), "pieces": pieces, "score": score, "player": np.array([player])}
+        (4, 21) uint8 matrix in relative player order, scores rolled (reference :721-768); evaluated by
+        ``crl_blokus_observe``."""
+        import torch
+        bb = self._upload(state, player)
+        obs = bb.observe(torch.tensor([player], dtype=torch.int8, device=bb.device))
+        return {"board": obs["board"].cpu().numpy().astype(np.int64).reshape(20, 20),
+                "pieces": obs["pieces"].cpu().numpy().reshape(4, 21),
+                "score": obs["score"].cpu().numpy().astype(np.int64).reshape(4),
+                "player": np.array([player])}

@@ -9,7 +9,6 @@ upload the state into a B=1 ``TronBatch`` and run the HIP kernels; without an
 MI355X they raise.  For throughput use ``colosseumrl_amd.batched.TronBatch``
 directly -- this class exists so existing agents and servers drop in unchanged.
 """
-from collections import Counter
 from time import time
 from typing import Dict, List, Tuple
 
@@ -207,19 +206,9 @@ class TronGridEnvironment(BaseEnvironment):
         return x, y
 
     def compute_ranking(self, state: object, players: List[int], winners: List[int]) -> Dict[int, int]:
-        """Competition ranking by trail length with the mutual-kill tie rule (reference :483-508)."""
-        board, _, _, deaths = state
-        num_players = deaths.shape[0]
-        scores = Counter(np.asarray(board).ravel() - 1)
-        del scores[-1]
-        mutual = np.where(deaths[deaths - 1] - np.arange(num_players) - 1 == 0)[0]
-        for victim in mutual:
-            killer = deaths[victim] - 1
-            scores[victim] = min(scores[victim], scores[killer])
-        rankings, rank, previous = {}, 0, np.inf
-        for position, (player, score) in enumerate(scores.most_common()):
-            if score < previous:
-                rank = position
-            rankings[player] = rank
-            previous = score
-        return rankings
+        """Competition ranking by trail length with the mutual-kill tie rule (reference :483-508), on the GPU
+        (``crl_tron_ranking``).  Keys are numpy integers ordered by rank like the reference's ``most_common()`` walk."""
+        tb = self._upload(state)
+        ranks = tb.ranking().cpu().numpy().reshape(-1)
+        order = sorted(range(len(ranks)), key=lambda p: (int(ranks[p]), p))
+        return {np.int64(p): int(ranks[p]) for p in order}

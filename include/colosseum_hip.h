@@ -121,6 +121,11 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
                      const int8_t *dirs, const int8_t *deaths, const int8_t *player,
                      int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream);
 
+/* replaces TronGridEnvironment.compute_ranking (TronGridEnvironment.py:483-508) for B games:
+ * rank int8 [P][B], 0 = best; trail-length scores, the mutual-kill tie rule (with its deaths[-1] read for
+ * alive players) and competition ranking, exactly as the reference computes them */
+int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *deaths, int8_t *rank, void *stream);
+
 /* ------------------------------------------------------------------ TicTacToe (D0 x D1 x D2, K in a row, P players)
  * State (reference tictactoe_2p_env.py:165-169: (board int8, winner)):
  *   occ     uint32 [P][B]  bit c set = flat cell c (row-major) holds player p's mark
@@ -188,6 +193,11 @@ int crl_blokus_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, uint32_t *inv,
  * mask uint32 [B][CRL_BLOKUS_MASK_WORDS] (may be NULL; 42 KB per game, meant for small B). */
 int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                      const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *count, uint32_t *mask, void *stream);
+/* replaces BlokusEnvironment.state_to_observation (BlokusEnvironment.py:721-768) for observer player[b]:
+ * obs_board int8 [B][20][20] (-1 empty, else (owner - observer) % 4, rotated by np.rot90(k=-observer)),
+ * obs_pieces uint8 [B][4][21] (row r = player (r + observer) % 4), obs_score int32 [B][4] (rolled by -observer) */
+int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                       const int8_t *player, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, void *stream);
 /* Board.board_contents as int8 [B][20][20] (0 empty, else colour) */
 int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t *board, void *stream);
 typedef struct {

@@ -253,6 +253,38 @@ void orc_blokus_board(int64_t B, const uint32_t *occ, int8_t *board)
             }
 }
 
+/* BlokusEnvironment.state_to_observation (:721-768): board = -1 empty else (owner - observer) % 4, rotated with
+ * np.rot90(k=-observer); pieces[r][i] = inventory bit i of player (r + observer) % 4; score rolled by -observer */
+void orc_blokus_observe(int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score, const int8_t *player,
+                        int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score)
+{
+    for (int64_t b = 0; b < B; ++b) {
+        int pl = player[b] & 3, rel[BN][BN];
+        for (int y = 0; y < BN; ++y)
+            for (int x = 0; x < BN; ++x) {
+                int v = -1;
+                for (int c = 0; c < 4; ++c) if ((occ[(b * 4 + c) * BN + y] >> x) & 1u) v = ((c - pl) % 4 + 4) % 4;
+                rel[y][x] = v;
+            }
+        for (int i = 0; i < BN; ++i)
+            for (int j = 0; j < BN; ++j) {
+                int v;
+                switch (pl) {                                    /* np.rot90(m, k=-pl) */
+                case 0: v = rel[i][j]; break;
+                case 1: v = rel[BN - 1 - j][i]; break;           /* one clockwise quarter turn */
+                case 2: v = rel[BN - 1 - i][BN - 1 - j]; break;
+                default: v = rel[j][BN - 1 - i]; break;          /* three clockwise = one counter-clockwise */
+                }
+                obs_board[(b * BN + i) * BN + j] = (int8_t)v;
+            }
+        for (int r = 0; r < 4; ++r) {
+            int src = (r + pl) % 4;
+            for (int i = 0; i < NP; ++i) obs_pieces[(b * 4 + r) * NP + i] = (uint8_t)((inv[b * 4 + src] >> i) & 1u);
+            obs_score[b * 4 + r] = score[b * 4 + src];
+        }
+    }
+}
+
 static inline uint32_t mulhi32b(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
 /* random agent: the mover plays the r-th action of valid_actions(), r = mulhi32(w, n), '' if n == 0;

@@ -255,6 +255,35 @@ void orc_tron_observe(int N, int P, int64_t B, const int8_t *board, const int16_
     }
 }
 
+/* TronGridEnvironment.compute_ranking (:483-508).  score = cells carrying the player's id; for every i
+ * with deaths[deaths[i]-1] == i+1 (an alive i reads deaths[-1], i.e. the LAST player's entry) the score becomes
+ * min(score[i], score[deaths[i]-1]) -- and for an alive i that "killer" index is -1, a key the Counter no
+ * longer holds, so the min is taken with 0; ranks are competition ranks by descending score. */
+void orc_tron_ranking(int N, int P, int64_t B, const int8_t *board, const int8_t *deaths, int8_t *rank)
+{
+    int NN = N * N;
+    for (int64_t b = 0; b < B; ++b) {
+        int score[ORC_TRON_MAX_P] = {0};
+        for (int c = 0; c < NN; ++c) {
+            int v = board[b * NN + c];
+            if (v >= 1 && v <= P) score[v - 1]++;
+        }
+        for (int i = 0; i < P; ++i) {                             /* :492-495, ascending like np.where */
+            int di = deaths[i * B + b];
+            int via = di > 0 ? di - 1 : P - 1;                    /* python index -1 = last player */
+            if (deaths[via * B + b] == i + 1) {
+                int other = di > 0 ? score[di - 1] : 0;           /* scores[-1] is a missing Counter key -> 0 */
+                if (other < score[i]) score[i] = other;
+            }
+        }
+        for (int i = 0; i < P; ++i) {                             /* :497-506 */
+            int higher = 0;
+            for (int q = 0; q < P; ++q) higher += score[q] > score[i];
+            rank[i * B + b] = (int8_t)higher;
+        }
+    }
+}
+
 /* ======================= TicTacToe ========================================= */
 
 /* WINNING_SHAPES (2p:12-17; 4p:19-38) slid over the board in 'valid' mode: every window of K

@@ -159,7 +159,28 @@ def tron_observe_cases(R, N, P, E, seed):
                 obs_heads=f(oh, np.int16), obs_dirs=f(od, np.int8), obs_deaths=f(ok, np.int8))
 
 
+def tron_ranking_cases(R, N, P, E, rng):
+    """compute_ranking (TronGridEnvironment.py:483-508) on states reached by random play (many of them terminal)."""
+    env = R["tron"]("%d;%d" % (N, P))
+    boards, deaths, ranks = [], [], []
+    for e in range(E):
+        s, _ = env.new_state()
+        w = None
+        for t in range(int(rng.integers(1, 40))):
+            s, pl, r, term, w = env.next_state(s, list(range(P)), [TRON_ACT[i] for i in rng.integers(0, 3, size=P)])
+            if term and rng.random() < 0.7:
+                break
+        rk = env.compute_ranking(s, list(range(P)), [] if w is None else list(w))
+        boards.append(s[0].ravel().astype(np.int8))
+        deaths.append(s[3].astype(np.int8))
+        ranks.append([rk[p] for p in range(P)])
+    return dict(N=N, P=P, board=np.array(boards), deaths=np.array(deaths), rank=np.array(ranks, np.int8))
+
+
 def gen_tron(R):
+    rng = np.random.default_rng(21)
+    for (N, P, E) in [(20, 4, 160), (9, 6, 96), (12, 2, 48), (7, 8, 64)]:
+        np.savez_compressed(os.path.join(OUT, "tron_ranking_n%dp%d.npz" % (N, P)), **tron_ranking_cases(R, N, P, E, rng))
     rows = tron_reset_table(R)
     np.savez_compressed(os.path.join(OUT, "tron_reset.npz"),
                         cfg=np.array([r[:4] for r in rows], np.int32),

@@ -135,6 +135,16 @@ def tron_observe(st, player):
     return ob, oh, od, ok
 
 
+def tron_ranking(N, P, board, deaths):
+    """board int8 [B, N*N], deaths int8 [P, B] -> rank int8 [P, B] (0 = best)"""
+    board = _chk(np.ascontiguousarray(board, dtype=np.int8), np.int8)
+    deaths = _chk(np.ascontiguousarray(deaths, dtype=np.int8), np.int8)
+    B = board.shape[0]
+    rank = np.zeros((P, B), dtype=np.int8)
+    lib().orc_tron_ranking(C.c_int(N), C.c_int(P), C.c_int64(B), _p(board), _p(deaths), _p(rank))
+    return rank
+
+
 # ------------------------------------------------------------------ TicTacToe
 def ttt_lines(D0, D1, D2, K):
     buf = np.zeros(256, dtype=np.uint32)
@@ -260,6 +270,15 @@ class BlokusState:
         for c in range(4):
             bits = (board == c + 1).astype(np.uint32) << np.arange(20, dtype=np.uint32)[None, None, :]
             self.occ[:, c, :] = bits.sum(axis=2).astype(np.uint32)
+
+
+def blokus_observe(st, player):
+    pl = _chk(np.ascontiguousarray(player, dtype=np.int8), np.int8, (st.B,))
+    ob = np.zeros((st.B, 20, 20), dtype=np.int8)
+    op = np.zeros((st.B, 4, 21), dtype=np.uint8)
+    osc = np.zeros((st.B, 4), dtype=np.int32)
+    lib().orc_blokus_observe(C.c_int64(st.B), _p(st.occ), _p(st.inv), _p(st.score), _p(pl), _p(ob), _p(op), _p(osc))
+    return ob, op, osc
 
 
 class _BlokusStats(C.Structure):

@@ -132,3 +132,50 @@ def test_dropin_env_golden(golden):
     assert env.is_valid_action(env.new_state()[0], 0, "monomino1;(5, 5);north0") is False
     with pytest.raises(ValueError):
         env.next_state(state, [0], [A.id_to_string(int(g["action"][0]))])      # piece already played
+
+
+def test_observe_golden_and_oracle(golden):
+    import torch
+    g = golden("blokus_observe")
+    n = len(g["player"])
+    be = HipBlokus(n)
+    be.set_state(g["board"], g["inv"], g["score"], g["round"], np.zeros(n, np.int32))
+    obs = be.bb.observe(torch.from_numpy(g["player"].astype(np.int8)).cuda())
+    assert np.array_equal(obs["board"].cpu().numpy(), g["obs_board"])
+    assert np.array_equal(obs["pieces"].cpu().numpy(), g["obs_pieces"])
+    assert np.array_equal(obs["score"].cpu().numpy(), g["obs_score"])
+    # larger random check against the oracle after a rollout
+    from colosseumrl_amd.batched import BlokusBatch
+    bb = BlokusBatch(2048)
+    bb.rollout(30, 5)
+    pl = torch.randint(0, 4, (2048,), dtype=torch.int8, device="cuda")
+    o = bb.observe(pl)
+    st = O.BlokusState(2048)
+    st.occ[:] = bb.occ.cpu().numpy().view(np.uint32)
+    st.inv[:] = bb.inv.cpu().numpy().view(np.uint32)
+    st.score[:] = bb.score.cpu().numpy()
+    ob, op, osc = O.blokus_observe(st, pl.cpu().numpy())
+    assert np.array_equal(o["board"].cpu().numpy(), ob) and np.array_equal(o["pieces"].cpu().numpy(), op)
+    assert np.array_equal(o["score"].cpu().numpy(), osc)
+
+
+def test_dropin_observation_golden(golden):
+    from colosseumrl_amd.envs.blokus import actions as A
+    from colosseumrl_amd.envs.blokus.BlokusEnvironment import BlokusEnvironment
+    from colosseumrl_amd.envs.blokus.ai import AI
+    from colosseumrl_amd.envs.blokus.board import Board
+    g = golden("blokus_observe")
+    env = BlokusEnvironment()
+    for i in range(0, len(g["player"]), 5):
+        b = Board()
+        b.board_contents = np.asarray(g["board"][i], dtype=np.int64)
+        players = []
+        for c in range(4):
+            ai = AI(b, c + 1)
+            ai.player_score = int(g["score"][i][c])
+            ai.current_pieces = [n for k, n in enumerate(A.PIECE_NAMES) if (int(g["inv"][i][c]) >> k) & 1]
+            players.append(ai)
+        obs = env.state_to_observation((b, int(g["round"][i]), players), int(g["player"][i]))
+        assert np.array_equal(obs["board"], g["obs_board"][i]) and obs["board"].shape == (20, 20)
+        assert np.array_equal(obs["pieces"], g["obs_pieces"][i]) and obs["pieces"].dtype == np.uint8
+        assert np.array_equal(obs["score"], g["obs_score"][i]) and obs["player"].tolist() == [int(g["player"][i])]

@@ -30,18 +30,6 @@ def test_action_codec_roundtrip():
     assert sum(A.PIECE_VALUES) == 89 and len(A.PIECE_NAMES) == 21
 
 
-def test_observation_matches_reference(golden):
-    g = golden("blokus_observe")
-    env = BlokusEnvironment()
-    assert env.observation_names() == ["board", "pieces", "score", "player"]
-    for i in range(len(g["player"])):
-        st = _state(g["board"][i], g["inv"][i], g["score"][i], g["round"][i])
-        obs = env.state_to_observation(st, int(g["player"][i]))
-        assert np.array_equal(obs["board"], g["obs_board"][i]) and obs["board"].shape == (20, 20)
-        assert np.array_equal(obs["pieces"], g["obs_pieces"][i]) and obs["pieces"].dtype == np.uint8
-        assert np.array_equal(obs["score"], g["obs_score"][i]) and obs["player"].tolist() == [int(g["player"][i])]
-
-
 def test_perspective_conversion_matches_reference(golden):
     g = golden("blokus_observe")
     env = BlokusEnvironment()

@@ -76,3 +76,14 @@ def test_rollout_equals_stepwise():
     assert np.array_equal(a.round, b.round) and np.array_equal(a.to_move, b.to_move)
     assert a.n_episodes.sum() == n_ep and n_ep >= 5 and (a.tcount == T).all()
     assert a.len_sum.sum() + a.tstep.sum() == B * T
+
+
+def test_observe_golden(golden):
+    g = golden("blokus_observe")
+    n = len(g["player"])
+    st = O.BlokusState(n)
+    st.set_board(g["board"])
+    st.inv[:] = g["inv"]
+    st.score[:] = g["score"]
+    ob, op, osc = O.blokus_observe(st, g["player"].astype(np.int8))
+    assert np.array_equal(ob, g["obs_board"]) and np.array_equal(op, g["obs_pieces"]) and np.array_equal(osc, g["obs_score"])

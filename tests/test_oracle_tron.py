@@ -146,3 +146,11 @@ def test_random_agent_is_uniform():
             for p, a in enumerate(tron_random_actions(42, g, c, 4)):
                 counts[c, p, a] += 1
     assert (np.abs(counts / 1500.0 - 1 / 3) < 0.05).all()
+
+
+@pytest.mark.parametrize("name", ["n20p4", "n9p6", "n12p2", "n7p8"])
+def test_ranking_golden(golden, name):
+    """compute_ranking incl. the deaths[-1] / missing-Counter-key quirk for survivors (TronGridEnvironment.py:483-508)."""
+    g = golden("tron_ranking_" + name)
+    r = O.tron_ranking(int(g["N"]), int(g["P"]), g["board"], np.ascontiguousarray(g["deaths"].T))
+    assert np.array_equal(r.T, g["rank"])
