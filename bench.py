@@ -77,6 +77,7 @@ def cpu_baseline(game, kw, seconds=12.0):
     """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample."""
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("CRL_CPU_THREADS", "16"))))    # a 1-GPU box's CPU share is 16 cores
     if game == "tron":
         N, P = kw["board_size"], kw["num_players"]
         sh, sd = O.tron_start_positions(N, P)
@@ -106,10 +107,13 @@ def cpu_baseline(game, kw, seconds=12.0):
             return time.perf_counter() - t0
     else:
         raise ValueError(game)
-    T = 8
-    dt = run(T)                       # also warms the thread pool
+    T = 4
+    dt = run(T)                       # warms the thread pool
+    while dt < 0.5 and T < (1 << 18):  # calibrate on a run long enough to be meaningful
+        T *= 4
+        dt = run(T)
     rate = B * T / max(dt, 1e-9)
-    T = int(max(8, min(1 << 20, rate * seconds / B)))
+    T = int(max(4, min(1 << 20, rate * seconds / B)))
     dt = run(T)
     return {"value": B * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %.1f s" % (B, T, dt)}
