@@ -117,3 +117,26 @@ def test_observation_golden(golden, name, env_name):
     for b, pl, want in list(zip(g["board"], g["player"], g["obs_board"]))[:24]:
         obs = env.state_to_observation((b.reshape(shape), None), int(pl))
         assert np.array_equal(obs["board"].ravel(), want)
+
+
+def test_vector_env_adapters():
+    import torch
+    from colosseumrl_amd.vector import TicTacToeVectorEnv, TronVectorEnv
+    env = TronVectorEnv(12, 4, 256)
+    obs = env.reset()
+    assert obs[0]["board"].shape == (256, 12, 12) and int(obs[2]["board"].max()) == 4
+    done_total = 0
+    for t in range(30):
+        a = torch.randint(-1, 2, (4, 256), dtype=torch.int8, device="cuda")
+        obs, rew, done, info = env.step(a)
+        done_total += int(done.sum())
+        assert rew.shape == (4, 256) and ((info["winners"] == 0) | (done == 1)).all()
+    assert done_total > 0
+    tenv = TicTacToeVectorEnv((3, 3), 3, 2, 512)
+    obs, mover, valid = tenv.reset()
+    assert int(valid[0]) == 0x1ff and obs["board"].shape == (512, 9)
+    for t in range(12):
+        empties = valid.cpu().numpy().view(np.uint32)
+        act = np.array([int(np.log2(int(e) & -int(e))) if e else -1 for e in empties], dtype=np.int8)   # first empty cell
+        obs, mover, valid, rew, done, info = tenv.step(torch.from_numpy(act).cuda())
+    assert int(tenv.batch.n_episodes.sum()) == 0 and int(done.sum()) >= 0
