@@ -17,7 +17,7 @@
 //   * LDS-resident (boards up to 25x25): every wave copies its 64 boards into LDS once, plays all T
 //     steps there (probe = ds_read_u8, a finished game clears its own 400-byte board with
 //     ds_write_b128), and writes the boards back once.  HBM sees 2*N*N bytes per game per LAUNCH.
-//   * global-memory (larger boards): boards stay in HBM/L2; resets are wave-cooperative 16-byte stores.
+//   * global-memory (larger boards): boards stay in HBM/L2, same tagged-cell scheme, tags stripped in place at the end.
 #include "crl_common.hpp"
 
 namespace {
@@ -388,7 +388,10 @@ struct TronAcc {
     }
 };
 
-// T fused steps, boards in global memory (any board size)
+// T fused steps, boards in global memory (any board size; L2 / Infinity-Cache resident at the benchmark sizes).
+// Same loop as the LDS kernel below: cells written during the launch carry an episode tag, so a reset is tag+1
+// plus P head stamps (no N*N-byte clear), the next step's actions are drawn while the probes are in flight,
+// and one wave-cooperative pass at the end strips the tags from the wave's 64 boards (16-byte loads / stores).
 template <int P>
 __global__ void __launch_bounds__(256)
 tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, const uint32_t seed_lo,
@@ -402,7 +405,8 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
     const bool valid = b < B;
     const int64_t bb = valid ? b : 0;
     const int64_t env0 = b - lane;
-    TronRegs<P> s;
+    const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
+    TronRegs<P> s, fresh;
     int act[P], rew[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -411,33 +415,73 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
         s.k[p] = valid ? deaths[p * B + bb] : 1;
     }
     tron_split_heads<P>(g, s);
+    tron_regs_to_start<P>(cfg, g, fresh);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        asm volatile("" : "+v"(fresh.h[p]), "+v"(fresh.x[p]), "+v"(fresh.y[p]), "+v"(fresh.d[p]));
+    }
     TronAcc<P> acc;
     acc.load(st, valid, bb);
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
-    const PlainBoard bd{board + bb * NN};
+    constexpr int OB = (P <= 7) ? 3 : 4;
+    constexpr uint32_t kTags = 1u << (8 - OB);
+    TaggedBoard<OB> bd{reinterpret_cast<uint8_t *>(board + bb * NN), 0u};
+    rng.next(gid, acc.tc, seed_lo, seed_hi, act);
     for (int t = 0; t < T; ++t) {
-        rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+        TronProbe<P> pr;
+        tron_probe<P>(g, bd, s, act, pr);                       // P byte loads in flight ...
         acc.tc += 1;
+        rng.next(gid, acc.tc, seed_lo, seed_hi, act);           // ... while the NEXT step's actions are drawn
         int term, wm;
-        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        tron_resolve<P>(bd, valid, s, pr, rew, term, wm);
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
-        const bool fin = valid && term;
-        unsigned long long m = __ballot(fin);
-        if (m) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                tron_wave_reset_board<P>(cfg, board + (env0 + src) * NN, NN, lane);
+        if (valid && term) {
+            uint32_t tag = (bd.tagbits >> OB) + 1u;
+            if (tag == kTags) {                                 // tag space exhausted: one real clear of this board
+                tag = 0;
+                if ((NN & 15) == 0)
+                    for (int off = 0; off < NN; off += 16) *reinterpret_cast<uint4 *>(bd.p + off) = make_uint4(0, 0, 0, 0);
+                else
+                    for (int off = 0; off < NN; ++off) bd.p[off] = 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (fin) {
-                acc.finish_episode(wm);
-                tron_regs_to_start<P>(cfg, g, s);
+            bd.tagbits = tag << OB;
+#pragma unroll
+            for (int p = 0; p < P; ++p) bd.put(fresh.h[p], p + 1);
+            acc.finish_episode(wm);
+            s = fresh;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- strip the tags in place: cells of older episodes become 0, current ones keep their owner
+    constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);
+    constexpr uint32_t TM = 0x01010101u * (kTags - 1u);
+    uint8_t *gslab = reinterpret_cast<uint8_t *>(board + env0 * NN);
+    if ((NN & 15) == 0) {
+        const int bytes = n_env * NN;
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = off / NN;
+            const uint32_t trep = (uint32_t)__shfl((int)(bd.tagbits >> OB), e, CRL_WAVE) * 0x01010101u;
+            const uint4 raw = *reinterpret_cast<const uint4 *>(gslab + off);
+            uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t diff = ((w[q] >> OB) & TM) ^ trep;
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                w[q] = w[q] & OM & ~(stale * 0xffu);
+            }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int e = 0; e < n_env; ++e) {
+            const uint32_t tb = (uint32_t)__shfl((int)bd.tagbits, e, CRL_WAVE);
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const uint32_t raw = gslab[(int64_t)e * NN + c];
+                gslab[(int64_t)e * NN + c] = (uint8_t)((((raw ^ tb) >> OB) == 0) ? (raw & ((1u << OB) - 1u)) : 0u);
             }
         }
     }
