@@ -24,13 +24,18 @@ struct ttt_dirs {
     uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
 };
 
+// Fully unrolled over the 13 possible directions: strides and start masks are then plain SGPR operands loaded
+// once per kernel instead of one scalar load per direction per step (2-D boards use 4 of them, 3-D boards 13).
 __device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t m)
 {
     uint32_t hit = 0;
-    for (int d = 0; d < dd.n_dirs; ++d) {          // wave-uniform loop, scalar operands
-        uint32_t run = m;
-        for (int s = 1; s < dd.K; ++s) run &= m >> (s * dd.stride[d]);
-        hit |= run & dd.start[d];
+#pragma unroll
+    for (int d = 0; d < 13; ++d) {
+        if (d < dd.n_dirs) {                       // wave-uniform: a scalar branch skips the unused directions
+            uint32_t run = m;
+            for (int s = 1; s < dd.K; ++s) run &= m >> (s * dd.stride[d]);
+            hit |= run & dd.start[d];
+        }
     }
     return hit != 0;
 }
