@@ -342,50 +342,31 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         }
     }
     wave_sync();
-    // ... and every lane takes one anchor: how many (orientation, shift) pairs of the piece are legal there?
-    // Shift j puts cell j on the anchor, so the shape's origin is anchor - s_j: one bit of the fit table.
-    // (origin row in [-4, 23], column in [-4, 23]: always inside the padded table, no bounds checks.)
+    // ... and the wave walks them in order with one lane per (orientation, shift) pair: lane o*n + j asks whether
+    // the piece fits with its cell j on the anchor (origin = anchor - s_j: one bit of the fit table; origin row and
+    // column are always inside the padded table).  The ballot of those answers is the anchor's legal set in
+    // reference order, its popcount the anchor's action count; both stay in scalar registers.
+    const bool pair = lane < 8 * n;
+    const int po = pair ? lane / n : 0, pj = pair ? lane - po * n : 0;
+    const uint32_t cb = T.cells[piece * 8 + po][pj];
+    const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
+    const uint32_t *frow = &L.fit[po][8 - dy4];                  // frow[ay] = fit[po][ay - dy + 4]
+    const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
     BlkMove mv = {piece, 0, 0, 0, 0};
-    uint32_t carried = 0;
-    for (int base = 0; base < n_anchor; base += 64) {
-        const int a = base + lane;
-        const bool active = a < n_anchor;
-        const int packed = active ? (int)L.alist[a] : 0;
+    for (int a = 0; a < n_anchor; ++a) {
+        const int packed = __builtin_amdgcn_readfirstlane((int)L.alist[a]);
         const int ay = packed >> 8, ax = packed & 0xff;
-        uint32_t cnt = 0, vlo = 0, vhi = 0;              // valid (orientation, shift) pairs: bit o*5+j
-#pragma nounroll
-        for (int o = 0; o < 8; ++o) {                    // wave-uniform loops; shape data via scalar registers
-            const uint2 raw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + o][0]);
-            const uint32_t c03 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.x);
-            const uint32_t c4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)raw.y);
-            const uint32_t *frow = &L.fit[o][0];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (j < n) {
-                    const uint32_t cb = (j < 4) ? (c03 >> (8 * j)) & 0xffu : c4 & 0xffu;
-                    const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);          // dx + 4, dy + 4
-                    const uint32_t bit = (frow[ay + 8 - dy4] >> (ax + 8 - dx4)) & 1u;   // fit[o][ty + 4] bit tx + 4
-                    cnt += bit;
-                    const int idx = o * 5 + j;
-                    if (idx < 32) vlo |= bit << idx; else vhi |= bit << (idx - 32);
-                }
-            }
-        }
-        cnt = active ? cnt : 0u;
-        const uint32_t inc = wave_scan_incl(cnt, lane);
-        const unsigned long long h2 = __ballot(active && r < carried + inc);
-        if (h2) {
-            const int src = __builtin_ctzll(h2);
-            const uint32_t r2 = r - carried - (uint32_t)__shfl((int)(inc - cnt), src, 64);
-            const int bit = nth_set_bit64(((unsigned long long)vhi << 32) | vlo, (int)r2);   // level 3, in order
-            mv.x = __builtin_amdgcn_readfirstlane(__shfl(ax, src, 64));
-            mv.y = __builtin_amdgcn_readfirstlane(__shfl(ay, src, 64));
-            const int b = __builtin_amdgcn_readfirstlane(__shfl(bit, src, 64));
-            mv.orient = b / 5;
-            mv.shift = b - mv.orient * 5;
+        const unsigned long long legal = __ballot(pair && ((frow[ay] >> (ax + shbase)) & 1u));
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
+        if (r < cnt) {                                           // level 3: the r-th legal pair at this anchor
+            const int lane_sel = nth_set_bit64(legal, (int)r);
+            mv.x = ax;
+            mv.y = ay;
+            mv.orient = lane_sel / n;
+            mv.shift = lane_sel - mv.orient * n;
             return mv;
         }
-        carried += (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)inc, 63, 64));
+        r -= cnt;
     }
     return mv;   // unreachable when r < total
 }
