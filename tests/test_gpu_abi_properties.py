@@ -1,0 +1,89 @@
+"""Properties the C ABI promises (include/colosseum_hip.h): asynchronous, graph-capturable, stream-ordered,
+usable from several host threads / contexts at once."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_calls_are_graph_capturable():
+    """step and rollout launches record into a HIP graph and replay to the same result as eager calls."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    a, b = TronBatch(20, 4, 4096), TronBatch(20, 4, 4096)
+    act = torch.randint(-1, 2, (4, 4096), dtype=torch.int8, device="cuda")
+    for tb in (a, b):                       # warm-up outside capture (one-time kernel attribute opt-in happens here)
+        tb.rollout(4, 1)
+        tb.step(act)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a.rollout(16, 1)
+        a.step(act, auto_reset=True)
+    for _ in range(3):
+        g.replay()
+    for _ in range(3):                      # capture itself does not execute: 3 replays == 3 eager rounds
+        b.rollout(16, 1)
+        b.step(act, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.board, b.board) and torch.equal(a.heads, b.heads) and torch.equal(a.ret_sum, b.ret_sum)
+    assert torch.equal(a.tcount, b.tcount) and int(a.tcount[0]) == 4 + 3 * 16
+
+
+def test_side_stream_ordering():
+    """Launches go to torch's CURRENT stream: work issued on a side stream is ordered on that stream."""
+    import torch
+    from colosseumrl_amd.batched import TTTBatch
+    side = torch.cuda.Stream()
+    ref = TTTBatch((3, 5), 3, 3, 8192)
+    ref.rollout(64, 9)
+    tb = TTTBatch((3, 5), 3, 3, 8192)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            tb.rollout(16, 9)
+    side.synchronize()
+    assert torch.equal(tb.occ, ref.occ) and torch.equal(tb.win_count, ref.win_count)
+
+
+def test_contexts_are_independent_across_threads():
+    """Several env instances live in one process (reference MatchmakingServer.py:128-135): no shared mutable state."""
+    from colosseumrl_amd.batched import BlokusBatch, TronBatch
+    out = {}
+
+    def worker(i):
+        tb = TronBatch(12 + i, 3, 700 + i, first_env_id=1000 * i)
+        bb = BlokusBatch(40 + i, first_env_id=77 * i)
+        for _ in range(3):
+            tb.rollout(20, i)
+            bb.rollout(6, i)
+        out[i] = (tb.board.cpu().numpy().copy(), bb.occ.cpu().numpy().copy())
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(4):                      # same work done alone, sequentially
+        tb = TronBatch(12 + i, 3, 700 + i, first_env_id=1000 * i)
+        bb = BlokusBatch(40 + i, first_env_id=77 * i)
+        for _ in range(3):
+            tb.rollout(20, i)
+            bb.rollout(6, i)
+        assert np.array_equal(out[i][0], tb.board.cpu().numpy()) and np.array_equal(out[i][1], bb.occ.cpu().numpy())
+
+
+def test_error_reporting_never_throws_across_the_abi():
+    import ctypes as C
+    from colosseumrl_amd import _native
+    lib = _native.require_gpu()
+    ctx = C.c_void_p()
+    assert lib.crl_ttt_create(6, 6, 1, 3, 2, C.byref(ctx)) == -1                    # 36 cells > 32
+    assert b"32" in lib.crl_last_error()
+    assert lib.crl_tron_step(None, 4, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.crl_blokus_create(C.byref(ctx)) == 0
+    assert lib.crl_tron_step(ctx, 4, None, None, None, None, None, None, None, None, 0, None) == -1   # wrong context kind
+    assert b"tron" in lib.crl_last_error()
+    lib.crl_destroy(ctx)
