@@ -15,9 +15,11 @@
 //
 // Two rollout kernels (T fused steps, random agent, auto-reset):
 //   * LDS-resident (boards up to 25x25): every wave copies its 64 boards into LDS once, plays all T
-//     steps there (probe = ds_read_u8, a finished game clears its own 400-byte board with
-//     ds_write_b128), and writes the boards back once.  HBM sees 2*N*N bytes per game per LAUNCH.
-//   * global-memory (larger boards): boards stay in HBM/L2, same tagged-cell scheme, tags stripped in place at the end.
+//     steps there (probe = ds_read_u8; a finished game bumps its episode tag instead of clearing its
+//     board), and writes the boards back once.  HBM sees 2*N*N bytes per game per LAUNCH.
+//   * global-memory (larger boards): boards stay in HBM / Infinity Cache, same tagged-cell scheme, tags
+//     stripped in place at the end.
+// plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
 
 namespace {
