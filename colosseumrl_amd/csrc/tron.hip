@@ -226,24 +226,6 @@ __device__ __forceinline__ uint4 tron_fresh_chunk16(const crl_tron_cfg &cfg, con
     return make_uint4(v0, v1, v2, v3);
 }
 
-// all 64 lanes of the wave rewrite one board in global memory (wave-uniform pointer) to the start layout
-template <int P>
-__device__ __forceinline__ void tron_wave_reset_board(const crl_tron_cfg &cfg, int8_t *__restrict__ bd,
-                                                      const int NN, const int lane)
-{
-    if ((NN & 15) == 0) {
-        for (int off = lane * 16; off < NN; off += CRL_WAVE * 16)
-            *reinterpret_cast<uint4 *>(bd + off) = tron_fresh_chunk16<P>(cfg, off);
-    } else {
-        for (int c = lane; c < NN; c += CRL_WAVE) {
-            int8_t v = 0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) v = (cfg.start_heads[p] == c) ? (int8_t)(p + 1) : v;
-            bd[c] = v;
-        }
-    }
-}
-
 template <int P>
 __device__ __forceinline__ void tron_regs_to_start(const crl_tron_cfg &cfg, const TronGeom &g, TronRegs<P> &s)
 {
@@ -303,7 +285,6 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
                  const uint32_t flags)
 {
     const int NN = g.NN;
-    const int lane = threadIdx.x & (CRL_WAVE - 1);
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = b < B;
     const int64_t bb = valid ? b : 0;
@@ -326,16 +307,17 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
         terminal[b] = (uint8_t)term;
         winners[b] = (uint8_t)wm;
     }
-    const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
-    if (flags & CRL_STEP_AUTO_RESET) {
-        unsigned long long m = __ballot(do_reset);
-        const int64_t env0 = b - lane;   // wave-uniform
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            tron_wave_reset_board<P>(cfg, board + (env0 + src) * NN, NN, lane);
-        }
-        if (do_reset) tron_regs_to_start<P>(cfg, g, s);
+    if (valid && term && (flags & CRL_STEP_AUTO_RESET)) {
+        // new_state for the games that just ended: every such lane clears its OWN board (all ending games of the
+        // wave in parallel, 16 bytes per store) and stamps the heads afterwards (same lane, same addresses: ordered)
+        int8_t *own = board + b * NN;
+        if ((NN & 15) == 0)
+            for (int off = 0; off < NN; off += 16) *reinterpret_cast<uint4 *>(own + off) = make_uint4(0, 0, 0, 0);
+        else
+            for (int off = 0; off < NN; ++off) own[off] = 0;
+        tron_regs_to_start<P>(cfg, g, s);
+#pragma unroll
+        for (int p = 0; p < P; ++p) own[s.h[p]] = (int8_t)(p + 1);
     }
     if (valid) {
 #pragma unroll
