@@ -1,0 +1,53 @@
+"""Longer randomized differential runs (HIP fused rollouts vs the CPU oracle, bit for bit): rare paths such as tag
+wrap-around, > 64 anchors, dead-player caching, every terminal flavour.  ~30 s on a GPU box."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("N,P,B,T,use_lds", [(20, 4, 4096, 1500, True), (20, 4, 2048, 1000, False), (13, 7, 1024, 1200, True),
+                                             (30, 3, 1024, 800, True), (6, 2, 512, 3000, True)])
+def test_tron_long_rollout(N, P, B, T, use_lds):
+    from colosseumrl_amd.batched import TronBatch
+    seed, first = 0x5EED + N, 10 ** 6
+    tb = TronBatch(N, P, B, first_env_id=first)
+    tb.rollout(T, seed, use_lds=use_lds)
+    sh, sd = O.tron_start_positions(N, P)
+    ost = O.TronState(N, P, B)
+    O.tron_reset(ost, sh, sd)
+    O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=16)
+    for k in ("board", "heads", "dirs", "deaths", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum",
+              "last_winners", "last_len"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
+    assert int(ost.n_episodes.min()) > 32          # every game wrapped its 5-bit episode tag at least once
+
+
+def test_blokus_long_rollout():
+    from colosseumrl_amd.batched import BlokusBatch
+    B, T, seed, first = 768, 160, 20240, 5000
+    bb = BlokusBatch(B, first_env_id=first)
+    ost = O.BlokusState(B)
+    for chunk in (100, 60):
+        bb.rollout(chunk, seed)
+        O.blokus_rollout(ost, seed, first, chunk, n_threads=16)
+    for k in ("occ", "inv", "score", "round", "to_move", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(bb, k).cpu().numpy().view(want.dtype), want), k
+    assert int(ost.n_episodes.sum()) >= B * 2
+
+
+@pytest.mark.parametrize("dims,K,P", [((3, 3), 3, 2), ((5, 5), 4, 3), ((3, 3, 3), 3, 4), ((4, 8), 5, 8)])
+def test_ttt_long_rollout(dims, K, P):
+    from colosseumrl_amd.batched import TTTBatch
+    B, T, seed, first = 16384, 2000, 99, 123
+    tb = TTTBatch(dims, K, P, B, first_env_id=first)
+    tb.rollout(T, seed)
+    ost = O.TTTState(dims, K, P, B)
+    O.ttt_rollout(ost, seed, first, T, n_threads=16)
+    for k in ("occ", "winner", "to_move", "tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
