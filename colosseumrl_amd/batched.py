@@ -145,6 +145,23 @@ class TronBatch:
                                              _stream()), "crl_tron_observe")
         return {"board": ob.view(self.B, self.N, self.N), "heads": oh, "directions": od, "deaths": ok}
 
+    # -- state_to_observation of every game for every observer in one pass
+    def observe_all(self, out: Optional[dict] = None):
+        """{'board': int8 [P, B, N, N], 'heads': int16 [P, P, B], 'directions' / 'deaths': int8 [P, P, B]};
+        slice [p] is what player p observes.  Pass a previous result as `out` to reuse its buffers."""
+        P, B, N = self.P, self.B, self.N
+        if out is None:
+            out = {"board": torch.empty((P, B, N, N), dtype=torch.int8, device=self.device),
+                   "heads": torch.empty((P, P, B), dtype=torch.int16, device=self.device),
+                   "directions": torch.empty((P, P, B), dtype=torch.int8, device=self.device),
+                   "deaths": torch.empty((P, P, B), dtype=torch.int8, device=self.device)}
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_observe_all(self._ctx.handle, B, _ptr(self.board), _ptr(self.heads), _ptr(self.dirs),
+                                                 _ptr(self.deaths), _ptr(out["board"]), _ptr(out["heads"]),
+                                                 _ptr(out["directions"]), _ptr(out["deaths"]), _stream()),
+                  "crl_tron_observe_all")
+        return out
+
     # -- compute_ranking for all games: int8 [P, B], 0 = best
     def ranking(self):
         out = torch.empty((self.P, self.B), dtype=torch.int8, device=self.device)

@@ -719,6 +719,94 @@ tron_ranking_kernel(const int NN, const int64_t B, const int8_t *__restrict__ bo
     }
 }
 
+// state_to_observation for ALL P observers in one pass over the boards: read 16 cells once, write them P times
+// relabelled (observer p sees itself as 1: CyTronGrid.pyx:65-71).  For P <= 7 the relabelling of four cells is ONE
+// v_perm_b32: the 8-byte table lut_p[v] = (v == 0 ? 0 : (v - (p+1) + P) % P + 1) is the permute source and the four
+// board bytes (values 0..7) are its selector.  Pure streaming: N*N bytes in, P*N*N bytes out per game.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs)
+{
+    const int64_t total = B * (int64_t)NN;
+    const bool wide = (NN & 15) == 0;
+    const int64_t n_items = wide ? total / 16 : total;
+    uint32_t lut_lo[P], lut_hi[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        lut_lo[p] = 0; lut_hi[p] = 0;
+#pragma unroll
+        for (int v = 1; v < 8; ++v) {
+            int n = v - (p + 1);
+            n = n < 0 ? n + P : n;
+            const uint32_t r = (v <= P) ? (uint32_t)(n + 1) : (uint32_t)v;
+            if (v < 4) lut_lo[p] |= r << (8 * v); else lut_hi[p] |= r << (8 * (v - 4));
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (wide) {
+            const int64_t off = i * 16;
+            const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                uint4 o;
+                if (P <= 7) {
+                    o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
+                    o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
+                    o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
+                    o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+                } else {
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w}, r4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t r = 0;
+#pragma unroll
+                        for (int s8 = 0; s8 < 32; s8 += 8) {
+                            const int c = (int)((w[q] >> s8) & 0xffu);
+                            int n = c - (p + 1);
+                            n = n < 0 ? n + P : n;
+                            r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+                        }
+                        r4[q] = r;
+                    }
+                    o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+                }
+                *reinterpret_cast<uint4 *>(obs + (int64_t)p * total + off) = o;
+            }
+        } else {
+            const int c = board[i];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                int n = c - (p + 1);
+                n = n < 0 ? n + P : n;
+                obs[(int64_t)p * total + i] = (int8_t)(c > 0 ? n + 1 : c);
+            }
+        }
+    }
+}
+
+// per-player vectors of all P observations: out[p][i][b] = in[(i + p) % P][b]
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_observe_all_players_kernel(const int64_t B, const int16_t *__restrict__ heads, const int8_t *__restrict__ dirs,
+                                const int8_t *__restrict__ deaths, int16_t *__restrict__ oh, int8_t *__restrict__ od,
+                                int8_t *__restrict__ ok)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int h[P], d[P], k[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { h[p] = heads[p * B + b]; d[p] = dirs[p * B + b]; k[p] = deaths[p * B + b]; }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int src = (i + p) % P;                 // compile-time after unrolling
+            oh[((int64_t)p * P + i) * B + b] = (int16_t)h[src];
+            od[((int64_t)p * P + i) * B + b] = (int8_t)d[src];
+            ok[((int64_t)p * P + i) * B + b] = (int8_t)k[src];
+        }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 inline TronGeom geom_of(const crl_tron_cfg &cfg)
@@ -877,6 +965,28 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, player, obs_heads, obs_dirs, obs_deaths);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, const int8_t *dirs,
+                         const int8_t *deaths, int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
+                         void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_observe_all");
+    CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_observe_all: NULL input pointer");
+    CRL_REQUIRE(obs_board && obs_heads && obs_dirs && obs_deaths, "crl_tron_observe_all: NULL output pointer");
+    const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe_all: boards must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
+    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_observe_all_kernel<PP>), dim3(grid), dim3(256), 0, s, NN, B, board, obs_board);
+        hipLaunchKernelGGL((tron_observe_all_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
+                           heads, dirs, deaths, obs_heads, obs_dirs, obs_deaths);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

@@ -121,6 +121,13 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
                      const int8_t *dirs, const int8_t *deaths, const int8_t *player,
                      int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream);
 
+/* The same observation for ALL P observers in one pass (what a self-play learner consumes every step):
+ * obs_board int8 [P][B][N*N], obs_heads int16 [P][P][B], obs_dirs / obs_deaths int8 [P][P][B]; slice [p] equals
+ * crl_tron_observe with player[b] = p.  Streams N*N bytes in and P*N*N bytes out per game. */
+int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, const int8_t *dirs,
+                         const int8_t *deaths, int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
+                         void *stream);
+
 /* replaces TronGridEnvironment.compute_ranking (TronGridEnvironment.py:483-508) for B games:
  * rank int8 [P][B], 0 = best; trail-length scores, the mutual-kill tie rule (with its deaths[-1] read for
  * alive players) and competition ranking, exactly as the reference computes them */

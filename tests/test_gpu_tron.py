@@ -229,3 +229,24 @@ def test_largest_board_and_single_game():
         ost.board[:], ost.heads[:], ost.dirs[:], ost.deaths[:] = s2["board"], s2["heads"], s2["dirs"], s2["deaths"]
         O.tron_rollout(ost, 5, 0, 300, sh, sd)
         assert np.array_equal(hip.tb.board.cpu().numpy(), ost.board) and np.array_equal(hip.tb.heads.cpu().numpy(), ost.heads)
+
+
+@pytest.mark.parametrize("N,P,B", [(20, 4, 5000), (9, 6, 777), (13, 8, 300), (40, 4, 1024)])
+def test_observe_all_matches_per_player_observe(N, P, B):
+    """The fused all-observers pass (v_perm table for P <= 7, arithmetic for P = 8, byte path for odd boards)
+    equals P single-observer calls, which equal the oracle."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    tb = TronBatch(N, P, B)
+    tb.rollout(17, 3)
+    allobs = tb.observe_all()
+    ost = O.TronState(N, P, B)
+    ost.board[:], ost.heads[:] = tb.board.cpu().numpy(), tb.heads.cpu().numpy()
+    ost.dirs[:], ost.deaths[:] = tb.dirs.cpu().numpy(), tb.deaths.cpu().numpy()
+    for p in range(P):
+        one = tb.observe(torch.full((B,), p, dtype=torch.int8, device="cuda"))
+        ob, oh, od, ok = O.tron_observe(ost, np.full(B, p, np.int8))
+        assert np.array_equal(allobs["board"][p].reshape(B, -1).cpu().numpy(), ob)
+        assert torch.equal(allobs["board"][p], one["board"]) and torch.equal(allobs["heads"][p], one["heads"])
+        assert np.array_equal(allobs["heads"][p].cpu().numpy(), oh) and np.array_equal(allobs["directions"][p].cpu().numpy(), od)
+        assert np.array_equal(allobs["deaths"][p].cpu().numpy(), ok)

@@ -37,6 +37,9 @@ def main():
     print("tron 20x20 P4 B=65536 step(auto_reset), 64-step graph: %.3g env-steps/s" % rate(g.replay, 100, B * 64))
     pl = torch.zeros((B,), dtype=torch.int8, device="cuda")
     print("tron observe (state_to_observation)               : %.3g obs/s" % rate(lambda: tb.observe(pl), 500, B))
+    buf = tb.observe_all()
+    rr = rate(lambda: tb.observe_all(buf), 500, B)
+    print("tron observe_all (4 observers, fused)             : %.3g games/s = %.2f TB/s (N*N in + 4*N*N out)" % (rr, rr * 5 * 400 / 1e12))
     print("tron ranking (compute_ranking)                    : %.3g games/s" % rate(lambda: tb.ranking(), 500, B))
     tt = TTTBatch((3, 5), 3, 3, 262144)
     a = torch.randint(0, 15, (262144,), dtype=torch.int8, device="cuda")
