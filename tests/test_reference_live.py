@@ -1,0 +1,81 @@
+"""Live differential checks of the CPU oracle against the REFERENCE itself (imported from /root/reference through
+oracle/ref_loader.py).  Only runs where the reference tree exists (the build container); skipped on the GPU box.
+Complements the committed golden vectors with fresh random configurations every run (seeded per test)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import ref_loader
+
+pytestmark = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+
+TRON_ACT = ["forward", "right", "left"]
+
+
+@pytest.fixture(scope="module")
+def R():
+    return ref_loader.load()
+
+
+@pytest.mark.parametrize("N,P", [(8, 2), (11, 3), (20, 4), (16, 5), (23, 7), (12, 8), (40, 4)])
+def test_tron_oracle_vs_reference(R, N, P):
+    rng = np.random.default_rng(N * 100 + P)
+    env = R["tron"]("%d;%d" % (N, P))
+    sh, sd = O.tron_start_positions(N, P)
+    for game in range(25):
+        s, _ = env.new_state()
+        assert s[1].tolist() == sh.tolist() and s[2].tolist() == sd.tolist()
+        st = O.TronState(N, P, 1)
+        O.tron_reset(st, sh, sd)
+        for t in range(60):
+            a = rng.integers(0, 3, size=P)
+            s, pl, rew, term, win = env.next_state(s, list(range(P)), [TRON_ACT[i] for i in a])
+            r, tm, wm = O.tron_step(st, np.array([[0, 1, -1][i] for i in a], np.int8).reshape(P, 1))
+            assert np.array_equal(st.board.reshape(N, N), s[0]) and np.array_equal(st.heads[:, 0], s[1])
+            assert np.array_equal(st.dirs[:, 0], s[2]) and np.array_equal(st.deaths[:, 0], s[3])
+            assert np.array_equal(r[:, 0], rew) and bool(tm[0]) == bool(term)
+            assert wm[0] == (sum(1 << int(w) for w in win) if win is not None else 0)
+            if term and t > 5 + game:
+                break
+        obs = env.state_to_observation(s, game % P)
+        ob, oh, od, ok = O.tron_observe(st, np.array([game % P], np.int8))
+        assert np.array_equal(ob.reshape(N, N), obs["board"]) and np.array_equal(oh[:, 0], obs["heads"])
+        rk = env.compute_ranking(s, list(range(P)), [] if win is None else list(win))
+        assert [rk[p] for p in range(P)] == O.tron_ranking(N, P, st.board, st.deaths)[:, 0].tolist()
+
+
+@pytest.mark.parametrize("which,dims,P", [("ttt2", (3, 3), 2), ("ttt3", (3, 5), 3), ("ttt4", (3, 3, 3), 4)])
+def test_ttt_oracle_vs_reference(R, which, dims, P):
+    rng = np.random.default_rng(P)
+    env = R[which]()
+    n_cells = int(np.prod(dims))
+    for game in range(40):
+        s, pl = env.new_state()
+        st = O.TTTState(dims, 3, P, 1)
+        for t in range(n_cells + 4):
+            cell = int(rng.integers(-1, n_cells))
+            astr = "" if cell < 0 else str(tuple(int(i) for i in np.unravel_index(cell, dims)))
+            s, pl, rew, term, win = env.next_state(s, pl, [astr])
+            r, tm, ws = O.ttt_step(st, np.array([cell], np.int8))
+            assert np.array_equal(st.board()[0], s[0].ravel())
+            assert st.winner[0] == (-1 if s[1] is None else s[1]) and st.to_move[0] == pl[0]
+            assert r[0] == rew[0] and bool(tm[0]) == bool(term) and ws[0] == (-1 if win is None else win[0])
+
+
+def test_blokus_oracle_vs_reference_short(R):
+    """A dozen plies of two fresh random games (the reference needs ~0.3 s per call without numba)."""
+    env = R["blokus"]()
+    rng = np.random.default_rng(2024)
+    for game in range(2):
+        s, pl = env.new_state()
+        st = O.BlokusState(1)
+        for t in range(12):
+            va = env.valid_actions(s, pl[0])
+            ids_ref = [O.blokus_action_id(a) for a in va if a]
+            cnt, ids = O.blokus_valid(st, cap=4096)
+            assert ids[0, :cnt[0]].tolist() == ids_ref
+            a = ids_ref[int(rng.integers(0, len(ids_ref)))] if ids_ref else -1
+            s, pl, rew, term, win = env.next_state(s, pl, [O.blokus_action_string(a)])
+            r, tm, wm = O.blokus_step(st, np.array([a], np.int32))
+            assert np.array_equal(st.board[0], s[0].board_contents) and st.score[0].tolist() == [p.player_score for p in s[2]]
+            assert r[0] == rew[0] and bool(tm[0]) == bool(term) and st.to_move[0] == pl[0] and st.round[0] == s[1]
