@@ -162,14 +162,17 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int r)
     return r < c ? nth_set_bit32(lo, r) : 32 + nth_set_bit32(hi, r - c);
 }
 
-// inclusive prefix sum across the 64 lanes
+// inclusive prefix sum across the 64 lanes: Hillis-Steele inside each row of 16 lanes with DPP row shifts (the shifted
+// operand is folded into the add), then the row totals with the two row-broadcast steps.  8 VALU, no LDS crossbar.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)v, d, 64);
-        v += (lane >= d) ? u : 0u;
-    }
+    (void)lane;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
