@@ -263,7 +263,7 @@ __device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, c
     int pos = (int)(incl - nu);
     for (uint32_t k = 0; k < nu; ++k) L.items[pos++] = (uint8_t)((lane << 3) | (int)k);
     wave_sync();
-    return __builtin_amdgcn_readfirstlane(__shfl((int)incl, NPIECE - 1, 64));
+    return __builtin_amdgcn_readlane((int)incl, NPIECE - 1);
 }
 
 // does player q have any legal action with inventory inv? (board.py:170-193 non-empty)
@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     wave_sync();
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
     const uint32_t total = wave_scan_incl(mine, lane);
-    return (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)total, 63, 64));
+    return (uint32_t)__builtin_amdgcn_readlane((int)total, 63);
 }
 
 struct BlkMove { int piece, x, y, orient, shift; };
@@ -320,7 +320,7 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const uint32_t incl = wave_scan_incl(mine, lane);
     const unsigned long long hit = __ballot(r < incl);
     const int piece = __builtin_ctzll(hit);
-    r -= (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(incl - mine), piece, 64));
+    r -= (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), piece);
     const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
     // fit masks of the 8 orientations of that piece, all 20 origin rows (rows outside the board stay 0)
     for (int i = lane; i < 8 * BN; i += 64) {
@@ -334,7 +334,7 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     // level 2: the anchors in row-major order.  Row lanes scatter their set bits into a list ...
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
     const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
-    const int n_anchor = __builtin_amdgcn_readfirstlane(__shfl((int)rinc, BN - 1, 64));
+    const int n_anchor = __builtin_amdgcn_readlane((int)rinc, BN - 1);
     {
         uint32_t m = crow;
         int pos = (int)rinc - __popc(crow);
