@@ -120,9 +120,15 @@ __device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, 
         moved[i] = run & !pr.oob[i] & (v <= 0);         // :60-62
         s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
         s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
+        // :56-57 the owner's head is this very cell -> the owner dies too (a head is never its owner's own target,
+        // so q == i cannot hit).  One head select + one compare instead of P compares against every head.
+        int hv = -1;
 #pragma unroll
-        for (int q = 0; q < P; ++q)                     // :56-57 owner's head is this very cell -> owner dies too
-            s.k[q] = (crash & (q == v - 1) & (s.h[q] == pr.tgt[i])) ? i + 1 : s.k[q];
+        for (int q = 0; q < P; ++q) hv = (q != i && v == q + 1) ? s.h[q] : hv;
+        const bool hit = crash & (hv == pr.tgt[i]);
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q != i) s.k[q] = (hit & (v == q + 1)) ? i + 1 : s.k[q];
         s.h[i] = moved[i] ? pr.tgt[i] : s.h[i];
         s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
         s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
