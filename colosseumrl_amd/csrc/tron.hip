@@ -94,7 +94,23 @@ __device__ __forceinline__ void tron_probe(const TronGeom &g, const BOARD &bd, c
         pr.ny[i] = s.y[i] + __builtin_amdgcn_sbfe((int)0x000100ffu, sh8, 8);
         pr.ndir[i] = dir;
         pr.oob[i] = ((unsigned)pr.nx[i] >= (unsigned)N) | ((unsigned)pr.ny[i] >= (unsigned)N);
-        pr.tgt[i] = pr.oob[i] ? 0 : pr.ny[i] * N + pr.nx[i];
+        // in-board coordinates are < 2^15: the 24-bit multiply-add is a full-rate VALU op (a 32-bit one is not)
+        pr.tgt[i] = pr.oob[i] ? 0 : (int)(__umul24((unsigned)pr.ny[i], (unsigned)N) + (unsigned)pr.nx[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) pr.raw[i] = bd.raw(pr.tgt[i]);
+}
+
+// the same for a wall-bordered slab: target = head + one of four byte steps, no bounds test (the probe answers it)
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_probe_padded(const uint32_t delta4, const BOARD &bd, const TronRegs<P> &s,
+                                                  const int (&act)[P], TronProbe<P> &pr)
+{
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int dir = (s.d[i] + act[i]) & 3;
+        pr.ndir[i] = dir;
+        pr.tgt[i] = s.h[i] + __builtin_amdgcn_sbfe((int)delta4, dir << 3, 8);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) pr.raw[i] = bd.raw(pr.tgt[i]);
@@ -103,9 +119,14 @@ __device__ __forceinline__ void tron_probe(const TronGeom &g, const BOARD &bd, c
 // phases 2+3: the reference's sequential resolution on registers (CyTronGrid.pyx:15-62), trail writes, and the
 // reward / terminal / winners tail (TronGridEnvironment.py:309-321).  Straight-line code: every decision is a
 // select, so a wave never diverges inside a step.
-template <int P, typename BOARD>
+// PADDED (LDS rollout kernel): the board lives in a slab with a wall border (cells == kWallCell), heads are slab
+// addresses, "outside the board" is read off the probe itself, x / y are not tracked, and a player that does not
+// move writes to the board's junk byte `junk` instead of masking the store.
+constexpr int kWallCell = 0xff;
+
+template <int P, bool PADDED, typename BOARD>
 __device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, TronRegs<P> &s, const TronProbe<P> &pr,
-                                             int (&rew)[P], int &term, int &wmask)
+                                             int (&rew)[P], int &term, int &wmask, const int junk = 0)
 {
     bool moved[P];
 #pragma unroll
@@ -115,11 +136,21 @@ __device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, 
 #pragma unroll
         for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
             v = (moved[j] & (pr.tgt[j] == pr.tgt[i])) ? j + 1 : v;
-        const bool wall = run & pr.oob[i];              // :47-48
-        const bool crash = run & !pr.oob[i] & (v > 0);  // :51-57
-        moved[i] = run & !pr.oob[i] & (v <= 0);         // :60-62
+        bool crash;
+        if (PADDED) {
+            // a wall kills exactly like the player's own trail would (deaths[i] = i + 1, nobody else involved):
+            // treat a wall cell as owned by the mover and the :47-48 case folds into :51-57
+            v = (pr.raw[i] == kWallCell) ? i + 1 : v;
+            crash = run & (v > 0);
+            moved[i] = run & !(v > 0);                  // :60-62
+            s.k[i] = crash ? v : s.k[i];
+        } else {
+            const bool wall = run & pr.oob[i];          // :47-48
+            crash = run & !pr.oob[i] & (v > 0);         // :51-57
+            moved[i] = run & !pr.oob[i] & (v <= 0);     // :60-62
+            s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
+        }
         s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
-        s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
         // :56-57 the owner's head is this very cell -> the owner dies too (a head is never its owner's own target,
         // so q == i cannot hit).  One head select + one compare instead of P compares against every head.
         int hv = -1;
@@ -130,12 +161,16 @@ __device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, 
         for (int q = 0; q < P; ++q)
             if (q != i) s.k[q] = (hit & (v == q + 1)) ? i + 1 : s.k[q];
         s.h[i] = moved[i] ? pr.tgt[i] : s.h[i];
-        s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
-        s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
+        if (!PADDED) {
+            s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
+            s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
+        }
     }
 #pragma unroll
-    for (int i = 0; i < P; ++i)
-        if (valid & moved[i]) bd.put(pr.tgt[i], i + 1);
+    for (int i = 0; i < P; ++i) {
+        if (PADDED) bd.put(moved[i] ? pr.tgt[i] : junk, i + 1);     // lanes past B are all-dead: they never move
+        else if (valid & moved[i]) bd.put(pr.tgt[i], i + 1);
+    }
     int alive = 0;
     wmask = 0;
 #pragma unroll
@@ -156,7 +191,7 @@ __device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &b
 {
     TronProbe<P> pr;
     tron_probe<P>(g, bd, s, act, pr);
-    tron_resolve<P>(bd, valid, s, pr, rew, term, wmask);
+    tron_resolve<P, false>(bd, valid, s, pr, rew, term, wmask);
 }
 
 // uniform random actions for step c of global env g (contract: include/colosseum_hip.h, crl_tron_rollout).
@@ -203,7 +238,11 @@ struct TronRng {
             x *= 3u;
             act[i] = (int)(a3 + (a3 >> 1));             // 0, 1, 3 == forward, right, left (-1 mod 4)
         }
-        if (odd) {
+        advance(g, c, k0, k1);
+    }
+    __device__ __forceinline__ void advance(const uint32_t g, const uint32_t c, const uint32_t k0, const uint32_t k1)
+    {
+        if (c & 1u) {
             if ((c & 7u) == 7u) {
                 lo.refill(g, (c + 1u) >> 3, 0u, k0, k1);
                 if (P > 4) hi.refill(g, (c + 1u) >> 3, 1u, k0, k1);
@@ -213,7 +252,34 @@ struct TronRng {
             }
         }
     }
+    // the same draw through a table: the four base-3 digits a step takes from a word are the base-3 digits of
+    // t = umulhi(v, 81) (floor(81 v / 2^32) = 27 a0 + 9 a1 + 3 a2 + a3), and lut[t] holds the four action codes
+    // (0, 1, 3) as 2-bit fields -- one multiply, one LDS byte and one bit-field extract per player.
+    __device__ __forceinline__ void next_lut(const uint32_t g, const uint32_t c, const uint32_t k0, const uint32_t k1,
+                                             const uint8_t *lut, int (&act)[P])
+    {
+        const bool odd = c & 1u;
+        const uint32_t code_lo = lut[__umulhi(lo.w0 * (odd ? 81u : 1u), 81u)];
+        const uint32_t code_hi = (P > 4) ? lut[__umulhi(hi.w0 * (odd ? 81u : 1u), 81u)] : 0u;
+#pragma unroll
+        for (int i = 0; i < P; ++i) act[i] = (int)((((i < 4) ? code_lo : code_hi) >> (2 * (i & 3))) & 3u);
+        advance(g, c, k0, k1);
+    }
 };
+
+constexpr int kTronLutSize = 81;
+// fills the action table of next_lut (one entry per thread; the caller synchronises the workgroup afterwards)
+__device__ __forceinline__ void tron_fill_action_lut(uint8_t *lut)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)kTronLutSize) {
+        const uint32_t a[4] = {t / 27u, (t / 9u) % 3u, (t / 3u) % 3u, t % 3u};
+        uint32_t code = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) code |= (a[i] + (a[i] >> 1)) << (2 * i);
+        lut[t] = (uint8_t)code;
+    }
+}
 
 // 16 bytes of a freshly reset board starting at byte offset `off` (heads stamped)
 template <int P>
@@ -421,14 +487,17 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
     constexpr int OB = (P <= 7) ? 3 : 4;
     constexpr uint32_t kTags = 1u << (8 - OB);
     TaggedBoard<OB> bd{reinterpret_cast<uint8_t *>(board + bb * NN), 0u};
-    rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    __syncthreads();
+    rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
     for (int t = 0; t < T; ++t) {
         TronProbe<P> pr;
         tron_probe<P>(g, bd, s, act, pr);                       // P byte loads in flight ...
         acc.tc += 1;
-        rng.next(gid, acc.tc, seed_lo, seed_hi, act);           // ... while the NEXT step's actions are drawn
+        rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);   // ... while the NEXT step's actions are drawn
         int term, wm;
-        tron_resolve<P>(bd, valid, s, pr, rew, term, wm);
+        tron_resolve<P, false>(bd, valid, s, pr, rew, term, wm);
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
@@ -489,118 +558,203 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
     }
 }
 
-// T fused steps, boards resident in LDS.  256 threads = 4 independent waves; wave w owns the LDS slab
-// [w*64*stride, (w+1)*64*stride) holding its 64 boards.  stride = N*N rounded up to a multiple of 4 whose
-// dword count is ODD: lane l's board starts at dword l*stride/4, so the 32 lanes of a half-wave that probe the
-// same cell of their boards (every game right after a reset!) hit 32 different LDS banks instead of 8.
-// No workgroup barrier is needed: a lane only ever touches its own board, and the copy in / copy out
-// of a wave's slab is done by that wave.
+// T fused steps, boards resident in LDS.  256 threads = 4 independent waves; every lane owns one board slab.
+//
+// Slab layout (TronPad): (N+2) rows of kRowBytes = 24 bytes (boards up to 20x20).  Row 0 and row N+1 are wall, and
+// so are the bytes x >= N of every row -- which makes the byte before a row's first cell wall as well.  Cell (x, y)
+// sits at (y+1)*24 + x; heads are kept as LDS ADDRESSES (slab base + cell), so a probe is head + step[dir] and one
+// ds_read_u8, leaving the board is "the probe read a wall", and no x / y / bounds arithmetic exists in the loop.
+// After the rows comes one junk byte that players who do not move write to, which keeps the trail store
+// unconditional.  The slab is a whole, ODD number of dwords: the 32 lanes of a half-wave that probe the same cell
+// of their boards (every game right after a reset!) hit 32 different LDS banks instead of 8.
+//
+// Cells carry an episode tag (TaggedBoard).  Random agents finish an episode every ~10 steps, so a reset must be
+// cheap and must never clear a board in one go: it bumps the tag, stamps the heads and rewrites `sweep_rows` rows
+// (6 dword stores each, cells = 0, walls = 0xff) round-robin, so every row is rewritten at least once per
+// (usable tags - 2) episodes and a stale cell never survives until its tag value comes round again.
+// Returns are not accumulated per step: with A_p = number of steps after which player p was alive,
+// ret_p = 2 A_p - T + 9 wins_p (alive +1, dead -1, alive at a terminal step +10 = the win count).
+// No barrier inside the loop: a lane only ever touches its own slab.
+constexpr int kRowBytes = 24;
+constexpr int kRowDwords = kRowBytes / 4;
+constexpr int kTronLdsMaxN = 20;
+
+struct TronPad {
+    int junk;        // slab offset of the junk byte = (N + 2) * kRowBytes
+    int stride;      // bytes per slab
+    int sweep_rows;  // rows rewritten per reset = ceil(N / (usable tags - 2))
+};
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// board view over absolute LDS addresses (no base add in front of every access)
+template <int OB>
+struct LdsBoard {
+    uint32_t tagbits;               // tag << OB
+    __device__ __forceinline__ int raw(const int a) const { return *(const lds_u8 *)(uintptr_t)(uint32_t)a; }
+    __device__ __forceinline__ int owner(const int r) const
+    {
+        const uint32_t x = (uint32_t)r ^ tagbits;
+        return x < (1u << OB) ? (int)x : 0;
+    }
+    __device__ __forceinline__ void put(const int a, const int who) const { *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)(tagbits | (uint32_t)who); }
+};
+
 template <int P>
 __global__ void __launch_bounds__(256)
-tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stride, const int64_t B,
+tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
                         int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
                         int8_t *__restrict__ deaths, const crl_tron_stats st)
 {
-    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-    const int NN = g.NN;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    constexpr int RS = kRowBytes;
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    const int N = g.N, NN = g.NN;
     const int lane = threadIdx.x & (CRL_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = b < B;
     const int64_t bb = valid ? b : 0;
     const int64_t env0 = b - lane;                              // first game of this wave
     const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
-    int8_t *slab = lds + (size_t)wave * CRL_WAVE * stride;
-    int8_t *gslab = board + env0 * NN;
-    const bool wide = (NN & 15) == 0;                           // 16-byte pieces never straddle two boards
-    // ---- copy in: HBM -> LDS (coalesced 16-byte loads, 4 dword stores into the padded slab)
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;   // LDS address of the dynamic part
+    const int mine = lds0 + (int)threadIdx.x * pad.stride;      // this lane's slab
+    const bool wide = (N & 3) == 0;                             // rows are whole dwords in HBM too
+    constexpr int OB = (P <= 7) ? 3 : 4;                        // owner bits; 8 - OB tag bits
+    constexpr uint32_t kTags = (1u << (8 - OB)) - 1u;           // the all-ones tag is never used: 0xff stays "wall"
+    // a fresh row: cells 0, walls 0xff (kept in registers for the rolling rewrite)
+    uint32_t rowpat[kRowDwords];
+#pragma unroll
+    for (int j = 0; j < kRowDwords; ++j) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
+        rowpat[j] = w;
+        asm volatile("" : "+v"(rowpat[j]));
+    }
+    // ---- copy in: walls everywhere, then the cells.  Canonical HBM cells are tag 0.
+    for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
     if (wide) {
-        const int bytes = n_env * NN;
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-            const int e = off / NN, c = off - e * NN;
-            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(slab + e * stride + c);
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        // each lane streams its own board, 16 bytes per load; row / column bookkeeping is wave-uniform (scalar)
+        const uint4 *src = reinterpret_cast<const uint4 *>(board + bb * NN);
+        const int nq = N >> 2;
+        int y = 0, xq = 0;
+        for (int k = 0; k < NN / 16; ++k) {
+            const uint4 v = src[k];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *(lds_u32 *)(uintptr_t)(uint32_t)(mine + (y + 1) * RS + 4 * xq) = valid ? w[q] : 0u;
+                if (++xq == nq) { xq = 0; ++y; }
+            }
         }
     } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wall fill above vs other lanes' cell writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int8_t *gslab = board + env0 * NN;
+        const int slab0 = mine - lane * pad.stride;
         for (int e = 0; e < n_env; ++e)
-            for (int c = lane; c < NN; c += CRL_WAVE) slab[e * stride + c] = gslab[(int64_t)e * NN + c];
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
+            }
     }
+    // heads as LDS addresses
     TronRegs<P> s, fresh;                                       // fresh = the start layout, kept in VGPRs for resets
     int act[P], rew[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        s.h[p] = valid ? heads[p * B + bb] : 0;
+        const int h = valid ? heads[p * B + bb] : 0;
+        const int y = (int)__umulhi((uint32_t)h, g.inv_n);
+        s.h[p] = mine + (y + 1) * RS + (h - y * N);
         s.d[p] = valid ? dirs[p * B + bb] : 0;
         s.k[p] = valid ? deaths[p * B + bb] : 1;
+        const int fh = cfg.start_heads[p];
+        const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
+        fresh.h[p] = mine + (fy + 1) * RS + (fh - fy * N);
+        fresh.d[p] = cfg.start_dirs[p];
+        fresh.k[p] = 0;
+        asm volatile("" : "+v"(fresh.h[p]), "+v"(fresh.d[p]));
     }
-    tron_split_heads<P>(g, s);
-    tron_regs_to_start<P>(cfg, g, fresh);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        asm volatile("" : "+v"(fresh.h[p]), "+v"(fresh.x[p]), "+v"(fresh.y[p]), "+v"(fresh.d[p]));
-    }
+    const int junk = mine + pad.junk;
+    int sweep = mine + RS;                                      // next row of the rolling rewrite
+    const int sweep_end = mine + (N + 1) * RS;
     TronAcc<P> acc;
     acc.load(st, valid, bb);
+    uint32_t alive_steps[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) alive_steps[p] = 0;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
-    constexpr int OB = (P <= 7) ? 3 : 4;                        // owner bits; 8 - OB tag bits
-    constexpr uint32_t kTags = 1u << (8 - OB);
-    TaggedBoard<OB> bd{reinterpret_cast<uint8_t *>(slab + lane * stride), 0u};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // slab written by other lanes of this wave
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rng.next(gid, acc.tc, seed_lo, seed_hi, act);
+    LdsBoard<OB> bd{0u};
+    __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
+    rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
     for (int t = 0; t < T; ++t) {
         TronProbe<P> pr;
-        tron_probe<P>(g, bd, s, act, pr);                       // P ds_read_u8 in flight ...
+        tron_probe_padded<P>(step4, bd, s, act, pr);            // P ds_read_u8 in flight ...
         acc.tc += 1;
-        rng.next(gid, acc.tc, seed_lo, seed_hi, act);           // ... while the NEXT step's actions are drawn
+        rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);   // ... while the NEXT step's actions are drawn
         int term, wm;
-        tron_resolve<P>(bd, valid, s, pr, rew, term, wm);
+        tron_resolve<P, true>(bd, valid, s, pr, rew, term, wm, junk);
         acc.ts += 1;
 #pragma unroll
-        for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
+        for (int p = 0; p < P; ++p) alive_steps[p] += (s.k[p] == 0);
         if (valid && term) {
-            // new_state for this game only: bump the tag (every stale cell becomes empty) and stamp the heads
+            // new_state for this game only: bump the tag (every stale cell becomes empty), rewrite the next row(s)
+            // of the rolling clear, stamp the heads
             uint32_t tag = (bd.tagbits >> OB) + 1u;
-            if (tag == kTags) {                                 // tag space exhausted: one real clear
-                tag = 0;
-                for (int off = 0; off < stride; off += 4) *reinterpret_cast<uint32_t *>(bd.p + off) = 0u;
-            }
+            tag = (tag == kTags) ? 0u : tag;
             bd.tagbits = tag << OB;
+            for (int r = 0; r < pad.sweep_rows; ++r) {
+#pragma unroll
+                for (int j = 0; j < kRowDwords; ++j) *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * j) = rowpat[j];
+                sweep += RS;
+                sweep = (sweep == sweep_end) ? mine + RS : sweep;
+            }
 #pragma unroll
             for (int p = 0; p < P; ++p) bd.put(fresh.h[p], p + 1);
             acc.finish_episode(wm);
-            s = fresh;
+#pragma unroll
+            for (int p = 0; p < P; ++p) { s.h[p] = fresh.h[p]; s.d[p] = fresh.d[p]; s.k[p] = 0; }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc.ret[p] = 2 * (int)alive_steps[p] - T + 9 * (int)acc.wins[p];
     // ---- copy out: LDS -> HBM, dropping the tags (cells of older episodes become 0)
     constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);    // owner bits of 4 cells
-    constexpr uint32_t TM = 0x01010101u * (kTags - 1u);         // tag bits of 4 cells, shifted down
+    constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);   // tag bits of 4 cells, shifted down
     if (wide) {
-        const int bytes = n_env * NN;
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-            const int e = off / NN, c = off - e * NN;           // game this 16-byte piece belongs to
-            const uint32_t trep = (uint32_t)__shfl((int)(bd.tagbits >> OB), e, CRL_WAVE) * 0x01010101u;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(slab + e * stride + c);
-            uint32_t w[4] = {src[0], src[1], src[2], src[3]};
+        if (valid) {
+            uint4 *dst = reinterpret_cast<uint4 *>(board + b * NN);
+            const uint32_t trep = (bd.tagbits >> OB) * 0x01010101u;
+            const int nq = N >> 2;
+            int y = 0, xq = 0;
+            for (int k = 0; k < NN / 16; ++k) {
+                uint32_t w[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t diff = ((w[q] >> OB) & TM) ^ trep;               // per byte: 0 iff tag matches
-                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
-                w[q] = w[q] & OM & ~(stale * 0xffu);
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(mine + (y + 1) * RS + 4 * xq);
+                    const uint32_t diff = ((c4 >> OB) & TM) ^ trep;                  // per byte: 0 iff the tag matches
+                    const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
+                    w[q] = c4 & OM & ~(stale * 0xffu);
+                    if (++xq == nq) { xq = 0; ++y; }
+                }
+                dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
+        __syncthreads();
+        int8_t *gslab = board + env0 * NN;
+        const int slab0 = mine - lane * pad.stride;
         for (int e = 0; e < n_env; ++e) {
             const uint32_t tb = (uint32_t)__shfl((int)bd.tagbits, e, CRL_WAVE);
             for (int c = lane; c < NN; c += CRL_WAVE) {
-                const uint32_t raw = (uint8_t)slab[e * stride + c];
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                const uint32_t raw = *(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N));
                 gslab[(int64_t)e * NN + c] = (int8_t)((((raw ^ tb) >> OB) == 0) ? (raw & ((1u << OB) - 1u)) : 0u);
             }
         }
@@ -608,7 +762,9 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const int stri
     if (valid) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            heads[p * B + b] = (int16_t)s.h[p];
+            const int rel = s.h[p] - mine;
+            const int row = rel / RS;                                                // = y + 1
+            heads[p * B + b] = (int16_t)((row - 1) * N + (rel - row * RS));
             dirs[p * B + b] = (int8_t)s.d[p];
             deaths[p * B + b] = (int8_t)s.k[p];
         }
@@ -827,7 +983,21 @@ inline TronGeom geom_of(const crl_tron_cfg &cfg)
     return g;
 }
 
-constexpr int kLdsBudget = 160 * 1024;   // MI355X: 160 KiB LDS per CU, one 256-thread workgroup per CU
+// wall-bordered LDS slab of the rollout kernel (see tron_rollout_lds_kernel)
+inline TronPad pad_of(const crl_tron_cfg &cfg)
+{
+    TronPad p;
+    const int N = cfg.N;
+    p.junk = (N + 2) * kRowBytes;
+    p.stride = (p.junk + 1 + 3) & ~3;                 // a whole, ODD number of dwords
+    if (((p.stride >> 2) & 1) == 0) p.stride += 4;
+    const int usable = (cfg.P <= 7 ? 31 : 15) - 2;
+    p.sweep_rows = (N + usable - 1) / usable;
+    return p;
+}
+
+constexpr int kLdsDynamic = 160 * 1024 - 256;   // dynamic part; the kernel also holds a small static action table
+
 
 } // namespace
 
@@ -931,10 +1101,9 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     if (T == 0) return CRL_OK;
     hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
-    int stride = (NN + 3) & ~3;                       // bytes per board in LDS: a whole, ODD number of dwords
-    if (((stride >> 2) & 1) == 0) stride += 4;
-    const size_t lds_bytes = (size_t)256 * stride;
-    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && lds_bytes <= (size_t)kLdsBudget && (((uintptr_t)board & 15) == 0);
+    const TronPad pad = pad_of(cfg);
+    const size_t lds_bytes = (size_t)256 * pad.stride;
+    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kTronLdsMaxN && lds_bytes <= (size_t)kLdsDynamic && (((uintptr_t)board & 15) == 0);
     TRON_DISPATCH_P(cfg.P, {
         if (use_lds) {
             // opt in to > 64 KiB of dynamic LDS once per kernel instance and device (not per launch)
@@ -943,10 +1112,10 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
             CRL_HIP(hipGetDevice(&dev));
             if (dev < 0 || dev >= 64 || !opted_in[dev]) {
                 CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDynamic));
                 if (dev >= 0 && dev < 64) opted_in[dev] = 1;
             }
-            hipLaunchKernelGGL((tron_rollout_lds_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), lds_bytes, s, cfg, g, stride, B,
+            hipLaunchKernelGGL((tron_rollout_lds_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), lds_bytes, s, cfg, g, pad, B,
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         } else {
             hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
