@@ -116,61 +116,10 @@ __device__ __forceinline__ void tron_probe_padded(const uint32_t delta4, const B
     for (int i = 0; i < P; ++i) pr.raw[i] = bd.raw(pr.tgt[i]);
 }
 
-// phases 2+3: the reference's sequential resolution on registers (CyTronGrid.pyx:15-62), trail writes, and the
-// reward / terminal / winners tail (TronGridEnvironment.py:309-321).  Straight-line code: every decision is a
-// select, so a wave never diverges inside a step.
-// PADDED (LDS rollout kernel): the board lives in a slab with a wall border (cells == kWallCell), heads are slab
-// addresses, "outside the board" is read off the probe itself, x / y are not tracked, and a player that does not
-// move writes to the board's junk byte `junk` instead of masking the store.
-constexpr int kWallCell = 0xff;
-
-template <int P, bool PADDED, typename BOARD>
-__device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, TronRegs<P> &s, const TronProbe<P> &pr,
-                                             int (&rew)[P], int &term, int &wmask, const int junk = 0)
+// reward / terminal / winners tail of a step (TronGridEnvironment.py:309-321)
+template <int P>
+__device__ __forceinline__ void tron_outcome(const TronRegs<P> &s, int (&rew)[P], int &term, int &wmask)
 {
-    bool moved[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
-        int v = bd.owner(pr.raw[i]);
-#pragma unroll
-        for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
-            v = (moved[j] & (pr.tgt[j] == pr.tgt[i])) ? j + 1 : v;
-        bool crash;
-        if (PADDED) {
-            // a wall kills exactly like the player's own trail would (deaths[i] = i + 1, nobody else involved):
-            // treat a wall cell as owned by the mover and the :47-48 case folds into :51-57
-            v = (pr.raw[i] == kWallCell) ? i + 1 : v;
-            crash = run & (v > 0);
-            moved[i] = run & !(v > 0);                  // :60-62
-            s.k[i] = crash ? v : s.k[i];
-        } else {
-            const bool wall = run & pr.oob[i];          // :47-48
-            crash = run & !pr.oob[i] & (v > 0);         // :51-57
-            moved[i] = run & !pr.oob[i] & (v <= 0);     // :60-62
-            s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
-        }
-        s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
-        // :56-57 the owner's head is this very cell -> the owner dies too (a head is never its owner's own target,
-        // so q == i cannot hit).  One head select + one compare instead of P compares against every head.
-        int hv = -1;
-#pragma unroll
-        for (int q = 0; q < P; ++q) hv = (q != i && v == q + 1) ? s.h[q] : hv;
-        const bool hit = crash & (hv == pr.tgt[i]);
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-            if (q != i) s.k[q] = (hit & (v == q + 1)) ? i + 1 : s.k[q];
-        s.h[i] = moved[i] ? pr.tgt[i] : s.h[i];
-        if (!PADDED) {
-            s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
-            s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (PADDED) bd.put(moved[i] ? pr.tgt[i] : junk, i + 1);     // lanes past B are all-dead: they never move
-        else if (valid & moved[i]) bd.put(pr.tgt[i], i + 1);
-    }
     int alive = 0;
     wmask = 0;
 #pragma unroll
@@ -184,6 +133,85 @@ __device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, 
     for (int i = 0; i < P; ++i) rew[i] = (s.k[i] > 0) ? -1 : (term ? 10 : 1);
 }
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// phases 2+3: the reference's sequential resolution on registers (CyTronGrid.pyx:15-62), trail writes, and the
+// reward / terminal / winners tail (TronGridEnvironment.py:309-321).  Straight-line code: every decision is a
+// select, so a wave never diverges inside a step.
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_resolve(const BOARD &bd, const bool valid, TronRegs<P> &s, const TronProbe<P> &pr,
+                                             int (&rew)[P], int &term, int &wmask)
+{
+    bool moved[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
+        int v = bd.owner(pr.raw[i]);
+#pragma unroll
+        for (int j = 0; j < i; ++j)                     // a lower id that moved into the same cell this step
+            v = (moved[j] & (pr.tgt[j] == pr.tgt[i])) ? j + 1 : v;
+        const bool wall = run & pr.oob[i];              // :47-48
+        const bool crash = run & !pr.oob[i] & (v > 0);  // :51-57
+        moved[i] = run & !pr.oob[i] & (v <= 0);         // :60-62
+        s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
+        s.k[i] = wall ? i + 1 : (crash ? v : s.k[i]);
+        // :56-57 the owner's head is this very cell -> the owner dies too (a head is never its owner's own target,
+        // so q == i cannot hit).  One head select + one compare instead of P compares against every head.
+        int hv = -1;
+#pragma unroll
+        for (int q = 0; q < P; ++q) hv = (q != i && v == q + 1) ? s.h[q] : hv;
+        const bool hit = crash & (hv == pr.tgt[i]);
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q != i) s.k[q] = (hit & (v == q + 1)) ? i + 1 : s.k[q];
+        s.h[i] = moved[i] ? pr.tgt[i] : s.h[i];
+        s.x[i] = moved[i] ? pr.nx[i] : s.x[i];
+        s.y[i] = moved[i] ? pr.ny[i] : s.y[i];
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (valid & moved[i]) bd.put(pr.tgt[i], i + 1);
+    tron_outcome<P>(s, rew, term, wmask);
+}
+
+// The LDS rollout kernel's resolve.  Its board is a slab with a wall border (cells == kWallCell), heads are LDS
+// addresses, and it relies on the invariant every state produced by new_state / next_state has: the cell under a
+// player's head holds that player's id (nobody ever overwrites an occupied cell).  Hence
+//   * "the cell I move into is q's head" already says the cell is occupied, by q: one compare per (i, q) answers
+//     both the :56-57 head-on test and, for q < i, the "q moved there earlier in this very step" patch;
+//   * a wall kills exactly like the player's own trail would (deaths[i] = i + 1, nobody else involved), so a wall
+//     cell is treated as owned by the mover and :47-48 folds into :51-57;
+//   * a player that does not move stores to the slab's junk byte, which keeps the trail store unconditional;
+//     `stamp[i]` is the byte to store (tag | i + 1), refreshed by the caller when the tag changes.
+constexpr int kWallCell = 0xff;
+
+template <int P, typename BOARD>
+__device__ __forceinline__ void tron_resolve_lds(const BOARD &bd, TronRegs<P> &s, const TronProbe<P> &pr,
+                                                 const uint32_t (&stamp)[P], const int junk)
+{
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
+        bool on_head[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) on_head[q] = (q != i) && (pr.tgt[i] == s.h[q]);   // h[q] already moved for q < i
+        int v = bd.owner(pr.raw[i]);
+        v = (pr.raw[i] == kWallCell) ? i + 1 : v;
+#pragma unroll
+        for (int j = 0; j < i; ++j) v = on_head[j] ? j + 1 : v;
+        const bool crash = run & (v > 0);               // :47-48, :51-57
+        const bool moved = run & !(v > 0);              // :60-62
+        s.d[i] = run ? pr.ndir[i] : s.d[i];             // :44 direction is committed even if the move dies
+        s.k[i] = crash ? v : s.k[i];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q != i) s.k[q] = (run & on_head[q]) ? i + 1 : s.k[q];                 // :56-57
+        s.h[i] = moved ? pr.tgt[i] : s.h[i];
+        *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? pr.tgt[i] : junk) = (uint8_t)stamp[i];
+    }
+}
+
 template <int P, typename BOARD>
 __device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &bd, const bool valid,
                                                TronRegs<P> &s, const int (&act)[P],
@@ -191,7 +219,7 @@ __device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &b
 {
     TronProbe<P> pr;
     tron_probe<P>(g, bd, s, act, pr);
-    tron_resolve<P, false>(bd, valid, s, pr, rew, term, wmask);
+    tron_resolve<P>(bd, valid, s, pr, rew, term, wmask);
 }
 
 // uniform random actions for step c of global env g (contract: include/colosseum_hip.h, crl_tron_rollout).
@@ -497,7 +525,7 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
         acc.tc += 1;
         rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);   // ... while the NEXT step's actions are drawn
         int term, wm;
-        tron_resolve<P, false>(bd, valid, s, pr, rew, term, wm);
+        tron_resolve<P>(bd, valid, s, pr, rew, term, wm);
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) acc.ret[p] += rew[p];
@@ -584,9 +612,6 @@ struct TronPad {
     int stride;      // bytes per slab
     int sweep_rows;  // rows rewritten per reset = ceil(N / (usable tags - 2))
 };
-
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // board view over absolute LDS addresses (no base add in front of every access)
 template <int OB>
@@ -691,6 +716,9 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
     LdsBoard<OB> bd{0u};
+    uint32_t stamp[P];                                          // the byte a trail cell of player p gets: tag | p + 1
+#pragma unroll
+    for (int p = 0; p < P; ++p) stamp[p] = (uint32_t)(p + 1);
     __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
     rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
     for (int t = 0; t < T; ++t) {
@@ -698,8 +726,9 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
         tron_probe_padded<P>(step4, bd, s, act, pr);            // P ds_read_u8 in flight ...
         acc.tc += 1;
         rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);   // ... while the NEXT step's actions are drawn
+        tron_resolve_lds<P>(bd, s, pr, stamp, junk);
         int term, wm;
-        tron_resolve<P, true>(bd, valid, s, pr, rew, term, wm, junk);
+        tron_outcome<P>(s, rew, term, wm);
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) alive_steps[p] += (s.k[p] == 0);
@@ -709,6 +738,8 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
             uint32_t tag = (bd.tagbits >> OB) + 1u;
             tag = (tag == kTags) ? 0u : tag;
             bd.tagbits = tag << OB;
+#pragma unroll
+            for (int p = 0; p < P; ++p) stamp[p] = bd.tagbits | (uint32_t)(p + 1);
             for (int r = 0; r < pad.sweep_rows; ++r) {
 #pragma unroll
                 for (int j = 0; j < kRowDwords; ++j) *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * j) = rowpat[j];
@@ -716,7 +747,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
                 sweep = (sweep == sweep_end) ? mine + RS : sweep;
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) bd.put(fresh.h[p], p + 1);
+            for (int p = 0; p < P; ++p) *(lds_u8 *)(uintptr_t)(uint32_t)fresh.h[p] = (uint8_t)stamp[p];
             acc.finish_episode(wm);
 #pragma unroll
             for (int p = 0; p < P; ++p) { s.h[p] = fresh.h[p]; s.d[p] = fresh.d[p]; s.k[p] = 0; }
