@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="tron_p4_n20_b65536", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
-    ap.add_argument("--chunk", type=int, default=512, help="env-steps fused into one kernel launch")
+    ap.add_argument("--chunk", type=int, default=2048, help="env-steps fused into one kernel launch")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -611,6 +611,8 @@ struct TronPad {
     int junk;        // slab offset of the junk byte = (N + 2) * kRowBytes
     int stride;      // bytes per slab
     int sweep_rows;  // rows rewritten per reset = ceil(N / (usable tags - 2))
+    uint32_t inv_nn; // floor(2^32 / (N*N)) + 1: exact quotients for byte offsets inside a wave's 64 boards
+    uint32_t inv_nq; // floor(2^32 / (N/4)) + 1 (boards with N % 4 == 0 only)
 };
 
 // board view over absolute LDS addresses (no base add in front of every access)
@@ -663,21 +665,27 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     // ---- copy in: walls everywhere, then the cells.  Canonical HBM cells are tag 0.
     for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
     if (wide) {
-        // each lane streams its own board, 16 bytes per load; row / column bookkeeping is wave-uniform (scalar)
-        const uint4 *src = reinterpret_cast<const uint4 *>(board + bb * NN);
-        const int nq = N >> 2;
-        int y = 0, xq = 0;
-        for (int k = 0; k < NN / 16; ++k) {
-            const uint4 v = src[k];
+        // the wave streams its 64 boards as one contiguous run, 16 bytes per lane and load (coalesced), and scatters
+        // the dwords into the owners' slabs (a 16-byte piece never straddles two boards, its dwords may change row)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wall fill above vs other lanes' cell writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int8_t *gslab = board + env0 * NN;
+        const int slab0 = mine - lane * pad.stride;
+        const int bytes = n_env * NN;
+#pragma unroll 5
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            const int cq = (off - e * NN) >> 2;                 // first cell dword of the piece
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                *(lds_u32 *)(uintptr_t)(uint32_t)(mine + (y + 1) * RS + 4 * xq) = valid ? w[q] : 0u;
-                if (++xq == nq) { xq = 0; ++y; }
+                const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                *(lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
             }
         }
     } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wall fill above vs other lanes' cell writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int8_t *gslab = board + env0 * NN;
         const int slab0 = mine - lane * pad.stride;
@@ -758,31 +766,34 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     // ---- copy out: LDS -> HBM, dropping the tags (cells of older episodes become 0)
     constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);    // owner bits of 4 cells
     constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);   // tag bits of 4 cells, shifted down
+    *(lds_u8 *)(uintptr_t)(uint32_t)junk = (uint8_t)(bd.tagbits >> OB);   // the junk byte hands this board's tag to its copier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // slabs are read by other lanes of the wave below
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (wide) {
-        if (valid) {
-            uint4 *dst = reinterpret_cast<uint4 *>(board + b * NN);
-            const uint32_t trep = (bd.tagbits >> OB) * 0x01010101u;
-            const int nq = N >> 2;
-            int y = 0, xq = 0;
-            for (int k = 0; k < NN / 16; ++k) {
-                uint32_t w[4];
+        int8_t *gslab = board + env0 * NN;
+        const int slab0 = mine - lane * pad.stride;
+        const int bytes = n_env * NN;
+#pragma unroll 5
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            const int cq = (off - e * NN) >> 2;
+            const uint32_t trep = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + pad.junk) * 0x01010101u;
+            uint32_t w[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(mine + (y + 1) * RS + 4 * xq);
-                    const uint32_t diff = ((c4 >> OB) & TM) ^ trep;                  // per byte: 0 iff the tag matches
-                    const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
-                    w[q] = c4 & OM & ~(stale * 0xffu);
-                    if (++xq == nq) { xq = 0; ++y; }
-                }
-                dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int q = 0; q < 4; ++q) {
+                const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
+                const uint32_t diff = ((c4 >> OB) & TM) ^ trep;                  // per byte: 0 iff the tag matches
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
+                w[q] = c4 & OM & ~(stale * 0xffu);
             }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
-        __syncthreads();
         int8_t *gslab = board + env0 * NN;
         const int slab0 = mine - lane * pad.stride;
         for (int e = 0; e < n_env; ++e) {
-            const uint32_t tb = (uint32_t)__shfl((int)bd.tagbits, e, CRL_WAVE);
+            const uint32_t tb = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + pad.junk) << OB;
             for (int c = lane; c < NN; c += CRL_WAVE) {
                 const int y = (int)__umulhi((uint32_t)c, g.inv_n);
                 const uint32_t raw = *(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N));
@@ -1024,6 +1035,8 @@ inline TronPad pad_of(const crl_tron_cfg &cfg)
     if (((p.stride >> 2) & 1) == 0) p.stride += 4;
     const int usable = (cfg.P <= 7 ? 31 : 15) - 2;
     p.sweep_rows = (N + usable - 1) / usable;
+    p.inv_nn = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(N * N)) + 1u;
+    p.inv_nq = (N >= 4) ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(N / 4)) + 1u : 0u;
     return p;
 }
 
