@@ -299,8 +299,7 @@ constexpr int kTronLutSize = 81;
 // fills the action table of next_lut (one entry per thread; the caller synchronises the workgroup afterwards)
 __device__ __forceinline__ void tron_fill_action_lut(uint8_t *lut)
 {
-    const uint32_t t = threadIdx.x;
-    if (t < (uint32_t)kTronLutSize) {
+    for (uint32_t t = threadIdx.x; t < (uint32_t)kTronLutSize; t += blockDim.x) {
         const uint32_t a[4] = {t / 27u, (t / 9u) % 3u, (t / 3u) % 3u, t % 3u};
         uint32_t code = 0;
 #pragma unroll
@@ -588,9 +587,9 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
 
 // T fused steps, boards resident in LDS.  256 threads = 4 independent waves; every lane owns one board slab.
 //
-// Slab layout (TronPad): (N+2) rows of kRowBytes = 24 bytes (boards up to 20x20).  Row 0 and row N+1 are wall, and
+// Slab layout (TronPad): (N+2) rows of RS bytes (24 for boards up to 20x20, 44 up to 40x40).  Row 0 and row N+1 are wall, and
 // so are the bytes x >= N of every row -- which makes the byte before a row's first cell wall as well.  Cell (x, y)
-// sits at (y+1)*24 + x; heads are kept as LDS ADDRESSES (slab base + cell), so a probe is head + step[dir] and one
+// sits at (y+1)*RS + x; heads are kept as LDS ADDRESSES (slab base + cell), so a probe is head + step[dir] and one
 // ds_read_u8, leaving the board is "the probe read a wall", and no x / y / bounds arithmetic exists in the loop.
 // After the rows comes one junk byte that players who do not move write to, which keeps the trail store
 // unconditional.  The slab is a whole, ODD number of dwords: the 32 lanes of a half-wave that probe the same cell
@@ -603,12 +602,11 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
 // Returns are not accumulated per step: with A_p = number of steps after which player p was alive,
 // ret_p = 2 A_p - T + 9 wins_p (alive +1, dead -1, alive at a terminal step +10 = the win count).
 // No barrier inside the loop: a lane only ever touches its own slab.
-constexpr int kRowBytes = 24;
-constexpr int kRowDwords = kRowBytes / 4;
-constexpr int kTronLdsMaxN = 20;
+constexpr int kRowBytesSmall = 24, kLdsMaxNSmall = 20;   // 256 games per workgroup (4 waves, one per SIMD)
+constexpr int kRowBytesLarge = 44, kLdsMaxNLarge = 40;   // 64 games per workgroup (LDS holds one wave's boards)
 
 struct TronPad {
-    int junk;        // slab offset of the junk byte = (N + 2) * kRowBytes
+    int junk;        // slab offset of the junk byte = (N + 2) * RS
     int stride;      // bytes per slab
     int sweep_rows;  // rows rewritten per reset = ceil(N / (usable tags - 2))
     uint32_t inv_nn; // floor(2^32 / (N*N)) + 1: exact quotients for byte offsets inside a wave's 64 boards
@@ -628,7 +626,7 @@ struct LdsBoard {
     __device__ __forceinline__ void put(const int a, const int who) const { *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)(tagbits | (uint32_t)who); }
 };
 
-template <int P>
+template <int P, int RS>
 __global__ void __launch_bounds__(256)
 tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
@@ -638,7 +636,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint8_t act_lut[84];
     tron_fill_action_lut(act_lut);
-    constexpr int RS = kRowBytes;
+    constexpr int kRowDwords = RS / 4;
     constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
     const int N = g.N, NN = g.NN;
     const int lane = threadIdx.x & (CRL_WAVE - 1);
@@ -697,7 +695,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     }
     // heads as LDS addresses
     TronRegs<P> s, fresh;                                       // fresh = the start layout, kept in VGPRs for resets
-    int act[P], rew[P];
+    int act[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int h = valid ? heads[p * B + bb] : 0;
@@ -717,9 +715,11 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     const int sweep_end = mine + (N + 1) * RS;
     TronAcc<P> acc;
     acc.load(st, valid, bb);
+    const uint32_t ts_at_entry = acc.ts;
     uint32_t alive_steps[P];
+    int last_k[P];                                              // deaths at the latest terminal step
 #pragma unroll
-    for (int p = 0; p < P; ++p) alive_steps[p] = 0;
+    for (int p = 0; p < P; ++p) { alive_steps[p] = 0; last_k[p] = 1; }
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
@@ -735,8 +735,10 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
         acc.tc += 1;
         rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);   // ... while the NEXT step's actions are drawn
         tron_resolve_lds<P>(bd, s, pr, stamp, junk);
-        int term, wm;
-        tron_outcome<P>(s, rew, term, wm);
+        int alive = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) alive += (s.k[p] == 0);
+        const bool term = alive <= 1;                           // TronGridEnvironment.py:309-321
         acc.ts += 1;
 #pragma unroll
         for (int p = 0; p < P; ++p) alive_steps[p] += (s.k[p] == 0);
@@ -756,10 +758,22 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
             }
 #pragma unroll
             for (int p = 0; p < P; ++p) *(lds_u8 *)(uintptr_t)(uint32_t)fresh.h[p] = (uint8_t)stamp[p];
-            acc.finish_episode(wm);
+            acc.n_ep += 1;
+            acc.last_len = (int)acc.ts;
+            acc.ts = 0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) { s.h[p] = fresh.h[p]; s.d[p] = fresh.d[p]; s.k[p] = 0; }
+            for (int p = 0; p < P; ++p) {
+                acc.wins[p] += (s.k[p] == 0);                   // the winners are whoever is alive at the terminal step
+                last_k[p] = s.k[p];
+                s.h[p] = fresh.h[p]; s.d[p] = fresh.d[p]; s.k[p] = 0;
+            }
         }
+    }
+    acc.len_sum = ts_at_entry + (uint32_t)T - acc.ts;          // steps of this launch that belong to finished episodes
+    if (acc.n_ep > 0) {
+        acc.last_w = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc.last_w |= (last_k[p] == 0) << p;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) acc.ret[p] = 2 * (int)alive_steps[p] - T + 9 * (int)acc.wins[p];
@@ -1026,11 +1040,11 @@ inline TronGeom geom_of(const crl_tron_cfg &cfg)
 }
 
 // wall-bordered LDS slab of the rollout kernel (see tron_rollout_lds_kernel)
-inline TronPad pad_of(const crl_tron_cfg &cfg)
+inline TronPad pad_of(const crl_tron_cfg &cfg, const int RS)
 {
     TronPad p;
     const int N = cfg.N;
-    p.junk = (N + 2) * kRowBytes;
+    p.junk = (N + 2) * RS;
     p.stride = (p.junk + 1 + 3) & ~3;                 // a whole, ODD number of dwords
     if (((p.stride >> 2) & 1) == 0) p.stride += 4;
     const int usable = (cfg.P <= 7 ? 31 : 15) - 2;
@@ -1145,22 +1159,32 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     if (T == 0) return CRL_OK;
     hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
-    const TronPad pad = pad_of(cfg);
-    const size_t lds_bytes = (size_t)256 * pad.stride;
-    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kTronLdsMaxN && lds_bytes <= (size_t)kLdsDynamic && (((uintptr_t)board & 15) == 0);
+    // LDS-resident kernel: 256 games per workgroup on boards up to 20x20, 64 (one wave) up to 40x40
+    const bool small = cfg.N <= kLdsMaxNSmall;
+    const int RS = small ? kRowBytesSmall : kRowBytesLarge;
+    const int threads = small ? 256 : 64;
+    const TronPad pad = pad_of(cfg, RS);
+    const size_t lds_bytes = (size_t)threads * pad.stride;
+    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kLdsMaxNLarge && lds_bytes <= (size_t)kLdsDynamic &&
+                         (((uintptr_t)board & 15) == 0);
     TRON_DISPATCH_P(cfg.P, {
         if (use_lds) {
             // opt in to > 64 KiB of dynamic LDS once per kernel instance and device (not per launch)
-            static thread_local int opted_in[64] = {0};
+            static thread_local int opted_in[2][64] = {{0}};
             int dev = 0;
             CRL_HIP(hipGetDevice(&dev));
-            if (dev < 0 || dev >= 64 || !opted_in[dev]) {
-                CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDynamic));
-                if (dev >= 0 && dev < 64) opted_in[dev] = 1;
+            const void *fn = small ? reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesSmall>)
+                                   : reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesLarge>);
+            if (dev < 0 || dev >= 64 || !opted_in[small][dev]) {
+                CRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDynamic));
+                if (dev >= 0 && dev < 64) opted_in[small][dev] = 1;
             }
-            hipLaunchKernelGGL((tron_rollout_lds_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), lds_bytes, s, cfg, g, pad, B,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            if (small)
+                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesSmall>), dim3(blocks_for(B, threads)), dim3(threads), lds_bytes, s,
+                                   cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            else
+                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesLarge>), dim3(blocks_for(B, threads)), dim3(threads), lds_bytes, s,
+                                   cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         } else {
             hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);

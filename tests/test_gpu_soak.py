@@ -10,7 +10,8 @@ from oracle import oracle as O
 
 @pytest.mark.parametrize("N,P,B,T,use_lds", [(20, 4, 4096, 1500, True), (20, 4, 2048, 1000, False), (13, 7, 1024, 1200, True),
                                              (30, 3, 1024, 800, True), (6, 2, 512, 3000, True), (12, 8, 512, 1500, True),
-                                             (23, 4, 512, 1200, True), (16, 5, 700, 1200, True)])
+                                             (23, 4, 512, 1200, True), (16, 5, 700, 1200, True), (40, 4, 1000, 900, True),
+                                             (36, 8, 300, 700, True), (40, 4, 512, 600, False)])
 def test_tron_long_rollout(N, P, B, T, use_lds):
     from colosseumrl_amd.batched import TronBatch
     seed, first = 0x5EED + N, 10 ** 6
