@@ -15,6 +15,8 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
+CRL_ROLLOUT_BYTES = 4
+CRL_ROLLOUT_BITS = 8
 
 _lib = None
 _lock = threading.Lock()

@@ -125,11 +125,17 @@ class TronBatch:
                                                    self.len_sum, self.ret_sum, self.last_winners, self.last_len)])
 
     # -- T fused random-agent steps with auto-reset
-    def rollout(self, steps: int, seed: int = 0, use_lds: bool = True):
+    def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto"):
+        """``kernel``: "auto" (library's choice), "bits" / "bytes" (pin one of the LDS kernels) or "global";
+        ``use_lds=False`` is the older spelling of "global".  All kernels give identical results."""
+        flags = {"auto": 0, "bits": _native.CRL_ROLLOUT_BITS, "bytes": _native.CRL_ROLLOUT_BYTES,
+                 "global": _native.CRL_ROLLOUT_NO_LDS}[kernel]
+        if not use_lds:
+            flags = _native.CRL_ROLLOUT_NO_LDS
         with torch.cuda.device(self.device):
             check(self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
                                              _ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths),
-                                             self._stats(), 0 if use_lds else _native.CRL_ROLLOUT_NO_LDS, _stream()),
+                                             self._stats(), flags, _stream()),
                   "crl_tron_rollout")
 
     # -- state_to_observation for all games; player int8 [B]

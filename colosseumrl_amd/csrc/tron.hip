@@ -21,6 +21,8 @@
 //     stripped in place at the end.
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
+#include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -188,11 +190,11 @@ constexpr int kWallCell = 0xff;
 
 template <int P, typename BOARD>
 __device__ __forceinline__ void tron_resolve_lds(const BOARD &bd, TronRegs<P> &s, const TronProbe<P> &pr,
-                                                 const uint32_t (&stamp)[P], const int junk)
+                                                 const uint32_t (&stamp)[P], const int junk, const bool active = true)
 {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const bool run = s.k[i] == 0;                   // :16 (may have been killed head-on by j < i)
+        const bool run = active & (s.k[i] == 0);        // :16 (may have been killed head-on by j < i)
         bool on_head[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) on_head[q] = (q != i) && (pr.tgt[i] == s.h[q]);   // h[q] already moved for q < i
@@ -552,9 +554,11 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
     uint8_t *gslab = reinterpret_cast<uint8_t *>(board + env0 * NN);
     if ((NN & 15) == 0) {
         const int bytes = n_env * NN;
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-            const int e = off / NN;
+        for (int base = 0; base < bytes; base += CRL_WAVE * 16) {       // uniform trip count: the shuffle below reads
+            const int off = base + lane * 16;                            // lanes that have no piece of their own left
+            const int e = (off < bytes ? off : 0) / NN;
             const uint32_t trep = (uint32_t)__shfl((int)(bd.tagbits >> OB), e, CRL_WAVE) * 0x01010101u;
+            if (off >= bytes) continue;
             const uint4 raw = *reinterpret_cast<const uint4 *>(gslab + off);
             uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
@@ -825,6 +829,314 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
             deaths[p * B + b] = (int8_t)s.k[p];
         }
         acc.store(st, B, b);
+    }
+}
+
+// ---- bitboard rollout ---------------------------------------------------------------------------------------
+// For long launches the rollout does not need to know WHO owns a cell while it plays: the owner only decides the
+// value stored in deaths[], and deaths[] / the board bytes of all but the LAST episode of a launch are never
+// output (statistics only need "dead or alive").  So the T steps are played on an occupancy bitboard -- one row
+// word per board row, walls as set bits (x >= N, row 0, row N+1), heads as bit addresses, deaths as lane masks --
+// and a reset rewrites the whole board from a register-resident pattern (no tags, no rolling clear).  The state
+// the launch hands back is rebuilt afterwards by REPLAYING the unfinished episode with the byte-slab stepper of
+// tron_rollout_lds_kernel: actions are a pure function of (seed, env id, step counter), so a game that was reset
+// during the launch is replayed from the start layout for its `tstep` steps, and the rare game whose episode
+// spans the whole launch is replayed from the state it came in with.  Random agents live ~10 steps, so a replay
+// is a few dozen steps per wave against thousands of fused steps; crl_tron_rollout picks this kernel for T >= 256.
+// A 32-bit row holds boards up to 30x30, but the replay slabs limit it to the byte kernel's sizes (20 / 40).
+struct TronBits {
+    int stride;      // bytes per bit slab: rows 0 .. kMaxRows+1 plus one junk row; odd number of row words
+};
+
+template <int P, bool LARGE>
+__global__ void __launch_bounds__(256)
+tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const TronBits bits, const int64_t B,
+                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                         int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                         int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    typedef typename std::conditional<LARGE, uint64_t, uint32_t>::type row_t;
+    typedef __attribute__((address_space(3))) row_t lds_row;
+    constexpr int RB = (int)sizeof(row_t);                      // bytes per row word
+    constexpr int ROWBITS = 8 * RB;
+    constexpr int kMaxRows = LARGE ? kLdsMaxNLarge : 30;        // rows the reset rewrites (slabs are sized for it)
+    constexpr int RS = LARGE ? kRowBytesLarge : kRowBytesSmall; // byte slabs of the replay
+    constexpr uint32_t bstep4 = (uint32_t)((-ROWBITS) & 0xff) | (1u << 8) | ((uint32_t)ROWBITS << 16) | (0xffu << 24);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = b < B;
+    const int64_t bb = valid ? b : 0;
+    const int64_t env0 = b - lane;                              // first game of this wave
+    const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const int mine = lds0 + (int)threadIdx.x * bits.stride;     // this lane's bit slab
+    const bool wide = (N & 3) == 0;
+    const row_t wallpat = (row_t)(~(row_t)0) << N;              // bits x >= N of a board row
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+
+    // the start layout as row words (row r of the slab = board row r - 1), kept in registers for resets
+    row_t freshrow[kMaxRows];
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) {
+        row_t w = (r < N) ? wallpat : ~(row_t)0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int fh = cfg.start_heads[p];
+            const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
+            w |= (fy == r) ? (row_t)1 << (fh - fy * N) : (row_t)0;
+        }
+        freshrow[r] = w;
+    }
+    // ---- copy in: the lane lays out its slab (walls), the wave ORs the occupied cells of its 64 boards in
+    *(lds_row *)(uintptr_t)(uint32_t)mine = ~(row_t)0;
+    for (int r = 1; r <= kMaxRows + 2; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + r * RB) = (r <= N) ? wallpat : ~(row_t)0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const int8_t *gslab = board + env0 * NN;
+        const int slab0 = mine - lane * bits.stride;
+        if (wide) {
+            const int bytes = n_env * NN;
+            for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                const int cq = (off - e * NN) >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // one bit per non-zero byte of the dword (bit 7 of (b | (b & 0x7f) + 0x7f) <=> b != 0), gathered to a nibble
+                    const uint32_t nz = (((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u;
+                    const uint32_t nib = ((nz >> 7) * 0x10204080u) >> 28;
+                    const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                    const int x = 4 * (cq + q - y * (N >> 2));
+                    if (nib) atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), nib << (x & 31));
+                }
+            }
+        } else {
+            for (int e = 0; e < n_env; ++e)
+                for (int c = lane; c < NN; c += CRL_WAVE) {
+                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                    const int x = c - y * N;
+                    if (gslab[(int64_t)e * NN + c] != 0)
+                        atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), 1u << (x & 31));
+                }
+        }
+    }
+    // heads as BIT addresses: 8 * (slab address of the row word) + x; a step is +-1 or +-ROWBITS
+    int pos[P], dir_[P], fresh_pos[P], fresh_dir[P];
+    bool dead[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int h = valid ? heads[p * B + bb] : 0;
+        const int y = (int)__umulhi((uint32_t)h, g.inv_n);
+        pos[p] = 8 * mine + (y + 1) * ROWBITS + (h - y * N);
+        dir_[p] = valid ? dirs[p * B + bb] : 0;
+        dead[p] = valid ? (deaths[p * B + bb] != 0) : true;
+        const int fh = cfg.start_heads[p];
+        const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
+        fresh_pos[p] = 8 * mine + (fy + 1) * ROWBITS + (fh - fy * N);
+        fresh_dir[p] = cfg.start_dirs[p];
+        asm volatile("" : "+v"(fresh_pos[p]), "+v"(fresh_dir[p]));
+    }
+    const int junk_row = mine + (kMaxRows + 2) * RB;
+    TronAcc<P> acc;
+    acc.load(st, valid, bb);
+    const uint32_t ts_at_entry = acc.ts;
+    uint32_t alive_steps[P];
+    bool last_dead[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { alive_steps[p] = 0; last_dead[p] = true; }
+    TronRng<P> rng;
+    rng.start(gid, acc.tc, seed_lo, seed_hi);
+    int act[P];
+    __syncthreads();                                            // action table
+    rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
+    for (int t = 0; t < T; ++t) {
+        int np[P], nd[P], ra[P];
+        row_t roww[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {                           // CyTronGrid.pyx:21-41, all P probes in flight
+            nd[i] = (dir_[i] + act[i]) & 3;
+            np[i] = pos[i] + __builtin_amdgcn_sbfe((int)bstep4, nd[i] << 3, 8);
+            ra[i] = (np[i] >> 3) & ~(RB - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) roww[i] = *(const lds_row *)(uintptr_t)(uint32_t)ra[i];
+        acc.tc += 1;
+        rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {                           // CyTronGrid.pyx:15-62 with deaths as booleans
+            const bool run = !dead[i];
+            bool on_head[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) on_head[q] = (q != i) && (np[i] == pos[q]);
+            bool occ = ((roww[i] >> (np[i] & (ROWBITS - 1))) & 1) != 0;    // trail or wall
+#pragma unroll
+            for (int j = 0; j < i; ++j) occ |= on_head[j];      // j moved there earlier in this very step
+            const bool moved = run & !occ;
+            dead[i] |= run & occ;
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                if (q != i) dead[q] |= run & on_head[q];        // :56-57 head-on: the owner dies too
+            dir_[i] = run ? nd[i] : dir_[i];
+            pos[i] = moved ? np[i] : pos[i];
+            const row_t bit = (row_t)1 << (np[i] & (ROWBITS - 1));
+            if (LARGE) atomicOr((unsigned long long *)(lds + ((moved ? ra[i] : junk_row) - lds0)), (unsigned long long)bit);
+            else atomicOr((unsigned int *)(lds + ((moved ? ra[i] : junk_row) - lds0)), (unsigned int)bit);
+        }
+        int alive = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) alive += !dead[p];
+        const bool term = alive <= 1;                           // TronGridEnvironment.py:309-321
+        acc.ts += 1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) alive_steps[p] += !dead[p];
+        if (valid && term) {                                    // new_state: the whole board from the register pattern
+#pragma unroll
+            for (int r = 0; r < kMaxRows; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + (r + 1) * RB) = freshrow[r];
+            acc.n_ep += 1;
+            acc.last_len = (int)acc.ts;
+            acc.ts = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                acc.wins[p] += !dead[p];
+                last_dead[p] = dead[p];
+                pos[p] = fresh_pos[p]; dir_[p] = fresh_dir[p]; dead[p] = false;
+            }
+        }
+    }
+    acc.len_sum = ts_at_entry + (uint32_t)T - acc.ts;
+    if (acc.n_ep > 0) {
+        acc.last_w = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc.last_w |= (int)(!last_dead[p]) << p;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc.ret[p] = 2 * (int)alive_steps[p] - T + 9 * (int)acc.wins[p];
+    if (valid) acc.store(st, B, b);
+
+    // ---- replay of the unfinished episode on byte slabs: rebuilds board / heads / dirs / deaths
+    const bool from_start = acc.n_ep > 0;                       // else: from the state the launch came in with
+    const int steps_r = valid ? (from_start ? (int)acc.ts : T) : 0;
+    uint32_t c_r = acc.tc - (uint32_t)steps_r;
+    __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
+    constexpr int kTurns = LARGE ? 4 : 1;                       // LARGE: the LDS holds the byte slabs of one wave at a time
+    for (int turn = 0; turn < kTurns; ++turn) {
+        if (!LARGE || wave == turn) {
+            constexpr int kRowDwords = RS / 4;
+            constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+            const int slot = LARGE ? lane : (int)threadIdx.x;
+            const int bmine = lds0 + slot * pad.stride;
+            const int slab0 = bmine - lane * pad.stride;
+            for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + off) = 0xffffffffu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (__builtin_amdgcn_ballot_w64(valid && !from_start)) {        // somebody resumes from the incoming board
+                const int8_t *gslab = board + env0 * NN;
+                if (wide) {
+                    const int bytes = n_env * NN;
+                    for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                        const int cq = (off - e * NN) >> 2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                            *(lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
+                        }
+                    }
+                } else {
+                    for (int e = 0; e < n_env; ++e)
+                        for (int c = lane; c < NN; c += CRL_WAVE) {
+                            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                            *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            TronRegs<P> s;
+            uint32_t stamp[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                int h = cfg.start_heads[p];
+                s.d[p] = cfg.start_dirs[p];
+                s.k[p] = 0;
+                if (!from_start) {
+                    h = valid ? heads[p * B + bb] : 0;
+                    s.d[p] = valid ? dirs[p * B + bb] : 0;
+                    s.k[p] = valid ? deaths[p * B + bb] : 1;
+                }
+                const int y = (int)__umulhi((uint32_t)h, g.inv_n);
+                s.h[p] = bmine + (y + 1) * RS + (h - y * N);
+                stamp[p] = (uint32_t)(p + 1);
+            }
+            if (from_start) {                                   // an empty board with the heads stamped
+                for (int y = 0; y < N; ++y)
+#pragma unroll
+                    for (int j = 0; j < kRowDwords; ++j) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
+                        *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
+                    }
+#pragma unroll
+                for (int p = 0; p < P; ++p) *(lds_u8 *)(uintptr_t)(uint32_t)s.h[p] = (uint8_t)(p + 1);
+            }
+            const int junk = bmine + pad.junk;
+            LdsBoard<(P <= 7) ? 3 : 4> bd{0u};                  // single episode: tag 0, cells hold the plain owner
+            TronRng<P> rr;
+            rr.start(gid, c_r, seed_lo, seed_hi);
+            rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
+            for (int t = 0; __builtin_amdgcn_ballot_w64(t < steps_r) != 0; ++t) {
+                TronProbe<P> pr;
+                tron_probe_padded<P>(step4, bd, s, act, pr);
+                c_r += 1;
+                rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
+                tron_resolve_lds<P>(bd, s, pr, stamp, junk, t < steps_r);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // copy out: cells are plain owners (walls are never copied)
+            int8_t *gslab = board + env0 * NN;
+            if (wide) {
+                const int bytes = n_env * NN;
+                for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                    const int cq = (off - e * NN) >> 2;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                        w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
+                    }
+                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            } else {
+                for (int e = 0; e < n_env; ++e)
+                    for (int c = lane; c < NN; c += CRL_WAVE) {
+                        const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                        gslab[(int64_t)e * NN + c] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N));
+                    }
+            }
+            if (valid) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int rel = s.h[p] - bmine;
+                    const int row = rel / RS;
+                    heads[p * B + b] = (int16_t)((row - 1) * N + (rel - row * RS));
+                    dirs[p * B + b] = (int8_t)s.d[p];
+                    deaths[p * B + b] = (int8_t)s.k[p];
+                }
+            }
+        }
+        if (LARGE) __syncthreads();
     }
 }
 
@@ -1152,39 +1464,56 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
-    CRL_REQUIRE((flags & ~CRL_ROLLOUT_NO_LDS) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
     if (T == 0) return CRL_OK;
     hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
-    // LDS-resident kernel: 256 games per workgroup on boards up to 20x20, 64 (one wave) up to 40x40
+    // LDS-resident kernels.  Byte slabs: 256 games per workgroup on boards up to 20x20, 64 (one wave) up to 40x40.
+    // Bitboards (T >= 256): 256 games per workgroup either way; the replay takes the byte slabs one wave at a time
+    // on the larger boards.
     const bool small = cfg.N <= kLdsMaxNSmall;
     const int RS = small ? kRowBytesSmall : kRowBytesLarge;
-    const int threads = small ? 256 : 64;
     const TronPad pad = pad_of(cfg, RS);
-    const size_t lds_bytes = (size_t)threads * pad.stride;
-    const bool use_lds = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kLdsMaxNLarge && lds_bytes <= (size_t)kLdsDynamic &&
-                         (((uintptr_t)board & 15) == 0);
+    const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
+    const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || T >= 256);
+    TronBits bits;
+    bits.stride = small ? (30 + 3) * 4 : (kLdsMaxNLarge + 3) * 8;      // odd number of row words either way
+    const int threads = (use_bits || small) ? 256 : 64;
+    const size_t byte_slabs = (size_t)(small ? 256 : 64) * pad.stride;
+    const size_t lds_bytes = use_bits ? std::max(byte_slabs, (size_t)256 * bits.stride) : byte_slabs;
+    CRL_REQUIRE(!lds_ok || lds_bytes <= (size_t)kLdsDynamic, "crl_tron_rollout: internal: %zu bytes of LDS", lds_bytes);
     TRON_DISPATCH_P(cfg.P, {
-        if (use_lds) {
+        if (lds_ok) {
             // opt in to > 64 KiB of dynamic LDS once per kernel instance and device (not per launch)
-            static thread_local int opted_in[2][64] = {{0}};
+            static thread_local int opted_in[4][64] = {{0}};
             int dev = 0;
             CRL_HIP(hipGetDevice(&dev));
-            const void *fn = small ? reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesSmall>)
-                                   : reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesLarge>);
-            if (dev < 0 || dev >= 64 || !opted_in[small][dev]) {
+            const int which = (use_bits ? 2 : 0) + (small ? 1 : 0);
+            const void *fn = use_bits ? (small ? reinterpret_cast<const void *>(&tron_rollout_bits_kernel<PP, false>)
+                                               : reinterpret_cast<const void *>(&tron_rollout_bits_kernel<PP, true>))
+                                      : (small ? reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesSmall>)
+                                               : reinterpret_cast<const void *>(&tron_rollout_lds_kernel<PP, kRowBytesLarge>));
+            if (dev < 0 || dev >= 64 || !opted_in[which][dev]) {
                 CRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDynamic));
-                if (dev >= 0 && dev < 64) opted_in[small][dev] = 1;
+                if (dev >= 0 && dev < 64) opted_in[which][dev] = 1;
             }
-            if (small)
-                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesSmall>), dim3(blocks_for(B, threads)), dim3(threads), lds_bytes, s,
-                                   cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            const dim3 grid(blocks_for(B, threads));
+            const dim3 block(threads);
+            if (use_bits && small)
+                hipLaunchKernelGGL((tron_rollout_bits_kernel<PP, false>), grid, block, lds_bytes, s, cfg, g, pad, bits, B,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            else if (use_bits)
+                hipLaunchKernelGGL((tron_rollout_bits_kernel<PP, true>), grid, block, lds_bytes, s, cfg, g, pad, bits, B,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            else if (small)
+                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesSmall>), grid, block, lds_bytes, s, cfg, g, pad, B,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
             else
-                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesLarge>), dim3(blocks_for(B, threads)), dim3(threads), lds_bytes, s,
-                                   cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesLarge>), grid, block, lds_bytes, s, cfg, g, pad, B,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         } else {
             hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);

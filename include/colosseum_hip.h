@@ -49,6 +49,8 @@ extern "C" {
 #define CRL_STEP_AUTO_RESET 1u  /* after writing the step outputs, reset every env that just became terminal */
 /* flags for crl_tron_rollout */
 #define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
+#define CRL_ROLLOUT_BYTES   4u  /* force the byte-per-cell LDS kernel (default for T < 256) */
+#define CRL_ROLLOUT_BITS    8u  /* force the bitboard LDS kernel with replay epilogue (default for T >= 256) */
 
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 
@@ -108,8 +110,11 @@ typedef struct {
  *   W = Philox4x32-10(ctr = {g, c >> 3, p >> 2, 0x54520000}, key = {seed lo, seed hi})
  *   j = c & 7;  v = W[j >> 1] * 3^((j & 1) * 4 + (p & 3))  (mod 2^32)
  *   a = mulhi32(v, 3): 0 -> forward, 1 -> right, 2 -> left        (base-3 digits of the fraction W/2^32)
- * Boards up to 25x25 are played out of LDS (one copy in / one copy out per launch); larger boards, or
- * flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  Both give identical results. */
+ * Boards up to 40x40 are played out of LDS (one copy in / one copy out per launch): launches of T >= 256 steps on
+ * an occupancy bitboard whose final episode is replayed with owners, shorter ones on a byte-per-cell slab; larger
+ * boards, or flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / CRL_ROLLOUT_BITS pin
+ * one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
+ * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player. */
 int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                      crl_tron_stats stats, uint32_t flags, void *stream);

@@ -8,15 +8,17 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle as O
 
 
-@pytest.mark.parametrize("N,P,B,T,use_lds", [(20, 4, 4096, 1500, True), (20, 4, 2048, 1000, False), (13, 7, 1024, 1200, True),
-                                             (30, 3, 1024, 800, True), (6, 2, 512, 3000, True), (12, 8, 512, 1500, True),
-                                             (23, 4, 512, 1200, True), (16, 5, 700, 1200, True), (40, 4, 1000, 900, True),
-                                             (36, 8, 300, 700, True), (40, 4, 512, 600, False)])
-def test_tron_long_rollout(N, P, B, T, use_lds):
+@pytest.mark.parametrize("N,P,B,T,kernel", [(20, 4, 4096, 1500, "bits"), (20, 4, 4096, 1500, "bytes"), (20, 4, 2048, 1000, "global"),
+                                            (13, 7, 1024, 1200, "bits"), (13, 7, 1024, 1200, "bytes"), (30, 3, 1024, 800, "bits"),
+                                            (30, 3, 1024, 800, "bytes"), (6, 2, 512, 3000, "bits"), (6, 2, 512, 3000, "bytes"),
+                                            (12, 8, 512, 1500, "bits"), (12, 8, 512, 1500, "bytes"), (23, 4, 512, 1200, "auto"),
+                                            (16, 5, 700, 1200, "bytes"), (40, 4, 1000, 900, "bits"), (40, 4, 1000, 900, "bytes"),
+                                            (36, 8, 300, 700, "bits"), (36, 8, 300, 700, "bytes"), (40, 4, 512, 600, "global")])
+def test_tron_long_rollout(N, P, B, T, kernel):
     from colosseumrl_amd.batched import TronBatch
     seed, first = 0x5EED + N, 10 ** 6
     tb = TronBatch(N, P, B, first_env_id=first)
-    tb.rollout(T, seed, use_lds=use_lds)
+    tb.rollout(T, seed, kernel=kernel)
     sh, sd = O.tron_start_positions(N, P)
     ost = O.TronState(N, P, B)
     O.tron_reset(ost, sh, sd)

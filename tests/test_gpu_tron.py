@@ -64,14 +64,14 @@ def test_step_vs_oracle_random(N, P, B, T):
             assert np.array_equal(s1[k], s2[k]), (k, t)
 
 
-def _rollout_pair(N, P, B, chunks, seed, first, use_lds=True):
+def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
     sh, sd = O.tron_start_positions(N, P)
     hip = HipTron(N, P, B, sh, sd)
     hip.tb.first_env_id = first
     ost = O.TronState(N, P, B)
     O.tron_reset(ost, sh, sd)
     for T in chunks:
-        hip.tb.rollout(T, seed, use_lds=use_lds)
+        hip.tb.rollout(T, seed, kernel=kernel)
         O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=8)
     tb = hip.tb
     got = dict(board=tb.board, heads=tb.heads, dirs=tb.dirs, deaths=tb.deaths, tcount=tb.tcount, tstep=tb.tstep,
@@ -84,16 +84,43 @@ def _rollout_pair(N, P, B, chunks, seed, first, use_lds=True):
     return ost
 
 
-@pytest.mark.parametrize("use_lds", [True, False])
+@pytest.mark.parametrize("kernel", ["bits", "bytes", "global", "auto"])
 @pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
                                            (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,)),
-                                           (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,))])
-def test_rollout_vs_oracle(N, P, B, chunks, use_lds):
-    """Fused random-agent rollout == oracle rollout, bit for bit, for the LDS-resident and the global-memory
-    kernel, ragged batches, odd boards (byte copy path), split launches (state and RNG position carry over) and
-    launches long enough to wrap the LDS kernel's episode tags (32 episodes for P <= 7, 16 for P = 8)."""
-    ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, use_lds=use_lds)
+                                           (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,)),
+                                           (20, 4, 1000, (300, 2, 260)), (40, 4, 700, (1, 1, 290)), (37, 7, 130, (280,))])
+def test_rollout_vs_oracle(N, P, B, chunks, kernel):
+    """Fused random-agent rollout == oracle rollout, bit for bit, for the three kernels behind crl_tron_rollout (LDS
+    bitboard with replay epilogue, LDS byte slabs, global memory) and the library's own choice: ragged batches, odd
+    boards (byte copy path), split launches (state and RNG position carry over; a 1-step launch makes the bitboard
+    kernel replay from the incoming state), and launches long enough to wrap the byte kernel's episode tags."""
+    ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, kernel=kernel)
     assert ost.n_episodes.sum() > B
+
+
+@pytest.mark.parametrize("kernel", ["bits", "bytes", "global"])
+def test_rollout_after_scripted_steps(kernel):
+    """A rollout continues from whatever state the step API left (mid-episode, some players dead, histories that no
+    RNG stream produced): the bitboard kernel must resume from the incoming board, not from the episode start."""
+    N, P, B, seed, first = 20, 4, 2000, 99, 5
+    sh, sd = O.tron_start_positions(N, P)
+    hip, ora = HipTron(N, P, B, sh, sd), OracleTron(N, P, B, sh, sd)
+    hip.tb.first_env_id = first
+    rng = np.random.default_rng(3)
+    for t in range(6):
+        act = rng.choice(np.array([0, 1, -1], dtype=np.int8), size=(P, B))
+        r1, t1, w1 = hip.step(act)
+        r2, t2, w2 = ora.step(act)
+        assert np.array_equal(t1, t2)
+    ost = ora.st
+    ost.tcount[:] = 0
+    ost.tstep[:] = 0
+    for T in (3, 40):
+        hip.tb.rollout(T, seed, kernel=kernel)
+        O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=8)
+        for k in ("board", "heads", "dirs", "deaths", "tstep", "n_episodes", "win_count", "ret_sum", "len_sum"):
+            want = getattr(ost, k)
+            assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), (k, T)
 
 
 @pytest.mark.parametrize("N", [20, 40])
