@@ -57,7 +57,8 @@ def algorithmic_bytes_per_step(game, kw, mean_len):
 def kernel_name(game, kw):
     """The dominant kernel of the workload (what the rocprof summaries under profiles/ list)."""
     if game == "tron":
-        return "tron_rollout_lds_kernel" if kw["board_size"] <= 40 else "tron_rollout_kernel"   # csrc/tron.hip, crl_tron_rollout
+        n = kw["board_size"]                                     # csrc/tron.hip, crl_tron_rollout's choice
+        return "tron_rollout_lds_kernel" if n <= 20 else "tron_rollout_bits_kernel" if n <= 40 else "tron_rollout_kernel"
     return "%s_rollout_kernel" % game
 
 

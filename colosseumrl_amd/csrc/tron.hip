@@ -842,7 +842,8 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
 // tron_rollout_lds_kernel: actions are a pure function of (seed, env id, step counter), so a game that was reset
 // during the launch is replayed from the start layout for its `tstep` steps, and the rare game whose episode
 // spans the whole launch is replayed from the state it came in with.  Random agents live ~10 steps, so a replay
-// is a few dozen steps per wave against thousands of fused steps; crl_tron_rollout picks this kernel for T >= 256.
+// is a few dozen steps per wave against thousands of fused steps; crl_tron_rollout picks this kernel for T >= 256
+// on boards above 20x20 (where bitboards fit four times the games of byte slabs into a CU's LDS).
 // A 32-bit row holds boards up to 30x30, but the replay slabs limit it to the byte kernel's sizes (20 / 40).
 struct TronBits {
     int stride;      // bytes per bit slab: rows 0 .. kMaxRows+1 plus one junk row; odd number of row words
@@ -891,6 +892,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             w |= (fy == r) ? (row_t)1 << (fh - fy * N) : (row_t)0;
         }
         freshrow[r] = w;
+        asm volatile("" : "+v"(freshrow[r]));                   // VGPRs, not SGPRs: the reset stores them as they are
     }
     // ---- copy in: the lane lays out its slab (walls), the wave ORs the occupied cells of its 64 boards in
     *(lds_row *)(uintptr_t)(uint32_t)mine = ~(row_t)0;
@@ -928,15 +930,17 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         }
     }
     // heads as BIT addresses: 8 * (slab address of the row word) + x; a step is +-1 or +-ROWBITS
+    // deaths are LANE MASKS (one 64-bit scalar per player, bit = lane): every boolean of the resolve is then a
+    // scalar and/or on the side of the vector pipe; compares feed them through ballots, selects read them back
     int pos[P], dir_[P], fresh_pos[P], fresh_dir[P];
-    bool dead[P];
+    uint64_t dead[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int h = valid ? heads[p * B + bb] : 0;
         const int y = (int)__umulhi((uint32_t)h, g.inv_n);
         pos[p] = 8 * mine + (y + 1) * ROWBITS + (h - y * N);
         dir_[p] = valid ? dirs[p * B + bb] : 0;
-        dead[p] = valid ? (deaths[p * B + bb] != 0) : true;
+        dead[p] = __builtin_amdgcn_ballot_w64(valid ? (deaths[p * B + bb] != 0) : true);
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
         fresh_pos[p] = 8 * mine + (fy + 1) * ROWBITS + (fh - fy * N);
@@ -948,74 +952,80 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     acc.load(st, valid, bb);
     const uint32_t ts_at_entry = acc.ts;
     uint32_t alive_steps[P];
-    bool last_dead[P];
+    int last_alive = 0;                                         // who was alive at this lane's latest terminal step
 #pragma unroll
-    for (int p = 0; p < P; ++p) { alive_steps[p] = 0; last_dead[p] = true; }
+    for (int p = 0; p < P; ++p) alive_steps[p] = 0;
+    const uint64_t valid_m = __builtin_amdgcn_ballot_w64(valid);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
     int act[P];
     __syncthreads();                                            // action table
     rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
     for (int t = 0; t < T; ++t) {
+        // positions are linear bit addresses, so the 32-bit word holding a cell is (pos >> 3) & ~3 whatever the row width
         int np[P], nd[P], ra[P];
-        row_t roww[P];
+        uint32_t roww[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {                           // CyTronGrid.pyx:21-41, all P probes in flight
             nd[i] = (dir_[i] + act[i]) & 3;
             np[i] = pos[i] + __builtin_amdgcn_sbfe((int)bstep4, nd[i] << 3, 8);
-            ra[i] = (np[i] >> 3) & ~(RB - 1);
+            ra[i] = (np[i] >> 3) & ~3;
         }
 #pragma unroll
-        for (int i = 0; i < P; ++i) roww[i] = *(const lds_row *)(uintptr_t)(uint32_t)ra[i];
+        for (int i = 0; i < P; ++i) roww[i] = *(const lds_u32 *)(uintptr_t)(uint32_t)ra[i];
         acc.tc += 1;
         rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
 #pragma unroll
-        for (int i = 0; i < P; ++i) {                           // CyTronGrid.pyx:15-62 with deaths as booleans
-            const bool run = !dead[i];
-            bool on_head[P];
+        for (int i = 0; i < P; ++i) {                           // CyTronGrid.pyx:15-62 with deaths as lane masks
+            const uint64_t run = ~dead[i];                      // :16 (may have been killed head-on by j < i)
+            uint64_t on_head[P];
 #pragma unroll
-            for (int q = 0; q < P; ++q) on_head[q] = (q != i) && (np[i] == pos[q]);
-            bool occ = ((roww[i] >> (np[i] & (ROWBITS - 1))) & 1) != 0;    // trail or wall
+            for (int q = 0; q < P; ++q) on_head[q] = (q != i) ? __builtin_amdgcn_ballot_w64(np[i] == pos[q]) : 0ull;
+            const uint32_t bit = 1u << (np[i] & 31);
+            uint64_t occ = __builtin_amdgcn_ballot_w64((roww[i] & bit) != 0);     // trail or wall
 #pragma unroll
             for (int j = 0; j < i; ++j) occ |= on_head[j];      // j moved there earlier in this very step
-            const bool moved = run & !occ;
+            const uint64_t moved_m = run & ~occ;
             dead[i] |= run & occ;
 #pragma unroll
             for (int q = 0; q < P; ++q)
                 if (q != i) dead[q] |= run & on_head[q];        // :56-57 head-on: the owner dies too
-            dir_[i] = run ? nd[i] : dir_[i];
+            const bool moved = __builtin_amdgcn_inverse_ballot_w64(moved_m);
+            dir_[i] = __builtin_amdgcn_inverse_ballot_w64(run) ? nd[i] : dir_[i];
             pos[i] = moved ? np[i] : pos[i];
-            const row_t bit = (row_t)1 << (np[i] & (ROWBITS - 1));
-            if (LARGE) atomicOr((unsigned long long *)(lds + ((moved ? ra[i] : junk_row) - lds0)), (unsigned long long)bit);
-            else atomicOr((unsigned int *)(lds + ((moved ? ra[i] : junk_row) - lds0)), (unsigned int)bit);
+            atomicOr((unsigned int *)(lds + ((moved ? ra[i] : junk_row) - lds0)), bit);
         }
-        int alive = 0;
+        // per-lane view of who is alive (0 / 1), shared by the step count, the terminal test and the winners
+        uint32_t alive01[P], alive = 0, alive_bits = 0;
 #pragma unroll
-        for (int p = 0; p < P; ++p) alive += !dead[p];
-        const bool term = alive <= 1;                           // TronGridEnvironment.py:309-321
+        for (int p = 0; p < P; ++p) {
+            alive01[p] = __builtin_amdgcn_inverse_ballot_w64(~dead[p]) ? 1u : 0u;
+            alive_steps[p] += alive01[p];
+            alive += alive01[p];
+            alive_bits |= alive01[p] << p;
+        }
+        const uint64_t term_m = __builtin_amdgcn_ballot_w64(alive <= 1) & valid_m;      // TronGridEnvironment.py:309-321
         acc.ts += 1;
+        if (term_m) {                                           // some game of the wave ended
+            if (__builtin_amdgcn_inverse_ballot_w64(term_m)) {  // new_state: the whole board from the register pattern
+                last_alive = (int)alive_bits;
 #pragma unroll
-        for (int p = 0; p < P; ++p) alive_steps[p] += !dead[p];
-        if (valid && term) {                                    // new_state: the whole board from the register pattern
+                for (int r = 0; r < kMaxRows; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + (r + 1) * RB) = freshrow[r];
+                acc.n_ep += 1;
+                acc.last_len = (int)acc.ts;
+                acc.ts = 0;
 #pragma unroll
-            for (int r = 0; r < kMaxRows; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + (r + 1) * RB) = freshrow[r];
-            acc.n_ep += 1;
-            acc.last_len = (int)acc.ts;
-            acc.ts = 0;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                acc.wins[p] += !dead[p];
-                last_dead[p] = dead[p];
-                pos[p] = fresh_pos[p]; dir_[p] = fresh_dir[p]; dead[p] = false;
+                for (int p = 0; p < P; ++p) {
+                    acc.wins[p] += alive01[p];
+                    pos[p] = fresh_pos[p]; dir_[p] = fresh_dir[p];
+                }
             }
+#pragma unroll
+            for (int p = 0; p < P; ++p) dead[p] &= ~term_m;
         }
     }
     acc.len_sum = ts_at_entry + (uint32_t)T - acc.ts;
-    if (acc.n_ep > 0) {
-        acc.last_w = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc.last_w |= (int)(!last_dead[p]) << p;
-    }
+    if (acc.n_ep > 0) acc.last_w = last_alive;
 #pragma unroll
     for (int p = 0; p < P; ++p) acc.ret[p] = 2 * (int)alive_steps[p] - T + 9 * (int)acc.wins[p];
     if (valid) acc.store(st, B, b);
@@ -1023,7 +1033,13 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     // ---- replay of the unfinished episode on byte slabs: rebuilds board / heads / dirs / deaths
     const bool from_start = acc.n_ep > 0;                       // else: from the state the launch came in with
     const int steps_r = valid ? (from_start ? (int)acc.ts : T) : 0;
-    uint32_t c_r = acc.tc - (uint32_t)steps_r;
+    // every lane replays the LAST steps_r of the wave's `replay_len` iterations: the games of a wave normally share
+    // their step counter, so counting backwards from the end keeps the RNG position (Philox refills) wave-uniform
+    int replay_len = steps_r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) replay_len = max(replay_len, __shfl_xor(replay_len, off, CRL_WAVE));
+    const int first_r = replay_len - steps_r;                   // this lane joins at iteration first_r
+    uint32_t c_r = acc.tc - (uint32_t)replay_len;
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
     constexpr int kTurns = LARGE ? 4 : 1;                       // LARGE: the LDS holds the byte slabs of one wave at a time
     for (int turn = 0; turn < kTurns; ++turn) {
@@ -1094,12 +1110,12 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             TronRng<P> rr;
             rr.start(gid, c_r, seed_lo, seed_hi);
             rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
-            for (int t = 0; __builtin_amdgcn_ballot_w64(t < steps_r) != 0; ++t) {
+            for (int t = 0; t < replay_len; ++t) {
                 TronProbe<P> pr;
                 tron_probe_padded<P>(step4, bd, s, act, pr);
                 c_r += 1;
                 rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
-                tron_resolve_lds<P>(bd, s, pr, stamp, junk, t < steps_r);
+                tron_resolve_lds<P>(bd, s, pr, stamp, junk, t >= first_r);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1478,7 +1494,9 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     const int RS = small ? kRowBytesSmall : kRowBytesLarge;
     const TronPad pad = pad_of(cfg, RS);
     const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
-    const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || T >= 256);
+    // default: bitboards where they buy residency (boards above 20x20 fit 4x the games per CU); on small boards the
+    // byte kernel already has every game resident and no replay to pay for
+    const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || (!small && T >= 256));
     TronBits bits;
     bits.stride = small ? (30 + 3) * 4 : (kLdsMaxNLarge + 3) * 8;      // odd number of row words either way
     const int threads = (use_bits || small) ? 256 : 64;

@@ -110,9 +110,9 @@ typedef struct {
  *   W = Philox4x32-10(ctr = {g, c >> 3, p >> 2, 0x54520000}, key = {seed lo, seed hi})
  *   j = c & 7;  v = W[j >> 1] * 3^((j & 1) * 4 + (p & 3))  (mod 2^32)
  *   a = mulhi32(v, 3): 0 -> forward, 1 -> right, 2 -> left        (base-3 digits of the fraction W/2^32)
- * Boards up to 40x40 are played out of LDS (one copy in / one copy out per launch): launches of T >= 256 steps on
- * an occupancy bitboard whose final episode is replayed with owners, shorter ones on a byte-per-cell slab; larger
- * boards, or flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / CRL_ROLLOUT_BITS pin
+ * Boards up to 40x40 are played out of LDS (one copy in / one copy out per launch): boards up to 20x20 on a
+ * byte-per-cell slab, larger ones (T >= 256) on an occupancy bitboard whose unfinished episode is replayed with
+ * owners at the end of the launch; boards above 40x40, or flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / CRL_ROLLOUT_BITS pin
  * one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
  * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player. */
 int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
