@@ -191,7 +191,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                # PMC bytes are per launch: only comparable when this run fuses the same number of steps per launch
+                traffic = tj.get("hbm_bytes_per_launch") if tj.get("steps_per_launch") == args.chunk else None
             except Exception:
                 traffic = None
         out = {

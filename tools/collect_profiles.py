@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile_bench.sh left under gpurun_out/prof_<tag>/ into profiles/<prefix>_* and, for
+bench workloads, write profiles/traffic_<workload>.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes,
+FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).
+usage: tools/collect_profiles.py <tag> <prefix> [<workload> <kernel substring> <steps_per_launch>]"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, prefix = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, prefix + "_rocprofv3_summary.txt"))
+shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, prefix + "_rocprofv3_summary.json"))
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, prefix + "_kernel_stats.csv"))
+if len(sys.argv) > 3:
+    workload, kern, spl = sys.argv[3], sys.argv[4], int(sys.argv[5])
+    summ = json.load(open(os.path.join(src, "summary.json")))
+    def find(counter):
+        for name, vals in summ.get("pmc", {}).items():
+            if kern in name and counter in vals:
+                return name, vals[counter]
+        raise SystemExit("no %s for %s" % (counter, kern))
+    name, fetch = find("FETCH_SIZE")
+    _, write = find("WRITE_SIZE")
+    out = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip(), "workload": workload,
+           "steps_per_launch": spl, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+           "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-dispatch average over %d-step launches; "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); source: profiles/%s_rocprofv3_summary.json"
+                   % (spl, prefix)}
+    json.dump(out, open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
+    print(json.dumps(out))
