@@ -904,7 +904,8 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         const int slab0 = mine - lane * bits.stride;
         if (wide) {
             const int bytes = n_env * NN;
-            for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+#pragma unroll 5
+            for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {      // unrolled: several loads in flight
                 const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                 const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
@@ -916,7 +917,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                     const uint32_t nib = ((nz >> 7) * 0x10204080u) >> 28;
                     const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
                     const int x = 4 * (cq + q - y * (N >> 2));
-                    if (nib) atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), nib << (x & 31));
+                    atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), nib << (x & 31));
                 }
             }
         } else {
@@ -1041,17 +1042,43 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const int first_r = replay_len - steps_r;                   // this lane joins at iteration first_r
     uint32_t c_r = acc.tc - (uint32_t)replay_len;
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
-    constexpr int kTurns = LARGE ? 4 : 1;                       // LARGE: the LDS holds the byte slabs of one wave at a time
+    // The LDS holds the byte slabs of all 4 waves (boards up to 20x20) or of one wave at a time (LARGE).  Per turn:
+    // the whole workgroup lays out fresh boards, the owning wave(s) replay, the whole workgroup copies the boards out.
+    constexpr int kTurns = LARGE ? 4 : 1;
+    constexpr int kSlabs = LARGE ? CRL_WAVE : 256;
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    const int slot = LARGE ? lane : (int)threadIdx.x;
+    const int bmine = lds0 + slot * pad.stride;
+    const int slab0 = bmine - lane * pad.stride;                // first slab of this wave
+    const int sd = pad.stride >> 2;                             // dwords per slab
     for (int turn = 0; turn < kTurns; ++turn) {
+        // (1) fresh boards in every slab: walls, empty cells, the start heads
+        {
+            const int part = LARGE ? wave : 0, parts = LARGE ? 4 : 1;            // threads per slab
+            const int base = lds0 + (LARGE ? lane : (int)threadIdx.x) * pad.stride;
+            for (int d = part; d < sd; d += parts) {
+                const int byte = d * 4;
+                const int row = byte / RS, col = byte - row * RS;
+                const int left = N - col;                                        // cells from this dword to the row's end
+                uint32_t v = 0xffffffffu;
+                if (row >= 1 && row <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
+                *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
+            }
+        }
+        __syncthreads();
+        if (LARGE ? wave == 0 : true) {
+            const int base = lds0 + (LARGE ? lane : (int)threadIdx.x) * pad.stride;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int fh = cfg.start_heads[p];
+                const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(base + (fy + 1) * RS + (fh - fy * N)) = (uint8_t)(p + 1);
+            }
+        }
+        __syncthreads();
+        // (2) the owning wave replays
         if (!LARGE || wave == turn) {
             constexpr int kRowDwords = RS / 4;
-            constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
-            const int slot = LARGE ? lane : (int)threadIdx.x;
-            const int bmine = lds0 + slot * pad.stride;
-            const int slab0 = bmine - lane * pad.stride;
-            for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + off) = 0xffffffffu;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (__builtin_amdgcn_ballot_w64(valid && !from_start)) {        // somebody resumes from the incoming board
                 const int8_t *gslab = board + env0 * NN;
                 if (wide) {
@@ -1076,6 +1103,22 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (from_start) {                               // this lane's slab was overwritten too: fresh again
+                    for (int y = 0; y < N; ++y)
+#pragma unroll
+                        for (int j = 0; j < kRowDwords; ++j) {
+                            uint32_t w = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
+                            *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
+                        }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const int fh = cfg.start_heads[p];
+                        const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
+                        *(lds_u8 *)(uintptr_t)(uint32_t)(bmine + (fy + 1) * RS + (fh - fy * N)) = (uint8_t)(p + 1);
+                    }
+                }
             }
             TronRegs<P> s;
             uint32_t stamp[P];
@@ -1093,18 +1136,6 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 s.h[p] = bmine + (y + 1) * RS + (h - y * N);
                 stamp[p] = (uint32_t)(p + 1);
             }
-            if (from_start) {                                   // an empty board with the heads stamped
-                for (int y = 0; y < N; ++y)
-#pragma unroll
-                    for (int j = 0; j < kRowDwords; ++j) {
-                        uint32_t w = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
-                        *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
-                    }
-#pragma unroll
-                for (int p = 0; p < P; ++p) *(lds_u8 *)(uintptr_t)(uint32_t)s.h[p] = (uint8_t)(p + 1);
-            }
             const int junk = bmine + pad.junk;
             LdsBoard<(P <= 7) ? 3 : 4> bd{0u};                  // single episode: tag 0, cells hold the plain owner
             TronRng<P> rr;
@@ -1117,30 +1148,6 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
                 tron_resolve_lds<P>(bd, s, pr, stamp, junk, t >= first_r);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // copy out: cells are plain owners (walls are never copied)
-            int8_t *gslab = board + env0 * NN;
-            if (wide) {
-                const int bytes = n_env * NN;
-                for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                    const int cq = (off - e * NN) >> 2;
-                    uint32_t w[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                        w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
-                    }
-                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            } else {
-                for (int e = 0; e < n_env; ++e)
-                    for (int c = lane; c < NN; c += CRL_WAVE) {
-                        const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                        gslab[(int64_t)e * NN + c] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N));
-                    }
-            }
             if (valid) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
@@ -1149,6 +1156,36 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                     heads[p * B + b] = (int16_t)((row - 1) * N + (rel - row * RS));
                     dirs[p * B + b] = (int8_t)s.d[p];
                     deaths[p * B + b] = (int8_t)s.k[p];
+                }
+            }
+        }
+        __syncthreads();
+        // (3) copy out: cells are plain owners (walls are never copied)
+        {
+            const int64_t gbase = (int64_t)blockIdx.x * blockDim.x + (LARGE ? turn * CRL_WAVE : 0);
+            const int64_t rem = B - gbase;
+            const int n_out = (int)(rem < 0 ? 0 : (rem > kSlabs ? kSlabs : rem));
+            int8_t *gslab = board + gbase * NN;
+            if (wide) {
+                const int bytes = n_out * NN;
+                for (int off = (int)threadIdx.x * 16; off < bytes; off += 256 * 16) {
+                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                    const int cq = (off - e * NN) >> 2;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                        w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
+                    }
+                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            } else {
+                const int cells = n_out * NN;
+                for (int i = (int)threadIdx.x; i < cells; i += 256) {
+                    const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
+                    const int c = i - e * NN;
+                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                    gslab[i] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N));
                 }
             }
         }
