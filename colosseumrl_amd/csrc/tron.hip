@@ -846,9 +846,17 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
 // on boards above 20x20 (where bitboards fit four times the games of byte slabs into a CU's LDS).
 // A 32-bit row holds boards up to 30x30, but the replay slabs limit it to the byte kernel's sizes (20 / 40).
 struct TronBits {
-    int stride;      // bytes per bit slab: rows 0 .. kMaxRows+1 plus one junk row; odd number of row words
+    int stride;      // bytes per bit slab: kMaxW pattern words + junk, a multiple of 16 (the reset stores 16 bytes at a time)
+    uint32_t inv_s;  // floor(2^32 / (N + 1)) + 1
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128;
+
+// Bitboard layout: ONE linear bit string per game, bit (y+1)*S + x for cell (x, y) with S = N + 1.  Row 0 and row
+// N+1 are all ones, and so is column N of every row -- which also is "column -1" of the next one.  (N+2)(N+1) bits:
+// 216 bytes at 40x40, 58 at 20x20 -- what a reset has to rewrite.  A head is the LDS bit address 8*slab + bit; a
+// step adds +-1 or +-S, the word holding a position is (pos >> 3) & ~3 and the bit pos & 31.
 template <int P, bool LARGE>
 __global__ void __launch_bounds__(256)
 tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const TronBits bits, const int64_t B,
@@ -856,17 +864,15 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                          int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
                          int8_t *__restrict__ deaths, const crl_tron_stats st)
 {
-    typedef typename std::conditional<LARGE, uint64_t, uint32_t>::type row_t;
-    typedef __attribute__((address_space(3))) row_t lds_row;
-    constexpr int RB = (int)sizeof(row_t);                      // bytes per row word
-    constexpr int ROWBITS = 8 * RB;
-    constexpr int kMaxRows = LARGE ? kLdsMaxNLarge : 30;        // rows the reset rewrites (slabs are sized for it)
-    constexpr int RS = LARGE ? kRowBytesLarge : kRowBytesSmall; // byte slabs of the replay
-    constexpr uint32_t bstep4 = (uint32_t)((-ROWBITS) & 0xff) | (1u << 8) | ((uint32_t)ROWBITS << 16) | (0xffu << 24);
+    constexpr int kMaxN = LARGE ? kLdsMaxNLarge : kLdsMaxNSmall;
+    constexpr int kMaxW = (((kMaxN + 2) * (kMaxN + 1) + 31) / 32 + 3) & ~3;     // pattern words, a multiple of 4
+    constexpr int RS = LARGE ? kRowBytesLarge : kRowBytesSmall;                 // byte slabs of the replay
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint8_t act_lut[84];
+    __shared__ uint32_t wall_words[kMaxW];
     tron_fill_action_lut(act_lut);
-    const int N = g.N, NN = g.NN;
+    const int N = g.N, NN = g.NN, S = N + 1;
+    const uint32_t bstep4 = (uint32_t)((-S) & 0xff) | (1u << 8) | ((uint32_t)S << 16) | (0xffu << 24);
     const int lane = threadIdx.x & (CRL_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -877,26 +883,37 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
     const int mine = lds0 + (int)threadIdx.x * bits.stride;     // this lane's bit slab
     const bool wide = (N & 3) == 0;
-    const row_t wallpat = (row_t)(~(row_t)0) << N;              // bits x >= N of a board row
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
 
-    // the start layout as row words (row r of the slab = board row r - 1), kept in registers for resets
-    row_t freshrow[kMaxRows];
+    // the empty board (walls only), one word per thread, shared through LDS ...
+    if (threadIdx.x < kMaxW) {
+        uint32_t w = 0;
+        for (int k = 0; k < 32; ++k) {
+            const uint32_t bit = threadIdx.x * 32 + k;
+            const uint32_t row = __umulhi(bit, bits.inv_s), col = bit - row * S;
+            w |= (uint32_t)((row == 0) | (row > (uint32_t)N) | (col == (uint32_t)N)) << k;
+        }
+        wall_words[threadIdx.x] = w;
+    }
+    __syncthreads();
+    // ... and the start layout (walls + heads) in registers, for resets
+    uint32_t fresh[kMaxW];
 #pragma unroll
-    for (int r = 0; r < kMaxRows; ++r) {
-        row_t w = (r < N) ? wallpat : ~(row_t)0;
+    for (int j = 0; j < kMaxW; ++j) {
+        uint32_t w = wall_words[j];
+        *(lds_u32 *)(uintptr_t)(uint32_t)(mine + 4 * j) = w;    // this lane's slab starts out empty
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int fh = cfg.start_heads[p];
             const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
-            w |= (fy == r) ? (row_t)1 << (fh - fy * N) : (row_t)0;
+            const int fb = (fy + 1) * S + (fh - fy * N);
+            w |= ((fb >> 5) == j) ? 1u << (fb & 31) : 0u;
         }
-        freshrow[r] = w;
-        asm volatile("" : "+v"(freshrow[r]));                   // VGPRs, not SGPRs: the reset stores them as they are
+        fresh[j] = w;
+        asm volatile("" : "+v"(fresh[j]));                      // VGPRs, not SGPRs: the reset stores them as they are
     }
-    // ---- copy in: the lane lays out its slab (walls), the wave ORs the occupied cells of its 64 boards in
-    *(lds_row *)(uintptr_t)(uint32_t)mine = ~(row_t)0;
-    for (int r = 1; r <= kMaxRows + 2; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + r * RB) = (r <= N) ? wallpat : ~(row_t)0;
+    const int junk_row = mine + 4 * kMaxW;                      // a word nobody reads
+    // ---- copy in: the wave ORs the occupied cells of its 64 boards into the slabs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
@@ -914,23 +931,26 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 for (int q = 0; q < 4; ++q) {
                     // one bit per non-zero byte of the dword (bit 7 of (b | (b & 0x7f) + 0x7f) <=> b != 0), gathered to a nibble
                     const uint32_t nz = (((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u;
-                    const uint32_t nib = ((nz >> 7) * 0x10204080u) >> 28;
+                    const uint64_t nib = ((nz >> 7) * 0x10204080u) >> 28;
                     const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                    const int x = 4 * (cq + q - y * (N >> 2));
-                    atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), nib << (x & 31));
+                    const int bit = (y + 1) * S + 4 * (cq + q - y * (N >> 2));   // 4 cells of one row: contiguous bits,
+                    const uint64_t two = nib << (bit & 31);                       // possibly across a word boundary
+                    unsigned int *wp = (unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2));
+                    atomicOr(wp, (unsigned int)two);
+                    atomicOr(wp + 1, (unsigned int)(two >> 32));
                 }
             }
         } else {
             for (int e = 0; e < n_env; ++e)
                 for (int c = lane; c < NN; c += CRL_WAVE) {
                     const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                    const int x = c - y * N;
+                    const int bit = (y + 1) * S + (c - y * N);
                     if (gslab[(int64_t)e * NN + c] != 0)
-                        atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + (y + 1) * RB + ((x >> 5) << 2)), 1u << (x & 31));
+                        atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2)), 1u << (bit & 31));
                 }
         }
     }
-    // heads as BIT addresses: 8 * (slab address of the row word) + x; a step is +-1 or +-ROWBITS
+    // heads as BIT addresses: 8 * slab address + bit index; a step is +-1 or +-S
     // deaths are LANE MASKS (one 64-bit scalar per player, bit = lane): every boolean of the resolve is then a
     // scalar and/or on the side of the vector pipe; compares feed them through ballots, selects read them back
     int pos[P], dir_[P], fresh_pos[P], fresh_dir[P];
@@ -939,16 +959,15 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     for (int p = 0; p < P; ++p) {
         const int h = valid ? heads[p * B + bb] : 0;
         const int y = (int)__umulhi((uint32_t)h, g.inv_n);
-        pos[p] = 8 * mine + (y + 1) * ROWBITS + (h - y * N);
+        pos[p] = 8 * mine + (y + 1) * S + (h - y * N);
         dir_[p] = valid ? dirs[p * B + bb] : 0;
         dead[p] = __builtin_amdgcn_ballot_w64(valid ? (deaths[p * B + bb] != 0) : true);
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
-        fresh_pos[p] = 8 * mine + (fy + 1) * ROWBITS + (fh - fy * N);
+        fresh_pos[p] = 8 * mine + (fy + 1) * S + (fh - fy * N);
         fresh_dir[p] = cfg.start_dirs[p];
         asm volatile("" : "+v"(fresh_pos[p]), "+v"(fresh_dir[p]));
     }
-    const int junk_row = mine + (kMaxRows + 2) * RB;
     TronAcc<P> acc;
     acc.load(st, valid, bb);
     const uint32_t ts_at_entry = acc.ts;
@@ -1011,7 +1030,8 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             if (__builtin_amdgcn_inverse_ballot_w64(term_m)) {  // new_state: the whole board from the register pattern
                 last_alive = (int)alive_bits;
 #pragma unroll
-                for (int r = 0; r < kMaxRows; ++r) *(lds_row *)(uintptr_t)(uint32_t)(mine + (r + 1) * RB) = freshrow[r];
+                for (int j = 0; j < kMaxW; j += 4)
+                    *(lds_u128 *)(uintptr_t)(uint32_t)(mine + 4 * j) = (u32x4){fresh[j], fresh[j + 1], fresh[j + 2], fresh[j + 3]};
                 acc.n_ep += 1;
                 acc.last_len = (int)acc.ts;
                 acc.ts = 0;
@@ -1419,7 +1439,7 @@ inline TronPad pad_of(const crl_tron_cfg &cfg, const int RS)
     return p;
 }
 
-constexpr int kLdsDynamic = 160 * 1024 - 256;   // dynamic part; the kernel also holds a small static action table
+constexpr int kLdsDynamic = 160 * 1024 - 1024;  // dynamic part; the kernels also hold small static tables (actions, wall pattern)
 
 
 } // namespace
@@ -1535,7 +1555,12 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     // byte kernel already has every game resident and no replay to pay for
     const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || (!small && T >= 256));
     TronBits bits;
-    bits.stride = small ? (30 + 3) * 4 : (kLdsMaxNLarge + 3) * 8;      // odd number of row words either way
+    {
+        const int max_n = small ? kLdsMaxNSmall : kLdsMaxNLarge;
+        const int max_w = (((max_n + 2) * (max_n + 1) + 31) / 32 + 3) & ~3;
+        bits.stride = (max_w + 4) * 4;                                  // pattern words + a junk word, 16-byte multiple
+        bits.inv_s = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(cfg.N + 1)) + 1u;
+    }
     const int threads = (use_bits || small) ? 256 : 64;
     const size_t byte_slabs = (size_t)(small ? 256 : 64) * pad.stride;
     const size_t lds_bytes = use_bits ? std::max(byte_slabs, (size_t)256 * bits.stride) : byte_slabs;
