@@ -29,9 +29,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 WORKLOADS = {
-    # name: (game, kwargs, per-GPU batch)
+    # name: (game, kwargs, per-GPU batch[, env-steps fused into one launch when --chunk is not given (default 2048)])
     "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536),
-    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536),
+    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192),   # longer launches: replay epilogue
     "ttt_p3_5x5_k4_b262144": ("ttt", dict(dims=(5, 5), k=4, num_players=3), 262144),
     "ttt_p3_3x5_k3_b262144": ("ttt", dict(dims=(3, 5), k=3, num_players=3), 262144),
     "ttt_p4_3x3x3_b262144": ("ttt", dict(dims=(3, 3, 3), k=3, num_players=4), 262144),
@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="tron_p4_n20_b65536", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
-    ap.add_argument("--chunk", type=int, default=2048, help="env-steps fused into one kernel launch")
+    ap.add_argument("--chunk", type=int, default=0, help="env-steps fused into one kernel launch (default: the workload's, 2048)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -146,9 +146,11 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
 
-    game, kw, batch = WORKLOADS[args.workload]
+    game, kw, batch = WORKLOADS[args.workload][:3]
     if args.batch > 0:
         batch = args.batch
+    if args.chunk <= 0:
+        args.chunk = WORKLOADS[args.workload][3] if len(WORKLOADS[args.workload]) > 3 else 2048
     from colosseumrl_amd.parallel import ShardedRollout
     # weak scaling: every rank owns `batch` games; global ids rank*batch .. (rank+1)*batch - 1
     sr = ShardedRollout(lambda batch, first_env_id: make_stepper(game, kw, batch, device, first_env_id), world * batch)
