@@ -13,12 +13,14 @@
 // heads) and patches same-step interactions in registers, so it costs one round of loads and one
 // round of stores instead of P dependent round trips.
 //
-// Two rollout kernels (T fused steps, random agent, auto-reset):
-//   * LDS-resident (boards up to 25x25): every wave copies its 64 boards into LDS once, plays all T
-//     steps there (probe = ds_read_u8; a finished game bumps its episode tag instead of clearing its
-//     board), and writes the boards back once.  HBM sees 2*N*N bytes per game per LAUNCH.
-//   * global-memory (larger boards): boards stay in HBM / Infinity Cache, same tagged-cell scheme, tags
-//     stripped in place at the end.
+// Three interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
+//   * LDS byte slabs (boards up to 20x20: 256 games per workgroup; up to 40x40: 64): every wave copies its boards
+//     into LDS once, plays all T steps there (wall-bordered slabs, heads as LDS addresses, episode-tagged cells with
+//     a rolling one-row rewrite instead of board clears), and writes the boards back once.
+//   * LDS bitboards + replay (default above 20x20, T >= 256): occupancy only while playing, deaths as lane masks;
+//     the unfinished episode is replayed on byte slabs at the end to recover owners.
+//   * global-memory (boards above 40x40): boards stay in HBM / Infinity Cache, same tagged cells, tags stripped
+//     in place at the end.
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
 #include <type_traits>
