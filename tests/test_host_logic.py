@@ -79,6 +79,14 @@ def test_c_abi_exports_every_declared_symbol():
     assert _native.lib().crl_version() >= 100
 
 
+def test_native_constants_mirror_the_header():
+    """Flag / limit constants the Python side passes through the C ABI are the header's."""
+    header = open(os.path.join(ROOT, "include", "colosseum_hip.h")).read()
+    defines = {m.group(1): int(m.group(2).rstrip("u"), 0) for m in re.finditer(r"#define\s+(CRL_[A-Z_]+)\s+(-?[0-9a-fx]+u?)\b", header)}
+    for name in ("CRL_STEP_AUTO_RESET", "CRL_ROLLOUT_NO_LDS", "CRL_ROLLOUT_BYTES", "CRL_ROLLOUT_BITS"):
+        assert getattr(_native, name) == defines[name], name
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product path must raise, not compute."""
     import torch
