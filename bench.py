@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 
 WORKLOADS = {
     # name: (game, kwargs, per-GPU batch[, env-steps fused into one launch when --chunk is not given (default 2048)])
@@ -189,13 +190,15 @@ def main():
         per_launch_steps = batch * args.steps / launches
         launch_s = kernel_ms * 1e-3 / launches
         achieved = bytes_per_step * per_launch_steps / launch_s / 1e9
-        traffic = None
+        traffic = valu_insts = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 # PMC bytes are per launch: only comparable when this run fuses the same number of steps per launch
-                traffic = tj.get("hbm_bytes_per_launch") if tj.get("steps_per_launch") == args.chunk else None
+                same = tj.get("steps_per_launch") == args.chunk
+                traffic = tj.get("hbm_bytes_per_launch") if same else None
+                valu_insts = tj.get("valu_insts_per_launch") if same else None
             except Exception:
                 traffic = None
         out = {
@@ -211,6 +214,11 @@ def main():
                          "kernel": kernel_name(game, kw), "launch_ms": launch_s * 1e3,
                          "algorithmic_bytes_per_env_step": round(bytes_per_step, 2)},
         }
+        if valu_insts:
+            # second view for these integer kernels: wave-instructions the VALUs issued (PMC SQ_INSTS_VALU of the same
+            # launch shape, profiles/) over this run's launch time, against one wave64 VALU instruction per SIMD per 4 cycles
+            out["roofline"]["valu_issue"] = {"achieved": valu_insts / launch_s, "peak": VALU_PEAK_WAVE_INSTS,
+                                             "unit": "wave-instr/s", "frac": valu_insts / launch_s / VALU_PEAK_WAVE_INSTS}
         if out["roofline"]["frac"] > 1.0:
             # the fused rollout keeps boards in LDS for all steps of a launch: the per-step state traffic the
             # algorithmic figure counts (a step-at-a-time stepper) never reaches HBM, so the HBM roofline of
