@@ -68,6 +68,7 @@ PROTOTYPES = {
     "crl_tron_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_observe_all": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_ranking": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    "crl_tron_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _I, _VP, _VP]),
     "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),
     "crl_ttt_lines": (_I, [_VP, _VP, _I]),
     "crl_ttt_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "crl_ttt_valid": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
+    "crl_ttt_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _I, _VP, _VP]),
     "crl_blokus_create": (_I, [C.POINTER(_VP)]),
     "crl_blokus_placement": (_I, [_I, _I, _I, _VP]),
     "crl_blokus_stamps": (_I, [_VP, _I]),
@@ -84,6 +86,7 @@ PROTOTYPES = {
     "crl_blokus_board": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_blokus_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, _VP, BlokusStats, _VP]),
+    "crl_blokus_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
 }
 
 

@@ -138,6 +138,17 @@ class TronBatch:
                                              self._stats(), flags, _stream()),
                   "crl_tron_rollout")
 
+    # -- the rollout's random agent for one step: int8 [P][B] actions in the step() encoding
+    def sample(self, seed: int = 0, advance: bool = True):
+        """Actions the fused rollout would take at each game's step counter (``tcount``); with ``advance`` the counter
+        moves on, so ``step(sample(seed), auto_reset=True)`` T times == ``rollout(T, seed)``.  Overwrite the rows of
+        the players you control."""
+        act = torch.empty((self.P, self.B), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_sample(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id,
+                                            _ptr(self.tcount), int(advance), _ptr(act), _stream()), "crl_tron_sample")
+        return act
+
     # -- state_to_observation for all games; player int8 [B]
     def observe(self, player: torch.Tensor):
         _want(player, torch.int8, (self.B,), self.device, "player")
@@ -247,6 +258,15 @@ class TTTBatch:
             check(self._lib.crl_ttt_valid(self._ctx.handle, self.B, _ptr(self.occ), _ptr(out), _stream()), "crl_ttt_valid")
         return out
 
+    def sample(self, seed: int = 0, advance: bool = True):
+        """The rollout's random agent for one step: int8 [B] flat cell (uniform over the empty cells, -1 on a full
+        board) at each game's step counter; ``step(sample(seed), auto_reset=True)`` T times == ``rollout(T, seed)``."""
+        act = torch.empty((self.B,), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_ttt_sample(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, _ptr(self.occ),
+                                           _ptr(self.tcount), int(advance), _ptr(act), _stream()), "crl_ttt_sample")
+        return act
+
     def board(self, player: Optional[torch.Tensor] = None, rel_mod: Optional[int] = None):
         out = torch.empty((self.B, self.n_cells), dtype=torch.int8, device=self.device)
         if player is not None:
@@ -345,6 +365,16 @@ class BlokusBatch:
             check(self._lib.crl_blokus_valid(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(count),
                                              _ptr(mask), _stream()), "crl_blokus_valid")
         return (count, mask) if want_mask else count
+
+    def sample(self, seed: int = 0, advance: bool = True):
+        """The rollout's random agent for one step: int32 [B] dense action id of a uniformly drawn legal action of the
+        player to move (-1 = pass); ``step(sample(seed), auto_reset=True)`` T times == ``rollout(T, seed)``."""
+        act = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_blokus_sample(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id,
+                                              *self._state(), _ptr(self.tcount), int(advance), _ptr(act), _stream()),
+                  "crl_blokus_sample")
+        return act
 
     def observe(self, player: torch.Tensor):
         """state_to_observation for all games; player int8 [B] is the observer of each game."""

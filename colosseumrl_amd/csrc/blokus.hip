@@ -591,6 +591,39 @@ blokus_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const
     }
 }
 
+// the rollout's random agent for one step: the r-th legal action of the player to move, as a dense id
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+blokus_sample_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                     const uint64_t first_env_id, const uint32_t *__restrict__ occ, const uint32_t *__restrict__ inv_g,
+                     const int32_t *__restrict__ score_g, const int32_t *__restrict__ round_g,
+                     const int32_t *__restrict__ to_move_g, uint32_t *__restrict__ tcount, const int advance,
+                     int32_t *__restrict__ action)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    const int pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
+    uint32_t ip = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
+    const uint32_t total = blk_count(T, L, pl, ip, lane);
+    const uint32_t tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)tcount[b]);
+    const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
+    const uint32_t sel = tc & 3u;
+    const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+    int id = -1;
+    if (total > 0) {
+        const BlkMove mv = blk_select(T, L, pl, ip, __umulhi(word, total), lane);
+        id = ((mv.piece * 400 + mv.y * BN + mv.x) * 8 + mv.orient) * 5 + mv.shift;
+    }
+    if (lane == 0) {
+        action[b] = id;
+        if (advance) tcount[b] = tc + 1u;
+    }
+}
+
 __global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
                       const uint64_t first_env_id, const int T_steps, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv_g,
@@ -860,6 +893,19 @@ int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const
     const int64_t n = B * BN * BN;
     hipLaunchKernelGGL(blokus_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        B, occ, inv, score, player, obs_board, obs_pieces, obs_score);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, const uint32_t *occ,
+                      const uint32_t *inv, const int32_t *score, const int32_t *round, const int32_t *to_move,
+                      uint32_t *tcount, int advance, int32_t *action, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_sample");
+    CRL_REQUIRE(occ && inv && score && round && to_move && tcount && action, "crl_blokus_sample: NULL pointer");
+    hipLaunchKernelGGL(blokus_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id,
+                       occ, inv, score, round, to_move, tcount, advance, action);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -1215,6 +1215,32 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
 }
 
+// the rollout's random agent for one step (same digits as TronRng, straight from the contract)
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
+                   uint32_t *__restrict__ tcount, const int advance, int8_t *__restrict__ actions)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t c = tcount[b], g = (uint32_t)(first_env_id + (uint64_t)b), j = c & 7u;
+#pragma unroll
+    for (int q = 0; q < (P + 3) / 4; ++q) {
+        const philox_out r = philox4x32_10(g, c >> 3, (uint32_t)q, CRL_TAG_TRON, seed_lo, seed_hi);
+        uint32_t v = (j >> 1) == 0 ? r.w[0] : (j >> 1) == 1 ? r.w[1] : (j >> 1) == 2 ? r.w[2] : r.w[3];
+        v *= (j & 1u) ? 81u : 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (4 * q + i < P) {
+                const uint32_t a3 = __umulhi(v, 3u);
+                v *= 3u;
+                actions[(int64_t)(4 * q + i) * B + b] = (int8_t)(a3 == 2u ? -1 : (int)a3);
+            }
+        }
+    }
+    if (advance) tcount[b] = c + 1u;
+}
+
 // observation: board relabel is a pure streaming pass, 16 cells per thread
 __global__ void __launch_bounds__(256)
 tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8_t *__restrict__ board,
@@ -1600,6 +1626,19 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
             hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         }
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, uint32_t *tcount, int advance,
+                    int8_t *actions, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_sample");
+    CRL_REQUIRE(tcount && actions, "crl_tron_sample: NULL pointer");
+    TRON_DISPATCH_P(ctx->tron.P, {
+        hipLaunchKernelGGL((tron_sample_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tcount, advance, actions);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

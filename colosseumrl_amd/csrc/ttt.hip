@@ -160,6 +160,25 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     st.len_sum[b] += len_sum;
 }
 
+// the rollout's random agent for one step
+__global__ void __launch_bounds__(256)
+ttt_sample_kernel(const int P, const uint32_t full, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                  const uint64_t first_env_id, const uint32_t *__restrict__ occ, uint32_t *__restrict__ tcount,
+                  const int advance, int8_t *__restrict__ action)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t all = 0;
+    for (int p = 0; p < P; ++p) all |= occ[p * B + b];
+    const uint32_t empty = full & ~all, c = tcount[b];
+    const int n_empty = __popc(empty);
+    const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    const uint32_t sel = c & 3u;
+    const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+    action[b] = (int8_t)(n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1);
+    if (advance) tcount[b] = c + 1u;
+}
+
 __global__ void __launch_bounds__(256)
 ttt_reset_kernel(const int P, const int64_t B, const uint8_t *__restrict__ mask, uint32_t *__restrict__ occ,
                  int8_t *__restrict__ winner, int8_t *__restrict__ to_move)
@@ -341,6 +360,18 @@ int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8
     CRL_REQUIRE(player == nullptr || rel_mod >= 1, "crl_ttt_board: rel_mod must be >= 1 when player is given");
     hipLaunchKernelGGL(ttt_board_kernel, dim3(blocks_for(B * ctx->ttt.n_cells, 256)), dim3(256), 0, (hipStream_t)stream,
                        ctx->ttt.P, ctx->ttt.n_cells, B, occ, player, rel_mod, board);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, const uint32_t *occ,
+                   uint32_t *tcount, int advance, int8_t *action, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_sample");
+    CRL_REQUIRE(occ && tcount && action, "crl_ttt_sample: NULL pointer");
+    const ttt_dirs dd = dirs_of(ctx);
+    hipLaunchKernelGGL(ttt_sample_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, ctx->ttt.P, dd.full, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, occ, tcount, advance, action);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

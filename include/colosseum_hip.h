@@ -119,6 +119,13 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                      crl_tron_stats stats, uint32_t flags, void *stream);
 
+/* The random agent of crl_tron_rollout as a stand-alone call: actions[p*B+b] (0 forward, +1 right, -1 left, the
+ * crl_tron_step encoding) of step tcount[b] of env first_env_id + b under the RNG contract above; advance != 0 also
+ * increments tcount.  T x (crl_tron_sample; crl_tron_step with CRL_STEP_AUTO_RESET) leaves the same state as
+ * crl_tron_rollout(T); callers overwrite the rows of the players they control.  No reference counterpart. */
+int crl_tron_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, uint32_t *tcount, int advance,
+                    int8_t *actions, void *stream);
+
 /* replaces CyTronGrid.relative_player_inplace (CyTronGrid.pyx:65-71) + the rolls of
  * TronGridEnvironment.state_to_observation (TronGridEnvironment.py:385-405), fully observable branch.
  * player int8 [B]: observer of env b.  Outputs have the shapes of the state arrays. */
@@ -185,6 +192,12 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 #define CRL_BLOKUS_ACTION_IDS 336000
 #define CRL_BLOKUS_MASK_WORDS 10500
 int crl_blokus_create(crl_ctx **out);
+/* The random agent of crl_ttt_rollout as a stand-alone call: action[b] = the r-th empty cell (flat index, row-major
+ * np.where order) with r = mulhi32(Philox(...)[tcount & 3], number of empty cells), -1 on a full board; advance != 0
+ * also increments tcount.  T x (crl_ttt_sample; crl_ttt_step with CRL_STEP_AUTO_RESET) == crl_ttt_rollout(T). */
+int crl_ttt_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, const uint32_t *occ,
+                   uint32_t *tcount, int advance, int8_t *action, void *stream);
+
 /* DIAGNOSTIC: per-phase shader-cycle sums of crl_blokus_rollout (prep, count, rng, select, apply, exists, rest, -).
  * Returns 1 and the sums only in a library built with -DBLK_STAMPS, else 0 and zeros (the shipped build). */
 int crl_blokus_stamps(uint64_t *out8, int reset);
@@ -223,6 +236,14 @@ typedef struct {
 int crl_blokus_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                        uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
                        crl_blokus_stats stats, void *stream);
+
+/* The random agent of crl_blokus_rollout as a stand-alone call: action[b] = dense id of the r-th legal action of the
+ * player to move, in reference order, r = mulhi32(Philox(...)[tcount & 3], number of legal actions); -1 (pass, '')
+ * when there is none; advance != 0 also increments tcount.
+ * T x (crl_blokus_sample; crl_blokus_step with CRL_STEP_AUTO_RESET) == crl_blokus_rollout(T). */
+int crl_blokus_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, const uint32_t *occ,
+                      const uint32_t *inventory, const int32_t *score, const int32_t *round, const int32_t *to_move,
+                      uint32_t *tcount, int advance, int32_t *action, void *stream);
 
 #ifdef __cplusplus
 }

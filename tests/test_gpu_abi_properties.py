@@ -87,3 +87,28 @@ def test_error_reporting_never_throws_across_the_abi():
     assert lib.crl_tron_step(ctx, 4, None, None, None, None, None, None, None, None, 0, None) == -1   # wrong context kind
     assert b"tron" in lib.crl_last_error()
     lib.crl_destroy(ctx)
+
+
+@pytest.mark.parametrize("game", ["tron", "ttt", "blokus"])
+def test_sample_then_step_equals_rollout(game):
+    """SURVEY 8(b) batched surface: `sample()` is the fused rollout's random agent for one step, so
+    T x (sample; step with auto-reset) must leave exactly the state (and step counters) of rollout(T)."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch, TTTBatch, BlokusBatch
+    seed, first = 0xABCDEF0123, 777
+    if game == "tron":
+        mk, T, keys = (lambda: TronBatch(20, 5, 1000, first_env_id=first)), 60, ("board", "heads", "dirs", "deaths", "tcount")
+    elif game == "ttt":
+        mk, T, keys = (lambda: TTTBatch((3, 5), 3, 3, 2000, first_env_id=first)), 50, ("occ", "winner", "to_move", "tcount")
+    else:
+        mk, T, keys = (lambda: BlokusBatch(64, first_env_id=first)), 150, ("occ", "inv", "score", "round", "to_move", "tcount")
+    a, b = mk(), mk()
+    a.rollout(T, seed)
+    for _ in range(T):
+        b.step(b.sample(seed), auto_reset=True)
+    for k in keys:
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    # a sample without advance is repeatable and does not move the counter
+    before = b.tcount.clone()
+    s1, s2 = b.sample(seed, advance=False), b.sample(seed, advance=False)
+    assert torch.equal(s1, s2) and torch.equal(before, b.tcount)
