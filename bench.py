@@ -31,7 +31,7 @@ VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 VAL
 
 WORKLOADS = {
     # name: (game, kwargs, per-GPU batch[, env-steps fused into one launch when --chunk is not given (default 2048)])
-    "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536),
+    "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536, 8192),   # ~20 us per launch of copies
     "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192),   # longer launches: replay epilogue
     "ttt_p3_5x5_k4_b262144": ("ttt", dict(dims=(5, 5), k=4, num_players=3), 262144),
     "ttt_p3_3x5_k3_b262144": ("ttt", dict(dims=(3, 5), k=3, num_players=3), 262144),
