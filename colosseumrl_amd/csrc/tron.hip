@@ -653,7 +653,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
     const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;   // LDS address of the dynamic part
     const int mine = lds0 + (int)threadIdx.x * pad.stride;      // this lane's slab
-    const bool wide = (N & 3) == 0;                             // rows are whole dwords in HBM too
+    const bool wide = (N & 3) == 0 && N >= 8;                  // rows are whole dwords in HBM too (4x4: inv_nq would overflow)
     constexpr int OB = (P <= 7) ? 3 : 4;                        // owner bits; 8 - OB tag bits
     constexpr uint32_t kTags = (1u << (8 - OB)) - 1u;           // the all-ones tag is never used: 0xff stays "wall"
     // a fresh row: cells 0, walls 0xff (kept in registers for the rolling rewrite)
@@ -884,7 +884,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const int n_env = (int)((B - env0) < CRL_WAVE ? (B - env0 > 0 ? B - env0 : 0) : CRL_WAVE);
     const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
     const int mine = lds0 + (int)threadIdx.x * bits.stride;     // this lane's bit slab
-    const bool wide = (N & 3) == 0;
+    const bool wide = (N & 3) == 0 && N >= 8;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
 
     // the empty board (walls only), one word per thread, shared through LDS ...

@@ -88,7 +88,8 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
 @pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
                                            (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,)),
                                            (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,)),
-                                           (20, 4, 1000, (300, 2, 260)), (40, 4, 700, (1, 1, 290)), (37, 7, 130, (280,))])
+                                           (20, 4, 1000, (300, 2, 260)), (40, 4, 700, (1, 1, 290)), (37, 7, 130, (280,)),
+                                           (4, 2, 200, (50,)), (4, 4, 70, (20,)), (4, 3, 130, (30,)), (5, 4, 100, (40,))])
 def test_rollout_vs_oracle(N, P, B, chunks, kernel):
     """Fused random-agent rollout == oracle rollout, bit for bit, for the three kernels behind crl_tron_rollout (LDS
     bitboard with replay epilogue, LDS byte slabs, global memory) and the library's own choice: ragged batches, odd
