@@ -122,11 +122,13 @@ class BlokusEnvironment(BaseEnvironment):
 
     @staticmethod
     def serialize_state(state: object) -> bytearray:
-        return dill.dumps(state)
+        from ... import compat                         # reference class paths when compat.reference_wire_format() is on
+        return compat.dumps_blokus_state(state)
 
     @staticmethod
     def deserialize_state(serialized_state: bytearray) -> State:
-        return dill.loads(serialized_state)
+        from ... import compat
+        return compat.loads_blokus_state(serialized_state)
 
     def current_rewards(self, state: object) -> List[float]:
         return [p.player_score for p in state[2]]

@@ -79,3 +79,25 @@ def test_blokus_oracle_vs_reference_short(R):
             r, tm, wm = O.blokus_step(st, np.array([a], np.int32))
             assert np.array_equal(st.board[0], s[0].board_contents) and st.score[0].tolist() == [p.player_score for p in s[2]]
             assert r[0] == rew[0] and bool(tm[0]) == bool(term) and st.to_move[0] == pl[0] and st.round[0] == s[1]
+
+
+def test_blokus_wire_format_with_the_real_reference(R):
+    """with compat.reference_wire_format() on, the drop-in's state pickles load as the reference's
+    own Board / AI objects (and are playable by the reference env), and the reference's pickles load in the drop-in."""
+    from colosseumrl_amd import compat
+    from colosseumrl_amd.envs.blokus.BlokusEnvironment import BlokusEnvironment as Mine
+    from colosseumrl_amd.envs.blokus.board import Board as MyBoard
+    ref_env = R["blokus"]()
+    s, pl = ref_env.new_state()
+    for a in ("monomino1;(0, 0);north0", "domino1;(19, 0);south0"):
+        s, pl, *_ = ref_env.next_state(s, pl, [a])
+    try:
+        assert compat.reference_wire_format(True) is True            # the real classes are importable here
+        mine = Mine.deserialize_state(ref_env.serialize_state(s))    # reference -> drop-in
+        assert isinstance(mine[0], MyBoard) and np.array_equal(mine[0].board_contents, s[0].board_contents)
+        assert mine[1] == s[1] and [p.current_pieces for p in mine[2]] == [p.current_pieces for p in s[2]]
+        back = ref_env.deserialize_state(Mine.serialize_state(mine))  # drop-in -> reference
+        assert type(back[0]) is R["blokus_board"].Board and type(back[2][0]) is R["blokus_ai"].AI
+        assert ref_env.valid_actions(back, pl[0]) == ref_env.valid_actions(s, pl[0])
+    finally:
+        compat.reference_wire_format(False)
