@@ -24,23 +24,29 @@ struct ttt_dirs {
     uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
 };
 
-// Fully unrolled over the 13 possible directions: strides and start masks are then plain SGPR operands loaded
-// once per kernel instead of one scalar load per direction per step (2-D boards use 4 of them, 3-D boards 13).
+// ND = 4 (boards with at most 4 line directions: everything 1-D / 2-D) or 13 (3-D).  The K-1 shift-and rounds are
+// the outer, wave-uniform loop and the directions the unrolled inner one: strides and start masks are plain SGPR
+// operands, a round is 2 VALU per direction, and no direction needs its own branch (unused slots have start == 0).
+template <int ND>
 __device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t m)
 {
-    uint32_t hit = 0;
+    uint32_t t[ND], run[ND];
 #pragma unroll
-    for (int d = 0; d < 13; ++d) {
-        if (d < dd.n_dirs) {                       // wave-uniform: a scalar branch skips the unused directions
-            uint32_t run = m;
-            for (int s = 1; s < dd.K; ++s) run &= m >> (s * dd.stride[d]);
-            hit |= run & dd.start[d];
+    for (int d = 0; d < ND; ++d) t[d] = run[d] = m;
+    for (int s = 1; s < dd.K; ++s) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            t[d] >>= dd.stride[d];                  // cell c + s * stride of direction d, seen from c
+            run[d] &= t[d];
         }
     }
+    uint32_t hit = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) hit |= run[d] & dd.start[d];
     return hit != 0;
 }
 
-template <int P>
+template <int P, int ND>
 __device__ __forceinline__ void ttt_step_core(const ttt_dirs &dd, uint32_t (&o)[P], int &winner, int &to_move,
                                               const int action, int &reward, int &term, int &winners)
 {
@@ -57,7 +63,7 @@ __device__ __forceinline__ void ttt_step_core(const ttt_dirs &dd, uint32_t (&o)[
         all |= bit;
 #pragma unroll
         for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];
-        if (ttt_has_line(dd, mine)) winner = pl;       // :296-300
+        if (ttt_has_line<ND>(dd, mine)) winner = pl;   // :296-300
     }
     reward = 0; term = 0; winners = -1;
     if (winner >= 0) {                                 // :302-308
@@ -81,7 +87,7 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, int r)
     return pos;
 }
 
-template <int P>
+template <int P, int ND>
 __global__ void __launch_bounds__(256)
 ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, int8_t *__restrict__ winner,
                 int8_t *__restrict__ to_move, const int8_t *__restrict__ action, int8_t *__restrict__ reward,
@@ -93,7 +99,7 @@ ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, 
 #pragma unroll
     for (int p = 0; p < P; ++p) o[p] = occ[p * B + b];
     int w = winner[b], tm = to_move[b], r, t, ws;
-    ttt_step_core<P>(dd, o, w, tm, action[b], r, t, ws);
+    ttt_step_core<P, ND>(dd, o, w, tm, action[b], r, t, ws);
     reward[b] = (int8_t)r;
     terminal[b] = (uint8_t)t;
     winners[b] = (int8_t)ws;
@@ -108,7 +114,7 @@ ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, 
     to_move[b] = (int8_t)tm;
 }
 
-template <int P>
+template <int P, int ND>
 __global__ void __launch_bounds__(256)
 ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
                    const uint64_t first_env_id, const int T, uint32_t *__restrict__ occ,
@@ -138,7 +144,7 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         tc += 1;
         if ((tc & 3u) == 0) rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
         int r, term, ws;
-        ttt_step_core<P>(dd, o, w, tm, action, r, term, ws);
+        ttt_step_core<P, ND>(dd, o, w, tm, action, r, term, ws);
         ts += 1;
         if (term) {
             n_ep += 1;
@@ -337,8 +343,12 @@ int crl_ttt_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, int8_t *winner, i
     CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_ttt_step: unknown flags 0x%x", flags);
     const ttt_dirs dd = dirs_of(ctx);
     TTT_DISPATCH_P(ctx->ttt.P, {
-        hipLaunchKernelGGL((ttt_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                           occ, winner, to_move, action, reward, terminal, winners, flags);
+        if (dd.n_dirs <= 4)
+            hipLaunchKernelGGL((ttt_step_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               occ, winner, to_move, action, reward, terminal, winners, flags);
+        else
+            hipLaunchKernelGGL((ttt_step_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               occ, winner, to_move, action, reward, terminal, winners, flags);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
@@ -386,8 +396,12 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
     if (T == 0) return CRL_OK;
     const ttt_dirs dd = dirs_of(ctx);
     TTT_DISPATCH_P(ctx->ttt.P, {
-        hipLaunchKernelGGL((ttt_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
+        if (dd.n_dirs <= 4)
+            hipLaunchKernelGGL((ttt_rollout_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
+        else
+            hipLaunchKernelGGL((ttt_rollout_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
