@@ -16,8 +16,8 @@ dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, prefix + "_rocprofv3_summary.txt"))
 shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, prefix + "_rocprofv3_summary.json"))
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, prefix + "_kernel_stats.csv"))
+if stats:                                       # gpurun merges runs into the same directory: take the newest
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, prefix + "_kernel_stats.csv"))
 if len(sys.argv) > 3:
     workload, kern, spl = sys.argv[3], sys.argv[4], int(sys.argv[5])
     summ = json.load(open(os.path.join(src, "summary.json")))
