@@ -124,14 +124,14 @@ def test_rollout_after_scripted_steps(kernel):
             assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), (k, T)
 
 
-@pytest.mark.parametrize("N", [20, 40])
-def test_rollout_full_size_properties(N):
-    """BASELINE config 2 (N=20, LDS kernel) and config 5 per-GPU shard (N=40, global-memory kernel), B=65536, P=4:
-    size-independent properties of the fused rollout.
+@pytest.mark.parametrize("N,T", [(20, 128), (40, 128), (40, 300)])
+def test_rollout_full_size_properties(N, T):
+    """BASELINE config 2 (N=20, LDS byte slabs) and config 5 per-GPU shard (N=40: byte slabs at T=128, bitboards +
+    replay at T=300), B=65536, P=4: size-independent properties of the fused rollout.
     sum(len_sum)+sum(tstep) == B*T; wins <= episodes; board consistent with heads; shard invariance."""
     import torch
     from colosseumrl_amd.batched import TronBatch
-    B, T, seed = 65536, 128, 7
+    B, seed = 65536, 7
     tb = TronBatch(N, 4, B)
     tb.rollout(T, seed)
     n_ep = tb.n_episodes.cpu().numpy().astype(np.int64)
