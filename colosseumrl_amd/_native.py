@@ -69,6 +69,7 @@ PROTOTYPES = {
     "crl_tron_observe_all": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_ranking": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "crl_tron_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _I, _VP, _VP]),
+    "crl_tron_check_state": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),
     "crl_ttt_lines": (_I, [_VP, _VP, _I]),
     "crl_ttt_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),

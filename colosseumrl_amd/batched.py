@@ -138,6 +138,16 @@ class TronBatch:
                                              self._stats(), flags, _stream()),
                   "crl_tron_rollout")
 
+    def check_state(self) -> int:
+        """Number of games whose state breaks the invariant of every reset / step / rollout product that the LDS
+        rollout kernels rely on (heads on the board, ``board[heads[p]] == p + 1``); 0 unless states were hand-made.
+        Synchronises."""
+        bad = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self._lib.crl_tron_check_state(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.heads), _ptr(bad),
+                                                 _stream()), "crl_tron_check_state")
+        return int(bad.item())
+
     # -- the rollout's random agent for one step: int8 [P][B] actions in the step() encoding
     def sample(self, seed: int = 0, advance: bool = True):
         """Actions the fused rollout would take at each game's step counter (``tcount``); with ``advance`` the counter

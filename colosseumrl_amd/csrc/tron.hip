@@ -1215,6 +1215,21 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
 }
 
+// state sanity for hand-made states: heads inside the board and on their owner's cell
+__global__ void __launch_bounds__(256)
+tron_check_state_kernel(const int P, const int NN, const int64_t B, const int8_t *__restrict__ board,
+                        const int16_t *__restrict__ heads, int32_t *__restrict__ n_bad)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    bool bad = false;
+    for (int p = 0; p < P; ++p) {
+        const int h = heads[p * B + b];
+        bad |= h < 0 || h >= NN || board[b * NN + (h < 0 || h >= NN ? 0 : h)] != p + 1;
+    }
+    if (bad) atomicAdd(n_bad, 1);
+}
+
 // the rollout's random agent for one step (same digits as TronRng, straight from the contract)
 template <int P>
 __global__ void __launch_bounds__(256)
@@ -1627,6 +1642,17 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         }
     });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_check_state(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, int32_t *n_bad,
+                         void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_check_state");
+    CRL_REQUIRE(board && heads && n_bad, "crl_tron_check_state: NULL pointer");
+    hipLaunchKernelGGL(tron_check_state_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, ctx->tron.P,
+                       ctx->tron.N * ctx->tron.N, B, board, heads, n_bad);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -119,6 +119,12 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                      crl_tron_stats stats, uint32_t flags, void *stream);
 
+/* Counts (adds to *n_bad, a device int32 the caller zeroes) the games whose state breaks what every state produced by
+ * crl_tron_reset / _step / _rollout satisfies and the LDS rollout kernels rely on: every head inside the board and
+ * board[heads[p]] == p + 1.  For callers that upload hand-made states before a rollout.  No reference counterpart. */
+int crl_tron_check_state(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, int32_t *n_bad,
+                         void *stream);
+
 /* The random agent of crl_tron_rollout as a stand-alone call: actions[p*B+b] (0 forward, +1 right, -1 left, the
  * crl_tron_step encoding) of step tcount[b] of env first_env_id + b under the RNG contract above; advance != 0 also
  * increments tcount.  T x (crl_tron_sample; crl_tron_step with CRL_STEP_AUTO_RESET) leaves the same state as

@@ -112,3 +112,19 @@ def test_sample_then_step_equals_rollout(game):
     before = b.tcount.clone()
     s1, s2 = b.sample(seed, advance=False), b.sample(seed, advance=False)
     assert torch.equal(s1, s2) and torch.equal(before, b.tcount)
+
+
+def test_tron_check_state():
+    """The invariant the LDS rollout kernels rely on holds after reset / step / rollout and is reported when broken."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    tb = TronBatch(20, 4, 3000)
+    assert tb.check_state() == 0
+    tb.rollout(300, 5)
+    for _ in range(5):
+        tb.step(tb.sample(5), auto_reset=True)
+    assert tb.check_state() == 0
+    tb.board[7, int(tb.heads[2, 7])] = 1          # player 2's head cell now claims to be player 0's
+    tb.heads[1, 11] = 399
+    tb.board[11, 399] = 0
+    assert tb.check_state() == 2
