@@ -123,7 +123,7 @@ def cpu_baseline(game, kw, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16384)
+    ap.add_argument("--steps", type=int, default=65536)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="tron_p4_n20_b65536", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
