@@ -1256,11 +1256,25 @@ tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_
     if (advance) tcount[b] = c + 1u;
 }
 
-// observation: board relabel is a pure streaming pass, 16 cells per thread
+// observation: board relabel is a pure streaming pass, 16 cells per thread.  For P <= 7 the relabelling of observer pl is
+// an 8-entry byte table (cell value -> relative id); the P tables sit in LDS, a thread fetches its game's table (one
+// ds_read_b64) and relabels 4 cells per v_perm_b32, the board bytes being the selector.
 __global__ void __launch_bounds__(256)
 tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8_t *__restrict__ board,
                           const int8_t *__restrict__ player, int8_t *__restrict__ obs)
 {
+    __shared__ uint2 lut[CRL_TRON_MAX_P];
+    if (threadIdx.x < (unsigned)P) {
+        uint32_t lo = 0, hi = 0;
+        for (int v = 1; v < 8; ++v) {
+            int n = v - ((int)threadIdx.x + 1);                            // CyTronGrid.pyx:70-71
+            n = n < 0 ? n + P : n;
+            const uint32_t r = (v <= P) ? (uint32_t)(n + 1) : (uint32_t)v;
+            if (v < 4) lo |= r << (8 * v); else hi |= r << (8 * (v - 4));
+        }
+        lut[threadIdx.x] = make_uint2(lo, hi);
+    }
+    __syncthreads();
     const int64_t total = B * (int64_t)NN;
     const bool wide = (NN & 15) == 0;
     const int64_t n_items = wide ? total / 16 : total;
@@ -1270,17 +1284,23 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
             const int pl = player[off / NN] + 1;
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
             uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
+            if (P <= 7) {
+                const uint2 t = lut[pl - 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t r = 0;
+                for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(t.y, t.x, w[q]);
+            } else {
 #pragma unroll
-                for (int s8 = 0; s8 < 32; s8 += 8) {
-                    const int c = (int)((w[q] >> s8) & 0xffu);
-                    int n = c - pl;                                        // CyTronGrid.pyx:70-71, c in 1..P
-                    n = n < 0 ? n + P : n;
-                    r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int s8 = 0; s8 < 32; s8 += 8) {
+                        const int c = (int)((w[q] >> s8) & 0xffu);
+                        int n = c - pl;                                        // CyTronGrid.pyx:70-71, c in 1..P
+                        n = n < 0 ? n + P : n;
+                        r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+                    }
+                    o[q] = r;
                 }
-                o[q] = r;
             }
             *reinterpret_cast<uint4 *>(obs + off) = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
