@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/sec of the batched random-agent rollout (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the batched random-agent rollout (BASELINE.json metric) + the evidence around it.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one env-step of EVERY game of the batch (Tron: all live players move).  The default
-workload is BASELINE.json configs[1]: 4-player 20x20 Tron, 65,536 games per GPU, uniform random
-agent drawn from the counter-based RNG, auto-reset on terminal.  State is resident in HBM before the
-timed region; the timed region is W untimed + exactly K timed steps, issued as fused launches of
---chunk steps, bracketed by barrier + synchronize; the time is the max over ranks.  With N > 1 each
-rank owns the games [rank*B, (rank+1)*B) (weak scaling, no data-path collective) and the per-game
-results are gathered once with a single RCCL all_gather at the end (inside the timed region);
-the sharding / gather code is colosseumrl_amd.parallel.ShardedRollout (gloo-tested on CPU).
+HEADLINE (the contract line).  One "step" = one env-step of EVERY game of the batch (Tron: all live players move).
+The workload is BASELINE.json configs[1]: 4-player 20x20 Tron, 65,536 games per GPU, uniform random agent drawn from
+the counter-based RNG, auto-reset on terminal.  State is resident in HBM before the timed region; the timed region is W
+untimed + exactly K timed steps, issued as fused launches of min(--chunk, remaining) steps, bracketed by barrier +
+synchronize; the time is the max over ranks.  With N > 1 each rank owns the games [rank*B, (rank+1)*B) (weak scaling,
+no data-path collective) and the per-game result rows (written by the rollout kernel itself) are gathered once with a
+single RCCL all_gather at the end, inside the timed region (colosseumrl_amd.parallel.ShardedRollout; the collective also
+runs in a world of one rank when a process group exists, e.g. under `torchrun --nproc-per-node 1`).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --only-headline):
+  roofline      measured HBM bytes per launch (rocprofv3 PMC of the SAME launch shape, profiles/traffic_*.json; a
+                documented per-launch traffic model when no PMC pass exists for the shape) / launch time vs the 8 TB/s
+                spec and vs the device-copy bandwidth measured in this run; `algorithmic` = SURVEY 8(d)'s per-step bytes
+                x env-steps per launch / launch time (what a step-at-a-time stepper would have to move -- the fused
+                kernels keep state in LDS, so this exceeds the physical traffic on long launches); `valu_issue` = PMC
+                SQ_INSTS_VALU of that launch shape / launch time against the MEASURED issue peak
+                (tools/ubench/valu_rate.hip -> profiles/r2_valu_issue_calibration.json)
+  steady_state  the same workload in long launches (the regime a rollout worker lives in)
+  seeds         the headline region repeated for seeds {0, 1, 2}
+  others        the other BASELINE workloads (TicTacToe 5x5 / 3x5 / 3x3x3, Blokus, the Tron 40x40 shard of config 5)
+  step_api      the per-step batched API: sample / step(auto_reset) / observe_all / fused step+observe, TicTacToe and
+                Blokus step / valid / observe -- what replaces next_state + state_to_observation in a learner loop
+  cpu_baseline  the C oracle on this box's host cores: one thread and all threads, nproc stated, plus the reference's
+                own Python+Cython path as timed in the build container (it cannot run here)
 """
 import argparse
 import json
@@ -26,17 +40,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec (6.29 TB/s measured float4 copy)
+# fallback issue peak when no calibration file is present: one wave64 VALU instruction per 2 cycles per SIMD-32
+# (MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc"), 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PEAK_MODEL = 256 * 4 * 2.4e9 / 2
+CALIBRATION = os.path.join(ROOT, "profiles", "r2_valu_issue_calibration.json")
 
 WORKLOADS = {
-    # name: (game, kwargs, per-GPU batch[, env-steps fused into one launch when --chunk is not given (default 2048)])
-    "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536, 8192),   # ~20 us per launch of copies
-    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192),   # longer launches: replay epilogue
-    "ttt_p3_5x5_k4_b262144": ("ttt", dict(dims=(5, 5), k=4, num_players=3), 262144),
-    "ttt_p3_3x5_k3_b262144": ("ttt", dict(dims=(3, 5), k=3, num_players=3), 262144),
-    "ttt_p4_3x3x3_b262144": ("ttt", dict(dims=(3, 3, 3), k=3, num_players=4), 262144),
-    "blokus_p4_b16384": ("blokus", dict(), 16384),
+    # name: (game, kwargs, per-GPU batch, env-steps fused into one launch by default, resident waves per SIMD)
+    "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536, 8192, 1),
+    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192, 1),
+    "ttt_p3_5x5_k4_b262144": ("ttt", dict(dims=(5, 5), k=4, num_players=3), 262144, 2048, 4),
+    "ttt_p3_3x5_k3_b262144": ("ttt", dict(dims=(3, 5), k=3, num_players=3), 262144, 2048, 4),
+    "ttt_p4_3x3x3_b262144": ("ttt", dict(dims=(3, 3, 3), k=3, num_players=4), 262144, 2048, 4),
+    "blokus_p4_b16384": ("blokus", dict(), 16384, 2048, 8),
+}
+HEADLINE = "tron_p4_n20_b65536"
+# the reference's own CPU path (Python + Cython / scipy), one core, timed in the build container with the reference
+# imported from /root/reference; it cannot travel to the GPU box
+REFERENCE_PYTHON = {
+    "tron_p4_n20_b65536": 4.4e4, "tron_p4_n40_b65536": 4.3e4, "ttt_p3_3x5_k3_b262144": 2.4e4,
+    "ttt_p4_3x3x3_b262144": 2.0e3, "blokus_p4_b16384": 1.9,
 }
 
 
@@ -55,11 +79,29 @@ def algorithmic_bytes_per_step(game, kw, mean_len):
     raise ValueError(game)
 
 
-def kernel_name(game, kw):
+def launch_traffic_model(game, kw):
+    """HBM bytes per game one fused rollout LAUNCH has to move (state in + out once, statistics read-modify-write,
+    the packed result row), whatever the number of steps: the state lives in LDS / registers in between."""
+    if game == "tron":
+        P, N = kw["num_players"], kw["board_size"]
+        state = N * N + 4 * P
+        stats = 2 * (4 + 4 + 4 + 4 + 4 * P + 4 * P) + 3 + 4 * (3 + 2 * P)
+        return 2 * state + stats
+    if game == "ttt":
+        P = kw["num_players"]
+        return 2 * (4 * P + 2) + 2 * (4 * 4 + 4 * P + 4) + 4 * (3 + P)
+    if game == "blokus":
+        return 2 * 360 + 2 * 8 + 4 * 10
+    raise ValueError(game)
+
+
+def kernel_name(game, kw, steps_per_launch):
     """The dominant kernel of the workload (what the rocprof summaries under profiles/ list)."""
     if game == "tron":
         n = kw["board_size"]                                     # csrc/tron.hip, crl_tron_rollout's choice
-        return "tron_rollout_lds_kernel" if n <= 20 else "tron_rollout_bits_kernel" if n <= 40 else "tron_rollout_kernel"
+        if n <= 20:
+            return "tron_rollout_lds_kernel"
+        return ("tron_rollout_bits_kernel" if steps_per_launch >= 256 else "tron_rollout_lds_kernel") if n <= 40 else "tron_rollout_kernel"
     return "%s_rollout_kernel" % game
 
 
@@ -74,50 +116,287 @@ def make_stepper(game, kw, batch, device, first_env_id):
     raise ValueError(game)
 
 
-def cpu_baseline(game, kw, seconds=12.0):
-    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample."""
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=True):
+    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample:
+    all threads (`value`) and one thread, with the visible core count; plus the reference's own Python figure."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, int(os.environ.get("CRL_CPU_THREADS", "16"))))    # a 1-GPU box's CPU share is 16 cores
-    if game == "tron":
-        N, P = kw["board_size"], kw["num_players"]
-        sh, sd = O.tron_start_positions(N, P)
-        B = 65536
+    game, kw = WORKLOADS[workload][:2]
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads_all = max(1, min(nproc, int(os.environ.get("CRL_CPU_THREADS", "16"))))    # a 1-GPU box's CPU share is 16 cores
+    extra = {}
 
-        def run(T):
-            st = O.TronState(N, P, B)
-            O.tron_reset(st, sh, sd)
-            t0 = time.perf_counter()
-            O.tron_rollout(st, 1, 0, T, sh, sd, n_threads=cores)
-            return time.perf_counter() - t0
-    elif game == "ttt":
-        B = 65536
+    def runner(B, cores):
+        if game == "tron":
+            N, P = kw["board_size"], kw["num_players"]
+            sh, sd = O.tron_start_positions(N, P)
 
-        def run(T):
-            st = O.TTTState(kw["dims"], kw["k"], kw["num_players"], B)
-            t0 = time.perf_counter()
-            O.ttt_rollout(st, 1, 0, T, n_threads=cores)
-            return time.perf_counter() - t0
-    elif game == "blokus":
-        B = 64 * cores
+            def run(T):
+                st = O.TronState(N, P, B)
+                O.tron_reset(st, sh, sd)
+                t0 = time.perf_counter()
+                O.tron_rollout(st, 1, 0, T, sh, sd, n_threads=cores)
+                return time.perf_counter() - t0
+        elif game == "ttt":
+            def run(T):
+                st = O.TTTState(kw["dims"], kw["k"], kw["num_players"], B)
+                t0 = time.perf_counter()
+                O.ttt_rollout(st, 1, 0, T, n_threads=cores)
+                return time.perf_counter() - t0
+        else:
+            def run(T):
+                st = O.BlokusState(B)
+                O.blokus_placement_tests(reset=True)
+                t0 = time.perf_counter()
+                O.blokus_rollout(st, 1, 0, T, n_threads=cores)
+                dt = time.perf_counter() - t0
+                extra["placement_tests_per_env_step"] = O.blokus_placement_tests() / float(B * T)
+                return dt
+        return run
 
-        def run(T):
-            st = O.BlokusState(B)
-            t0 = time.perf_counter()
-            O.blokus_rollout(st, 1, 0, T, n_threads=cores)
-            return time.perf_counter() - t0
-    else:
-        raise ValueError(game)
-    T = 4
-    dt = run(T)                       # warms the thread pool
-    while dt < 0.5 and T < (1 << 18):  # calibrate on a run long enough to be meaningful
-        T *= 4
+    def timed(cores, seconds):
+        B = (64 * cores) if game == "blokus" else (65536 if cores > 1 else 8192)
+        run = runner(B, cores)
+        T = 4
+        dt = run(T)                                # warms the thread pool
+        while dt < 0.3 and T < (1 << 18):           # calibrate on a run long enough to be meaningful
+            T *= 4
+            dt = run(T)
+        rate = B * T / max(dt, 1e-9)
+        T = int(max(4, min(1 << 20, rate * seconds / B)))
         dt = run(T)
-    rate = B * T / max(dt, 1e-9)
-    T = int(max(4, min(1 << 20, rate * seconds / B)))
-    dt = run(T)
-    return {"value": B * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %.1f s" % (B, T, dt)}
+        return {"value": B * T / dt, "threads": cores,
+                "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %.1f s" % (B, T, dt)}
+
+    allt = timed(threads_all, seconds_all)
+    out = {"value": allt["value"], "unit": "env-steps/s", "cores": threads_all, "kind": "port", "sample": allt["sample"],
+           "nproc": nproc, "threads_all": allt}
+    if with_one_thread:
+        out["threads_1"] = timed(1, seconds_one)
+    if workload in REFERENCE_PYTHON:
+        out["reference_python"] = {"value": REFERENCE_PYTHON[workload], "unit": "env-steps/s", "cores": 1,
+                                   "where": "build container (the Python reference cannot travel to the GPU box)",
+                                   "source": "SURVEY.md section 6: the reference envs imported from /root/reference, random agent incl. new_state resets"
+                                             + ("; numba absent, so un-jitted" if game == "blokus" else "")}
+    out.update(extra)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- roofline
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def pmc_for(workload, steps_per_launch):
+    """PMC record of this workload's dominant kernel for EXACTLY this launch shape, or None."""
+    tj = _load_json(os.path.join(ROOT, "profiles", "traffic_%s.json" % workload))
+    if not tj:
+        return None
+    shapes = tj.get("launch_shapes")
+    if shapes is None:                                   # round-1 file format: one shape per file
+        shapes = {str(tj.get("steps_per_launch")): tj}
+    return shapes.get(str(int(steps_per_launch)))
+
+
+def valu_peaks(waves_per_simd):
+    """(chip VALU issue peak, peak at this occupancy, source) in wave64 instructions / s from the calibration ubench."""
+    cal = _load_json(CALIBRATION)
+    if not cal:
+        return VALU_PEAK_MODEL, None, "model: 1 wave64 VALU / 2 cycles / SIMD at 2.4 GHz (no calibration file)"
+    rows = {int(r["waves_per_simd"]): r for r in cal["mixes"]["valu"]}
+    peak = max(r["valu_wave_insts_per_s"] for r in rows.values())
+    w = max(k for k in rows if k <= max(1, waves_per_simd))
+    return peak, rows[w]["valu_wave_insts_per_s"], "measured: profiles/r2_valu_issue_calibration.json (tools/ubench/valu_rate.hip)"
+
+
+def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs):
+    game, kw = WORKLOADS[workload][:2]
+    wps = WORKLOADS[workload][4]
+    alg_bps = algorithmic_bytes_per_step(game, kw, mean_len)
+    alg_gbs = alg_bps * batch * steps_per_launch / launch_s / 1e9
+    pmc = pmc_for(workload, steps_per_launch)
+    if pmc and pmc.get("hbm_bytes_per_launch"):
+        traffic, source = int(pmc["hbm_bytes_per_launch"]) * batch // int(pmc.get("games", batch)), "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), same launch shape: profiles/traffic_%s.json" % workload
+    else:
+        traffic, source = int(launch_traffic_model(game, kw) * batch), "model: state in + out once per launch + statistics (no PMC pass for %d-step launches)" % steps_per_launch
+    achieved = traffic / launch_s / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": source, "kernel": kernel_name(game, kw, steps_per_launch),
+         "steps_per_launch": int(steps_per_launch), "launch_ms": launch_s * 1e3,
+         "algorithmic": {"bytes_per_env_step": round(alg_bps, 2), "achieved": alg_gbs, "frac": alg_gbs / HBM_PEAK_GBS,
+                         "note": "SURVEY 8(d) bytes of a step-at-a-time stepper x env-steps per launch / launch time; the fused "
+                                 "kernel keeps state in LDS/registers across the launch, so this is not physical traffic"}}
+    if copy_gbs:
+        r["copy_peak"] = copy_gbs
+        r["frac_of_copy"] = achieved / copy_gbs
+    if pmc and pmc.get("valu_insts_per_launch"):
+        peak, peak_occ, src = valu_peaks(wps)
+        v = pmc["valu_insts_per_launch"] / launch_s
+        vi = {"achieved": v, "peak": peak, "unit": "wave-instr/s", "frac": v / peak, "peak_source": src,
+              "waves_per_simd": wps}
+        if peak_occ:
+            vi["peak_at_occupancy"] = peak_occ
+            vi["frac_at_occupancy"] = v / peak_occ
+        r["valu_issue"] = vi
+    return r
+
+
+def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
+    """On-box device-to-device copy bandwidth (read + write bytes / time): the practical HBM ceiling."""
+    src = torch.empty(nbytes // 4, dtype=torch.int32, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+# ---------------------------------------------------------------------------------------------- measurements
+def timed_rollout(torch, sr, steps, seed, chunk, barrier):
+    """The contract's timed region: exactly `steps` env-steps + the gather, wall clock between two barriers."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()                                           # same stream the kernels are launched on
+    launches = sr.rollout(steps, seed, chunk)
+    ev1.record()
+    gathered = sr.gather()                                 # the one collective: per-game results to every rank
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, ev0.elapsed_time(ev1) * 1e-3, launches, gathered
+
+
+def mean_episode_len(gathered):
+    n_ep = int(gathered[..., 0].sum().item())
+    return int(gathered[..., 1].sum().item()) / max(n_ep, 1), n_ep
+
+
+def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
+    """env-steps/s of a workload in its default long launches: one warm-up launch, then n equal launches (n chosen
+    for ~target_s of GPU time), wall clock between synchronisations; roofline from the HIP-event launch time."""
+    game, kw, batch, chunk = WORKLOADS[workload][:4]
+    st = make_stepper(game, kw, batch, device, 0)
+    st.rollout(chunk, seed)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    st.rollout(chunk, seed)
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+    n = int(max(2, min(64, target_s / one)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        st.rollout(chunk, seed)
+    e1.record()
+    res = st.results()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mean_len, n_ep = mean_episode_len(res)
+    launch_s = e0.elapsed_time(e1) * 1e-3 / n
+    out = {"value": batch * chunk * n / elapsed, "unit": "env-steps/s", "games": batch, "steps_per_launch": chunk,
+           "launches": n, "ms_per_env_step": elapsed * 1e3 / (chunk * n), "mean_episode_len": round(mean_len, 3),
+           "dtype": "u32" if game == "ttt" else "int8",
+           "roofline": roofline(workload, batch, chunk, launch_s, mean_len, copy_gbs)}
+    del st
+    return out
+
+
+def step_api_rates(torch, device, copy_gbs):
+    """The per-step batched API (external or sampled actions, every output written every step)."""
+    from colosseumrl_amd.batched import BlokusBatch, TronBatch, TTTBatch
+    out = {}
+
+    def rate(fn, calls):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(calls):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / calls, e0.elapsed_time(e1) * 1e-3 / calls
+
+    B, N, P = 65536, 20, 4
+    tb = TronBatch(N, P, B, device=device)
+    acts = [torch.randint(-1, 2, (P, B), dtype=torch.int8, device=device) for _ in range(16)]
+    i = [0]
+
+    def eager():
+        tb.step(acts[i[0] & 15], auto_reset=True)
+        i[0] += 1
+    wall, gpu = rate(eager, 1000)
+    out["tron_n20_step_auto_reset"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                       "algorithmic_GBs": (12 * P + 2) * B / gpu / 1e9, "games": B}
+    buf = tb.observe_all()
+    wall, gpu = rate(lambda: tb.observe_all(buf), 500)
+    nbytes = (1 + P) * N * N * B
+    out["tron_n20_observe_all"] = {"games_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                   "GBs": nbytes / gpu / 1e9, "frac_of_hbm_peak": nbytes / gpu / 1e9 / HBM_PEAK_GBS,
+                                   "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None,
+                                   "bytes_per_call": nbytes, "what": "N*N in + P*N*N out per game (all P observers)"}
+
+    def unfused():
+        tb.step(tb.sample(7), auto_reset=True)
+        tb.observe_all(buf)
+    wall, gpu = rate(unfused, 500)
+    out["tron_n20_sample_step_observe_all_3calls"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6,
+                                                      "gpu_us_per_call": gpu * 1e6, "GBs": nbytes / gpu / 1e9,
+                                                      "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None}
+    if hasattr(tb, "step_observe"):
+        fo = tb.step_observe(None, seed=7, out=None)
+
+        def fused():
+            tb.step_observe(None, seed=7, out=fo)
+        wall, gpu = rate(fused, 500)
+        out["tron_n20_step_observe_fused"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                              "GBs": nbytes / gpu / 1e9, "frac_of_hbm_peak": nbytes / gpu / 1e9 / HBM_PEAK_GBS,
+                                              "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None,
+                                              "bytes_per_call": nbytes,
+                                              "what": "ONE launch: sample -> next_state (auto-reset) -> state_to_observation of all P observers; "
+                                                      "bytes counted = N*N in + P*N*N out per game"}
+    wall, gpu = rate(lambda: tb.ranking(), 200)
+    out["tron_n20_ranking"] = {"games_per_s": B / wall, "gpu_us_per_call": gpu * 1e6}
+    del tb, buf, acts
+    Bt = 262144
+    tt = TTTBatch((3, 5), 3, 3, Bt, device=device)
+    a = torch.randint(0, 15, (Bt,), dtype=torch.int8, device=device)
+    wall, gpu = rate(lambda: tt.step(a, auto_reset=True), 1000)
+    out["ttt_3x5_step_auto_reset"] = {"env_steps_per_s": Bt / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                      "algorithmic_GBs": 26 * Bt / gpu / 1e9, "games": Bt}
+    del tt
+    Bb = 16384
+    bb = BlokusBatch(Bb, device=device)
+    bb.rollout(24, 5)                                      # mid-game positions
+    wall, gpu = rate(lambda: bb.valid(), 50)
+    out["blokus_valid_count"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "games": Bb}
+    act = bb.sample(5, advance=False)
+    occ0, inv0, sc0, rd0, tm0 = bb.occ.clone(), bb.inv.clone(), bb.score.clone(), bb.round.clone(), bb.to_move.clone()
+
+    def bstep():
+        bb.occ.copy_(occ0); bb.inv.copy_(inv0); bb.score.copy_(sc0); bb.round.copy_(rd0); bb.to_move.copy_(tm0)
+        bb.step(act)
+    wall, gpu = rate(bstep, 50)
+    out["blokus_step_legal_action"] = {"env_steps_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6,
+                                       "what": "next_state with a sampled legal action (incl. restoring the position: 5 small copies)"}
+    pl = torch.zeros((Bb,), dtype=torch.int8, device=device)
+    wall, gpu = rate(lambda: bb.observe(pl), 100)
+    out["blokus_observe"] = {"obs_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6}
+    return out
 
 
 def main():
@@ -125,11 +404,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=65536)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="tron_p4_n20_b65536", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
-    ap.add_argument("--chunk", type=int, default=0, help="env-steps fused into one kernel launch (default: the workload's, 2048)")
+    ap.add_argument("--chunk", type=int, default=0, help="env-steps fused into one kernel launch (default: the workload's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-headline", action="store_true", help="skip steady_state / seeds / others / step_api (profiling runs)")
+    ap.add_argument("--only-step-api", action="store_true", help="run just the per-step API section (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -138,97 +419,101 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    torch.cuda.set_device(local_rank if under_launcher else 0)
+    if under_launcher:                                     # also for a world of ONE rank: the RCCL path is the same code
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
+    use_dist = dist.is_initialized()
 
-    game, kw, batch = WORKLOADS[args.workload][:3]
+    if args.only_step_api:
+        print(json.dumps({"step_api": step_api_rates(torch, device, measure_copy_bandwidth(torch, device))}))
+        return
+
+    game, kw, batch, default_chunk = WORKLOADS[args.workload][:4]
     if args.batch > 0:
         batch = args.batch
     if args.chunk <= 0:
-        args.chunk = WORKLOADS[args.workload][3] if len(WORKLOADS[args.workload]) > 3 else 2048
+        args.chunk = default_chunk
     from colosseumrl_amd.parallel import ShardedRollout
     # weak scaling: every rank owns `batch` games; global ids rank*batch .. (rank+1)*batch - 1
     sr = ShardedRollout(lambda batch, first_env_id: make_stepper(game, kw, batch, device, first_env_id), world * batch)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
+    steps_per_launch = min(args.chunk, args.steps)
+    # warm-up: W untimed steps and the rollout epilogue (gather), so lazily loaded code objects and the RCCL
+    # communicator are not set up inside the timed region
     sr.rollout(args.warmup, args.seed, args.chunk)
-    sr.gather()   # the rollout epilogue (result packing + the gather) is warmed up too: torch loads kernels lazily
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                                           # same stream the kernels are launched on
-    launches = sr.rollout(args.steps, args.seed, args.chunk)
-    ev1.record()
-    gathered = sr.gather()                                 # the one collective: per-game results to every rank
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    sr.gather()
+    elapsed, kernel_s, launches, gathered = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier)
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    n_ep = int(gathered[..., 0].sum().item())
-    len_sum = int(gathered[..., 1].sum().item())
-    mean_len = len_sum / max(n_ep, 1)
+    mean_len, n_ep = mean_episode_len(gathered)
 
     if rank == 0:
-        total_steps = world * batch * args.steps
-        value = total_steps / elapsed
-        bytes_per_step = algorithmic_bytes_per_step(game, kw, mean_len)
-        per_launch_steps = batch * args.steps / launches
-        launch_s = kernel_ms * 1e-3 / launches
-        achieved = bytes_per_step * per_launch_steps / launch_s / 1e9
-        traffic = valu_insts = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                # PMC bytes are per launch: only comparable when this run fuses the same number of steps per launch
-                same = tj.get("steps_per_launch") == args.chunk
-                traffic = tj.get("hbm_bytes_per_launch") if same else None
-                valu_insts = tj.get("valu_insts_per_launch") if same else None
-            except Exception:
-                traffic = None
+        copy_gbs = measure_copy_bandwidth(torch, device) if world == 1 else None
+        value = world * batch * args.steps / elapsed
+        # launches of the timed region are equal-sized when steps % chunk == 0; otherwise the roofline describes the
+        # dominant (first) launch shape and uses the mean launch time only as an approximation -- flagged below
+        equal = (args.steps % steps_per_launch) == 0
+        launch_s = kernel_s / launches
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8" if game != "ttt" else "u32", "data": "synthetic",
             "config": {"workload": args.workload, "games_per_gpu": batch, "global_games": world * batch,
-                       "steps_per_launch": args.chunk, "agent": "uniform random (Philox-4x32-10), auto-reset",
-                       "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name(game, kw), "launch_ms": launch_s * 1e3,
-                         "algorithmic_bytes_per_env_step": round(bytes_per_step, 2)},
+                       "steps_per_launch": steps_per_launch, "launches": launches,
+                       "agent": "uniform random (Philox-4x32-10), auto-reset",
+                       "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
+                       "gather": "rccl all_gather_into_tensor" if use_dist else "none (single process, no process group)"},
+            "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
+            "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),
         }
-        if valu_insts:
-            # second view for these integer kernels: wave-instructions the VALUs issued (PMC SQ_INSTS_VALU of the same
-            # launch shape, profiles/) over this run's launch time, against one wave64 VALU instruction per SIMD per 4 cycles
-            out["roofline"]["valu_issue"] = {"achieved": valu_insts / launch_s, "peak": VALU_PEAK_WAVE_INSTS,
-                                             "unit": "wave-instr/s", "frac": valu_insts / launch_s / VALU_PEAK_WAVE_INSTS}
-        if out["roofline"]["frac"] > 1.0:
-            # the fused rollout keeps boards in LDS for all steps of a launch: the per-step state traffic the
-            # algorithmic figure counts (a step-at-a-time stepper) never reaches HBM, so the HBM roofline of
-            # that formulation is exceeded; what binds the kernel is instruction issue ("Tron rollout").
-            out["roofline"]["note"] = ("state is LDS-resident across the %d fused steps of a launch; measured HBM bytes "
-                                       "per launch are in 'traffic'; the kernel is instruction-issue bound" % args.chunk)
+        if not equal:
+            out["roofline"]["note"] = "launches of the timed region are not equal-sized; launch_ms is their mean"
+        if world == 1 and not args.only_headline:
+            seeds = {}
+            for s in (0, 1, 2):                             # seeds {0, 1, 2}, same timed region
+                sr.stepper.reset()
+                sr.stepper.reset_stats()
+                sr.rollout(args.warmup, s, args.chunk)
+                sr.gather()
+                e, _, _, g = timed_rollout(torch, sr, args.steps, s, args.chunk, barrier)
+                seeds[str(s)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
+            vals = [v["value"] for v in seeds.values()]
+            seeds["spread"] = (max(vals) - min(vals)) / (sum(vals) / len(vals))
+            out["seeds"] = seeds
+            out["steady_state"] = steady_state(torch, args.workload, device, args.seed, copy_gbs)
+            others = {}
+            for wl in WORKLOADS:
+                if wl == args.workload:
+                    continue
+                others[wl] = steady_state(torch, wl, device, args.seed, copy_gbs)
+            out["others"] = others
+            out["step_api"] = step_api_rates(torch, device, copy_gbs)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(game, kw)
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+            if "placement_tests_per_env_step" in out["cpu_baseline"]:
+                out["placement_tests_per_s"] = value * out["cpu_baseline"]["placement_tests_per_env_step"]
+            if "others" in out:
+                for wl, rec in out["others"].items():
+                    rec["cpu_baseline"] = cpu_baseline(wl, seconds_all=3.0, with_one_thread=False)
+                    if "placement_tests_per_env_step" in rec["cpu_baseline"]:
+                        # reference-equivalent work: placements the reference's loops test per env-step (counted by the
+                        # oracle on its sample) x the GPU's env-steps/s; the HIP kernel fits whole shapes instead
+                        rec["placement_tests_per_s"] = rec["value"] * rec["cpu_baseline"]["placement_tests_per_env_step"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

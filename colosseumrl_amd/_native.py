@@ -10,7 +10,8 @@ import subprocess
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libcolosseum_hip.so")
+# CRL_LIB_PATH: load a diagnostic build (tools/blokus_stamps.sh, ...) kept OUTSIDE the tree instead of the shipped library
+LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum_hip.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 CRL_STEP_AUTO_RESET = 1
@@ -41,15 +42,15 @@ def build(force=False, verbose=False):
 
 class TronStats(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len")]
+                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len", "results")]
 
 
 class TTTStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum", "results")]
 
 
 class BlokusStats(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum")]
+    _fields_ = [(n, C.c_void_p) for n in ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum", "results")]
 
 
 _VP, _I, _I64, _U32, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "crl_tron_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_observe_all": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_ranking": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
+    "crl_tron_step_observe": (_I, [_VP, _I64, _U64, _U64] + [_VP] * 13 + [_U32, _VP]),
     "crl_tron_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _I, _VP, _VP]),
     "crl_tron_check_state": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),

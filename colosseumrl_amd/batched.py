@@ -27,6 +27,28 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _DevGuard:
+    """``torch.cuda.device(dev)`` only when `dev` is not already current (the context manager costs several
+    microseconds per call, which is visible next to a 20-step rollout launch)."""
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, dev):
+        self.dev = dev.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+            self.prev = -1
+        return False
+
+
 def _want(t: torch.Tensor, dtype, shape, device, name):
     if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != device:
         raise ValueError("%s must be a contiguous %s tensor of shape %s on %s (got %s %s on %s)"
@@ -95,6 +117,8 @@ class TronBatch:
             self.ret_sum = torch.zeros((P, B), dtype=torch.int32, device=dev)
             self.last_winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
             self.last_len = torch.zeros((B,), dtype=torch.int16, device=dev)
+            self._results = torch.zeros((B, 3 + 2 * P), dtype=torch.int32, device=dev)   # packed by the rollout kernels
+        self._rollout_args = None
         self.reset()
 
     # -- new_state for all (or masked) games
@@ -107,7 +131,7 @@ class TronBatch:
 
     def reset_stats(self):
         for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.ret_sum,
-                  self.last_winners, self.last_len):
+                  self.last_winners, self.last_len, self._results):
             t.zero_()
 
     # -- next_state for all games; actions int8 [P, B] in {0, +1, -1}
@@ -122,7 +146,8 @@ class TronBatch:
 
     def _stats(self):
         return TronStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
-                                                   self.len_sum, self.ret_sum, self.last_winners, self.last_len)])
+                                                   self.len_sum, self.ret_sum, self.last_winners, self.last_len,
+                                                   self._results)])
 
     # -- T fused random-agent steps with auto-reset
     def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto"):
@@ -132,11 +157,13 @@ class TronBatch:
                  "global": _native.CRL_ROLLOUT_NO_LDS}[kernel]
         if not use_lds:
             flags = _native.CRL_ROLLOUT_NO_LDS
-        with torch.cuda.device(self.device):
-            check(self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
-                                             _ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths),
-                                             self._stats(), flags, _stream()),
-                  "crl_tron_rollout")
+        if self._rollout_args is None:       # the state / statistics tensors are never reallocated: bind them once
+            self._rollout_args = (_ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths), self._stats())
+        with _DevGuard(self.device):
+            rc = self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
+                                            *self._rollout_args, flags, _stream())
+        if rc:
+            check(rc, "crl_tron_rollout")
 
     def check_state(self) -> int:
         """Number of games whose state breaks the invariant of every reset / step / rollout product that the LDS
@@ -178,16 +205,44 @@ class TronBatch:
         slice [p] is what player p observes.  Pass a previous result as `out` to reuse its buffers."""
         P, B, N = self.P, self.B, self.N
         if out is None:
-            out = {"board": torch.empty((P, B, N, N), dtype=torch.int8, device=self.device),
-                   "heads": torch.empty((P, P, B), dtype=torch.int16, device=self.device),
-                   "directions": torch.empty((P, P, B), dtype=torch.int8, device=self.device),
-                   "deaths": torch.empty((P, P, B), dtype=torch.int8, device=self.device)}
-        with torch.cuda.device(self.device):
+            out = self.observe_all_buffers()
+        with _DevGuard(self.device):
             check(self._lib.crl_tron_observe_all(self._ctx.handle, B, _ptr(self.board), _ptr(self.heads), _ptr(self.dirs),
                                                  _ptr(self.deaths), _ptr(out["board"]), _ptr(out["heads"]),
                                                  _ptr(out["directions"]), _ptr(out["deaths"]), _stream()),
                   "crl_tron_observe_all")
         return out
+
+    # -- [sample ->] next_state -> state_to_observation of all observers, one launch
+    def step_observe(self, actions: Optional[torch.Tensor] = None, seed: int = 0, auto_reset: bool = True,
+                     out: Optional[dict] = None):
+        """What a self-play learner needs every step, fused: plays `actions` (int8 [P, B]; None = the rollout's random
+        agent at each game's step counter, which then advances) and returns the observations of ALL P players of the
+        resulting states together with the step outputs:
+        {'board' [P, B, N, N], 'heads' [P, P, B], 'directions', 'deaths', 'rewards' [P, B], 'terminal' [B], 'winners' [B]}.
+        Equals ``step(sample(seed) or actions, auto_reset); observe_all()``.  Pass a previous result as `out` to reuse
+        its observation buffers."""
+        P, B, N = self.P, self.B, self.N
+        if actions is not None:
+            _want(actions, torch.int8, (P, B), self.device, "actions")
+        if out is None:
+            out = self.observe_all_buffers()
+        with _DevGuard(self.device):
+            check(self._lib.crl_tron_step_observe(self._ctx.handle, B, seed & (2 ** 64 - 1), self.first_env_id,
+                                                  _ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths),
+                                                  _ptr(actions), _ptr(self.tcount), _ptr(self.rewards), _ptr(self.terminal),
+                                                  _ptr(self.winners), _ptr(out["board"]), _ptr(out["heads"]),
+                                                  _ptr(out["directions"]), _ptr(out["deaths"]),
+                                                  CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()), "crl_tron_step_observe")
+        out["rewards"], out["terminal"], out["winners"] = self.rewards, self.terminal, self.winners
+        return out
+
+    def observe_all_buffers(self):
+        P, B, N = self.P, self.B, self.N
+        return {"board": torch.empty((P, B, N, N), dtype=torch.int8, device=self.device),
+                "heads": torch.empty((P, P, B), dtype=torch.int16, device=self.device),
+                "directions": torch.empty((P, P, B), dtype=torch.int8, device=self.device),
+                "deaths": torch.empty((P, P, B), dtype=torch.int8, device=self.device)}
 
     # -- compute_ranking for all games: int8 [P, B], 0 = best
     def ranking(self):
@@ -198,7 +253,14 @@ class TronBatch:
         return out
 
     def results(self):
-        """Per-game episode results packed for the end-of-rollout gather: int32 [B, 3+2P]."""
+        """Per-game episode results packed for the end-of-rollout gather: int32 [B, 3+2P] =
+        n_episodes, len_sum, last_winners, win_count[P], ret_sum[P].  The rows are written by the rollout kernel
+        itself at the end of every launch (``crl_tron_stats.results``): this returns that buffer, no packing pass.
+        It is rewritten in place by the next rollout; ``clone()`` it to keep a snapshot."""
+        return self._results
+
+    def results_from_columns(self):
+        """The same rows assembled from the per-column statistics (what ``results()`` must equal; used by the tests)."""
         cols = [self.n_episodes, self.len_sum, self.last_winners.to(torch.int32)]
         cols += [self.win_count[p] for p in range(self.P)] + [self.ret_sum[p] for p in range(self.P)]
         return torch.stack(cols, dim=1).contiguous()
@@ -241,6 +303,11 @@ class TTTBatch:
             self.win_count = torch.zeros((P, B), dtype=torch.int32, device=dev)
             self.draw_count = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self._results = torch.zeros((B, 3 + P), dtype=torch.int32, device=dev)
+
+    def reset_stats(self):
+        for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.draw_count, self.len_sum, self._results):
+            t.zero_()
 
     def lines(self):
         buf = (C.c_uint32 * 256)()
@@ -292,7 +359,7 @@ class TTTBatch:
 
     def _stats(self):
         return TTTStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
-                                                  self.draw_count, self.len_sum)])
+                                                  self.draw_count, self.len_sum, self._results)])
 
     def rollout(self, steps: int, seed: int = 0):
         with torch.cuda.device(self.device):
@@ -301,6 +368,10 @@ class TTTBatch:
                                             _stream()), "crl_ttt_rollout")
 
     def results(self):
+        """int32 [B, 3+P] = n_episodes, len_sum, draw_count, win_count[P]; written by the rollout kernel (see TronBatch)."""
+        return self._results
+
+    def results_from_columns(self):
         cols = [self.n_episodes, self.len_sum, self.draw_count] + [self.win_count[p] for p in range(self.P)]
         return torch.stack(cols, dim=1).contiguous()
 
@@ -345,6 +416,7 @@ class BlokusBatch:
             self.win_count = torch.zeros((4, B), dtype=torch.int32, device=dev)
             self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.score_sum = torch.zeros((4, B), dtype=torch.int32, device=dev)
+            self._results = torch.zeros((B, 10), dtype=torch.int32, device=dev)
         self.reset()
 
     def _state(self):
@@ -405,7 +477,11 @@ class BlokusBatch:
 
     def _stats(self):
         return _native.BlokusStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
-                                                            self.len_sum, self.score_sum)])
+                                                            self.len_sum, self.score_sum, self._results)])
+
+    def reset_stats(self):
+        for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.score_sum, self._results):
+            t.zero_()
 
     def rollout(self, steps: int, seed: int = 0):
         with torch.cuda.device(self.device):
@@ -413,5 +489,9 @@ class BlokusBatch:
                                                *self._state(), self._stats(), _stream()), "crl_blokus_rollout")
 
     def results(self):
+        """int32 [B, 10] = n_episodes, len_sum, win_count[4], score_sum[4]; written by the rollout kernel (see TronBatch)."""
+        return self._results
+
+    def results_from_columns(self):
         cols = [self.n_episodes, self.len_sum] + [self.win_count[p] for p in range(4)] + [self.score_sum[p] for p in range(4)]
         return torch.stack(cols, dim=1).contiguous()

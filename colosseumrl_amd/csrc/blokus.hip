@@ -711,6 +711,16 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         round_g[b] = round; to_move_g[b] = pl;
         st.tcount[b] = tc; st.tstep[b] = ts;
     }
+    if (st.results && lane == 0) {     // packed result row for the gather, from the running totals: lane 0 wrote every one
+        int32_t *row = st.results + b * 10;                          // of them itself (program order: no fence needed)
+        row[0] = (int32_t)st.n_episodes[b];
+        row[1] = (int32_t)st.len_sum[b];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            row[2 + c] = (int32_t)st.win_count[c * B + b];
+            row[6 + c] = st.score_sum[c * B + b];
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)

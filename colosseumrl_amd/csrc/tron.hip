@@ -460,20 +460,32 @@ struct TronAcc {
         for (int p = 0; p < P; ++p) wins[p] += (wm >> p) & 1;
         ts = 0;
     }
+    // adds this launch's share to the running per-game totals and, when the caller asked for it, also writes the
+    // packed result row [n_episodes, len_sum, last_winners, win_count[P], ret_sum[P]] the end-of-rollout gather ships
     __device__ __forceinline__ void store(const crl_tron_stats &st, const int64_t B, const int64_t b) const
     {
+        int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            st.ret_sum[p * B + b] += ret[p];
-            st.win_count[p * B + b] += wins[p];
+            const int r = st.ret_sum[p * B + b] + ret[p];
+            const uint32_t w = st.win_count[p * B + b] + wins[p];
+            st.ret_sum[p * B + b] = r;
+            st.win_count[p * B + b] = w;
+            if (row) { row[3 + p] = (int32_t)w; row[3 + P + p] = r; }
         }
         st.tcount[b] = tc;
         st.tstep[b] = ts;
-        st.n_episodes[b] += n_ep;
-        st.len_sum[b] += len_sum;
+        const uint32_t ne = st.n_episodes[b] + n_ep, ls = st.len_sum[b] + len_sum;
+        st.n_episodes[b] = ne;
+        st.len_sum[b] = ls;
         if (last_w >= 0) {
             st.last_winners[b] = (uint8_t)last_w;
             st.last_len[b] = (uint16_t)last_len;
+        }
+        if (row) {
+            row[0] = (int32_t)ne;
+            row[1] = (int32_t)ls;
+            row[2] = last_w >= 0 ? last_w : (int32_t)st.last_winners[b];
         }
     }
 };
@@ -704,10 +716,11 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     int act[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int h = valid ? heads[p * B + bb] : 0;
+        int h = valid ? heads[p * B + bb] : 0;
+        h = min(max(h, 0), NN - 1);                             // a hand-made state must not turn into a wild LDS address
         const int y = (int)__umulhi((uint32_t)h, g.inv_n);
         s.h[p] = mine + (y + 1) * RS + (h - y * N);
-        s.d[p] = valid ? dirs[p * B + bb] : 0;
+        s.d[p] = valid ? dirs[p * B + bb] & 3 : 0;
         s.k[p] = valid ? deaths[p * B + bb] : 1;
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
@@ -959,10 +972,11 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     uint64_t dead[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int h = valid ? heads[p * B + bb] : 0;
+        int h = valid ? heads[p * B + bb] : 0;
+        h = min(max(h, 0), NN - 1);                             // a hand-made state must not turn into a wild LDS address
         const int y = (int)__umulhi((uint32_t)h, g.inv_n);
         pos[p] = 8 * mine + (y + 1) * S + (h - y * N);
-        dir_[p] = valid ? dirs[p * B + bb] : 0;
+        dir_[p] = valid ? dirs[p * B + bb] & 3 : 0;
         dead[p] = __builtin_amdgcn_ballot_w64(valid ? (deaths[p * B + bb] != 0) : true);
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
@@ -1150,8 +1164,8 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 s.d[p] = cfg.start_dirs[p];
                 s.k[p] = 0;
                 if (!from_start) {
-                    h = valid ? heads[p * B + bb] : 0;
-                    s.d[p] = valid ? dirs[p * B + bb] : 0;
+                    h = valid ? min(max((int)heads[p * B + bb], 0), NN - 1) : 0;
+                    s.d[p] = valid ? dirs[p * B + bb] & 3 : 0;
                     s.k[p] = valid ? deaths[p * B + bb] : 1;
                 }
                 const int y = (int)__umulhi((uint32_t)h, g.inv_n);
@@ -1230,15 +1244,13 @@ tron_check_state_kernel(const int P, const int NN, const int64_t B, const int8_t
     if (bad) atomicAdd(n_bad, 1);
 }
 
-// the rollout's random agent for one step (same digits as TronRng, straight from the contract)
+// the rollout's random agent for one step (same digits as TronRng, straight from the contract): actions of step c of
+// global game g in the crl_tron_step encoding (0 forward, +1 right, -1 left)
 template <int P>
-__global__ void __launch_bounds__(256)
-tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
-                   uint32_t *__restrict__ tcount, const int advance, int8_t *__restrict__ actions)
+__device__ __forceinline__ void tron_sample_actions(const uint32_t g, const uint32_t c, const uint32_t seed_lo,
+                                                    const uint32_t seed_hi, int (&act)[P])
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t c = tcount[b], g = (uint32_t)(first_env_id + (uint64_t)b), j = c & 7u;
+    const uint32_t j = c & 7u;
 #pragma unroll
     for (int q = 0; q < (P + 3) / 4; ++q) {
         const philox_out r = philox4x32_10(g, c >> 3, (uint32_t)q, CRL_TAG_TRON, seed_lo, seed_hi);
@@ -1249,10 +1261,24 @@ tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_
             if (4 * q + i < P) {
                 const uint32_t a3 = __umulhi(v, 3u);
                 v *= 3u;
-                actions[(int64_t)(4 * q + i) * B + b] = (int8_t)(a3 == 2u ? -1 : (int)a3);
+                act[4 * q + i] = a3 == 2u ? -1 : (int)a3;
             }
         }
     }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
+                   uint32_t *__restrict__ tcount, const int advance, int8_t *__restrict__ actions)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t c = tcount[b];
+    int act[P];
+    tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c, seed_lo, seed_hi, act);
+#pragma unroll
+    for (int p = 0; p < P; ++p) actions[(int64_t)p * B + b] = (int8_t)act[p];
     if (advance) tcount[b] = c + 1u;
 }
 
@@ -1281,7 +1307,8 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (wide) {
             const int64_t off = i * 16;
-            const int pl = player[off / NN] + 1;
+            const int pr = player[off / NN];
+            const int pl = ((unsigned)pr < (unsigned)P ? pr : 0) + 1;       // an id outside 0..P-1 observes as player 0
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
             uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
             if (P <= 7) {
@@ -1304,7 +1331,8 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
             }
             *reinterpret_cast<uint4 *>(obs + off) = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
-            const int pl = player[i / NN] + 1;
+            const int pr = player[i / NN];
+            const int pl = ((unsigned)pr < (unsigned)P ? pr : 0) + 1;
             const int c = board[i];
             int n = c - pl;
             n = n < 0 ? n + P : n;
@@ -1321,7 +1349,8 @@ tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, 
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int pl = player[b];
+    const int pr = player[b];
+    const int pl = (unsigned)pr < (unsigned)P ? pr : 0;              // as the board kernel: out-of-range ids observe as player 0
     int h[P], d[P], k[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) { h[p] = heads[p * B + b]; d[p] = dirs[p * B + b]; k[p] = deaths[p * B + b]; }
@@ -1474,6 +1503,140 @@ tron_observe_all_players_kernel(const int64_t B, const int16_t *__restrict__ hea
             od[((int64_t)p * P + i) * B + b] = (int8_t)d[src];
             ok[((int64_t)p * P + i) * B + b] = (int8_t)k[src];
         }
+}
+
+// ---- fused per-step call: [sample ->] next_state (auto-reset) -> state_to_observation of ALL P observers ------------
+// What a self-play learner runs every step (TronGridEnvironment.next_state :265-323 + state_to_observation :363-420 for
+// every player).  As three launches (crl_tron_sample, crl_tron_step, crl_tron_observe_all) the board is probed with
+// scattered byte loads, rewritten, and then read again in full; here a workgroup reads its G boards ONCE, coalesced,
+// into LDS, one lane per game plays the step there (the same tron_step_core as crl_tron_step), and all 256 threads
+// stream the P relabelled copies out of LDS (one v_perm_b32 per 4 cells and observer).  HBM sees N*N bytes in and
+// P*N*N bytes out per game, plus the <= P trail bytes (byte stores) and, for the games that were reset, one fresh board.
+struct DualBoard {                  // step on the LDS copy, mirror the trail writes to the canonical HBM board
+    uint8_t *l;
+    int8_t *g;
+    __device__ __forceinline__ int raw(const int c) const { return l[c]; }
+    __device__ __forceinline__ int owner(const int r) const { return r; }
+    __device__ __forceinline__ void put(const int c, const int who) const { l[c] = (uint8_t)who; g[c] = (int8_t)who; }
+};
+
+template <int P, int G>
+__global__ void __launch_bounds__(256)
+tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t inv_cp, const int64_t B,
+                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
+                         int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                         int8_t *__restrict__ deaths, const int8_t *__restrict__ actions, uint32_t *__restrict__ tcount,
+                         int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                         int8_t *__restrict__ obs_board, int16_t *__restrict__ oh, int8_t *__restrict__ od,
+                         int8_t *__restrict__ ok, const uint32_t flags)
+{
+    static_assert(P <= 7, "the v_perm relabelling table holds cell values 0..7");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int NN = g.NN, SLAB = NN + 16;                        // NN % 16 == 0: 16-byte LDS accesses stay aligned
+    const int cp = NN >> 4;                                     // 16-byte chunks per board
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);
+    const int total = n_game * cp;
+    uint8_t *rflag = lds + G * SLAB;                            // [G] this game was reset by the step
+    // ---- phase A: boards HBM -> LDS, coalesced 16-byte loads, up to 4 in flight per thread
+    for (int base = threadIdx.x; base < total; base += 4 * 256) {
+        uint4 v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * 256;
+            const int cc = c < total ? c : 0;
+            const int e = (int)__umulhi((uint32_t)cc, inv_cp);
+            const int off = (cc - e * cp) << 4;
+            dst[u] = c < total ? e * SLAB + off : -1;
+            v[u] = *reinterpret_cast<const uint4 *>(board + (g0 + e) * NN + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4 *>(lds + dst[u]) = v[u];
+    }
+    __syncthreads();
+    // ---- phase B: one lane per game plays the step on its LDS board
+    if (threadIdx.x < G) {
+        const int e = threadIdx.x;
+        const bool valid = e < n_game;
+        const int64_t b = g0 + (valid ? e : 0);
+        TronRegs<P> s;
+        int act[P], rew[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = valid ? heads[p * B + b] : 0;
+            s.d[p] = valid ? dirs[p * B + b] : 0;
+            s.k[p] = valid ? deaths[p * B + b] : 1;
+            act[p] = (valid && actions) ? actions[p * B + b] : 0;
+        }
+        if (!actions) {                                         // the rollout's random agent at this game's step counter
+            const uint32_t c = valid ? tcount[b] : 0u;
+            tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c, seed_lo, seed_hi, act);
+            if (valid) tcount[b] = c + 1u;
+        }
+        tron_split_heads<P>(g, s);
+        int term, wm;
+        const DualBoard bd{lds + e * SLAB, board + b * NN};
+        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
+        rflag[e] = do_reset ? 1 : 0;
+        if (do_reset) tron_regs_to_start<P>(cfg, g, s);         // phase C writes the fresh board (LDS slab is ignored)
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                rewards[p * B + b] = (int8_t)rew[p];
+                heads[p * B + b] = (int16_t)s.h[p];
+                dirs[p * B + b] = (int8_t)s.d[p];
+                deaths[p * B + b] = (int8_t)s.k[p];
+            }
+            terminal[b] = (uint8_t)term;
+            winners[b] = (uint8_t)wm;
+#pragma unroll
+            for (int p = 0; p < P; ++p)                         // TronGridEnvironment.py:392-396: rolled so index 0 is the observer
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const int src = (i + p) % P;                // compile-time after unrolling
+                    oh[((int64_t)p * P + i) * B + b] = (int16_t)s.h[src];
+                    od[((int64_t)p * P + i) * B + b] = (int8_t)s.d[src];
+                    ok[((int64_t)p * P + i) * B + b] = (int8_t)s.k[src];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: stream the P relabelled copies out (CyTronGrid.pyx:65-71 as one v_perm_b32 per 4 cells)
+    uint32_t lut_lo[P], lut_hi[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        lut_lo[p] = 0; lut_hi[p] = 0;
+#pragma unroll
+        for (int v = 1; v < 8; ++v) {
+            int n = v - (p + 1);
+            n = n < 0 ? n + P : n;
+            const uint32_t r = (v <= P) ? (uint32_t)(n + 1) : (uint32_t)v;
+            if (v < 4) lut_lo[p] |= r << (8 * v); else lut_hi[p] |= r << (8 * (v - 4));
+        }
+    }
+    const int64_t plane = B * (int64_t)NN;                      // one observer's boards
+    for (int c = threadIdx.x; c < total; c += 256) {
+        const int e = (int)__umulhi((uint32_t)c, inv_cp);
+        const int off = (c - e * cp) << 4;
+        uint4 v = *reinterpret_cast<const uint4 *>(lds + e * SLAB + off);
+        const int64_t gofs = (g0 + e) * NN + off;
+        if (rflag[e]) {                                         // new_state: the fresh board replaces the finished one
+            v = tron_fresh_chunk16<P>(cfg, off);
+            *reinterpret_cast<uint4 *>(board + gofs) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
+            o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
+            o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
+            o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+            *reinterpret_cast<uint4 *>(obs_board + (int64_t)p * plane + gofs) = o;
+        }
+    }
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -1732,6 +1895,58 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
+}
+
+int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                          int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                          const int8_t *actions, uint32_t *tcount,
+                          int8_t *rewards, uint8_t *terminal, uint8_t *winners,
+                          int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
+                          uint32_t flags, void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_step_observe");
+    CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_step_observe: NULL state pointer");
+    CRL_REQUIRE(actions || tcount, "crl_tron_step_observe: actions and tcount are both NULL (nothing to play)");
+    CRL_REQUIRE(rewards && terminal && winners, "crl_tron_step_observe: NULL step output pointer");
+    CRL_REQUIRE(obs_board && obs_heads && obs_dirs && obs_deaths, "crl_tron_step_observe: NULL observation pointer");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_tron_step_observe: unknown flags 0x%x", flags);
+    const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_step_observe: boards must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const TronGeom g = geom_of(cfg);
+    // the fused kernel needs whole 16-byte chunks per board, the 8-entry relabelling table (P <= 7) and G boards in LDS;
+    // everything else takes the same three kernels the separate entry points launch (identical results either way)
+    const int slab = NN + 16;
+    const int G = (64 * slab + 64 <= 48 * 1024) ? 64 : (16 * slab + 16 <= 48 * 1024) ? 16 : 0;
+    if ((NN % 16) == 0 && cfg.P <= 7 && G > 0) {
+        const uint32_t inv_cp = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;     // exact for chunk ids < 2^16
+        const size_t lds_bytes = (size_t)G * slab + G;
+        const dim3 grid(blocks_for(B, G));
+        switch (cfg.P) {
+#define CRL_SO_CASE(P_)                                                                                                   \
+        case P_:                                                                                                          \
+            if (G == 64)                                                                                                  \
+                hipLaunchKernelGGL((tron_step_observe_kernel<P_, 64>), grid, dim3(256), lds_bytes, s, cfg, g, inv_cp, B,   \
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,     \
+                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags); \
+            else                                                                                                          \
+                hipLaunchKernelGGL((tron_step_observe_kernel<P_, 16>), grid, dim3(256), lds_bytes, s, cfg, g, inv_cp, B,   \
+                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,     \
+                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags); \
+            break;
+            CRL_SO_CASE(1) CRL_SO_CASE(2) CRL_SO_CASE(3) CRL_SO_CASE(4) CRL_SO_CASE(5) CRL_SO_CASE(6) CRL_SO_CASE(7)
+#undef CRL_SO_CASE
+            default: crl_set_error("tron: P=%d out of range", cfg.P); return CRL_EINVAL;
+        }
+        CRL_LAUNCH_CHECK();
+        return CRL_OK;
+    }
+    CRL_REQUIRE(actions != nullptr, "crl_tron_step_observe: this board / player count takes the unfused path, which needs "
+                                    "explicit actions (call crl_tron_sample first)");
+    int rc = crl_tron_step(ctx, B, board, heads, dirs, deaths, actions, rewards, terminal, winners, flags, stream);
+    if (rc != CRL_OK) return rc;
+    return crl_tron_observe_all(ctx, B, board, heads, dirs, deaths, obs_board, obs_heads, obs_dirs, obs_deaths, stream);
 }
 
 int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *deaths, int8_t *rank, void *stream)

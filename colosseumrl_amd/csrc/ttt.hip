@@ -155,15 +155,23 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             w = -1; tm = 0; ts = 0;
         }
     }
+    int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
-    for (int p = 0; p < P; ++p) { occ[p * B + b] = o[p]; st.win_count[p * B + b] += wins[p]; }
+    for (int p = 0; p < P; ++p) {
+        occ[p * B + b] = o[p];
+        const uint32_t wc = st.win_count[p * B + b] + wins[p];
+        st.win_count[p * B + b] = wc;
+        if (row) row[3 + p] = (int32_t)wc;
+    }
     winner[b] = (int8_t)w;
     to_move[b] = (int8_t)tm;
     st.tcount[b] = tc;
     st.tstep[b] = ts;
-    st.n_episodes[b] += n_ep;
-    st.draw_count[b] += draws;
-    st.len_sum[b] += len_sum;
+    const uint32_t ne = st.n_episodes[b] + n_ep, dr = st.draw_count[b] + draws, ls = st.len_sum[b] + len_sum;
+    st.n_episodes[b] = ne;
+    st.draw_count[b] = dr;
+    st.len_sum[b] = ls;
+    if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = (int32_t)dr; }
 }
 
 // the rollout's random agent for one step

@@ -25,11 +25,15 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_results(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+def gather_results(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Concatenate per-game result rows [n_local, k] of all ranks, in global game order, on every rank.
 
     One collective: shards are padded to the largest shard so a single ``all_gather_into_tensor`` moves
-    everything (a ring over the 7 xGMI links per GPU is ample for a few MB)."""
+    everything (a ring over the 7 xGMI links per GPU is ample for a few MB).  The collective runs whenever a
+    process group is initialised -- also for a world of one rank (``torchrun --nproc-per-node 1``), so the RCCL
+    path is the same code at every world size.  `out` (``[world * ceil(total / world), k]``, same dtype / device)
+    is an optional preallocated receive buffer."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -41,7 +45,9 @@ def gather_results(local: torch.Tensor, total: int, group: Optional[dist.Process
     if local.shape[0] != widest:
         padded = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
-    out = torch.empty((world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    shape = (world * widest,) + tuple(local.shape[1:])
+    if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
+        out = torch.empty(shape, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
     if total == world * widest:
         return out
@@ -68,6 +74,7 @@ class ShardedRollout:
             self.world, self.rank = 1, 0
         self.lo, self.hi = shard_bounds(self.total, self.rank, self.world)
         self.stepper = make_stepper(batch=self.hi - self.lo, first_env_id=self.lo)
+        self._recv = None                      # receive buffer of the gather, allocated once
 
     def rollout(self, steps: int, seed: int = 0, chunk: int = 512) -> int:
         """Exactly `steps` env-steps for every local game, as fused launches of <= chunk steps."""
@@ -81,4 +88,8 @@ class ShardedRollout:
 
     def gather(self) -> torch.Tensor:
         """Per-game results of ALL games on every rank (the one collective of a rollout)."""
-        return gather_results(self.stepper.results(), self.total, self.group)
+        local = self.stepper.results()
+        if self._recv is None and dist.is_available() and dist.is_initialized():
+            widest = -(-self.total // self.world)
+            self._recv = torch.empty((self.world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        return gather_results(local, self.total, self.group, out=self._recv)

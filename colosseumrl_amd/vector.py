@@ -10,7 +10,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .batched import TronBatch, TTTBatch
+from .batched import BlokusBatch, TronBatch, TTTBatch
 
 
 class TronVectorEnv:
@@ -29,10 +29,12 @@ class TronVectorEnv:
         return {p: self.observe(p) for p in range(self.num_players)}
 
     def step(self, actions: torch.Tensor) -> Tuple[Dict[int, Dict[str, torch.Tensor]], torch.Tensor, torch.Tensor, Dict]:
-        """-> (obs per player of the state AFTER auto-reset, rewards int8 [P, B], done uint8 [B], info)."""
-        rewards, terminal, winners = self.batch.step(actions, auto_reset=True)
-        rewards, done, winners = rewards.clone(), terminal.clone(), winners.clone()
-        return {p: self.observe(p) for p in range(self.num_players)}, rewards, done, {"winners": winners}
+        """-> (obs per player of the state AFTER auto-reset, rewards int8 [P, B], done uint8 [B], info).
+        One launch: next_state and the observations of all players come out of the fused ``step_observe`` call."""
+        o = self.batch.step_observe(actions, auto_reset=True)
+        obs = {p: {"board": o["board"][p], "heads": o["heads"][p], "directions": o["directions"][p], "deaths": o["deaths"][p]}
+               for p in range(self.num_players)}
+        return obs, o["rewards"].clone(), o["terminal"].clone(), {"winners": o["winners"].clone()}
 
 
 class TicTacToeVectorEnv:
@@ -53,3 +55,39 @@ class TicTacToeVectorEnv:
         reward, done, winners = reward.clone(), terminal.clone(), winners.clone()
         mover = self.batch.to_move
         return self.batch.observe(mover), mover.clone(), self.batch.valid_mask(), reward, done, {"winners": winners}
+
+
+class BlokusVectorEnv:
+    """B turn-based Blokus games (4 players, 20x20).  ``step`` takes int32 dense action ids [B] for the player to move
+    (``envs.blokus.actions``: ``((piece*400 + y*20 + x)*8 + orientation)*5 + shift``; -1 = pass, the reference's '').
+    Like the reference's ``next_state`` it does not validate actions (``match_server`` does, via ``is_valid_action``):
+    pick them from ``sample_valid`` / ``valid_mask``."""
+
+    def __init__(self, batch: int = 1024, device="cuda"):
+        self.batch = BlokusBatch(batch, device=device)
+        self.num_players, self.num_envs = 4, batch
+
+    def _mover(self) -> torch.Tensor:
+        return self.batch.to_move.to(torch.int8)
+
+    def reset(self):
+        """-> (obs for the player to move, mover int8 [B], number of legal actions int32 [B])."""
+        self.batch.reset()
+        mover = self._mover()
+        return self.batch.observe(mover), mover, self.batch.valid()
+
+    def valid_mask(self) -> torch.Tensor:
+        """Dense legal-action bitmap int32 [B, 10500] of the player to move (42 KB per game: meant for small B)."""
+        return self.batch.valid(want_mask=True)[1]
+
+    def sample_valid(self, seed: int = 0) -> torch.Tensor:
+        """A uniformly drawn legal action id per game (-1 where the mover must pass)."""
+        return self.batch.sample(seed)
+
+    def step(self, action: torch.Tensor):
+        """-> (obs for the next mover, next mover int8 [B], its number of legal actions int32 [B], reward int8 [B] of the
+        player who just moved, done uint8 [B], info); finished games restart (obs / mover / counts are of the new game)."""
+        reward, terminal, winners = self.batch.step(action, auto_reset=True)
+        reward, done, winners = reward.clone(), terminal.clone(), winners.clone()
+        mover = self._mover()
+        return self.batch.observe(mover), mover, self.batch.valid(), reward, done, {"winners": winners}

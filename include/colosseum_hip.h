@@ -82,7 +82,8 @@ int crl_tron_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask,
 
 /* replaces CyTronGrid.next_state_inplace (CyTronGrid.pyx:3-62) + the tail of
  * TronGridEnvironment.next_state (TronGridEnvironment.py:309-323) for B envs.
- *   actions  int8 [P][B] in {0 forward, +1 right, -1 left} (dead players' entries ignored)
+ *   actions  int8 [P][B] in {0 forward, +1 right, -1 left} (dead players' entries ignored; not validated, exactly
+ *            like the reference's Cython kernel: other values are taken mod 4, so 2 would reverse)
  *   rewards  int8 [P][B] out: -1 dead, +1 alive, +10 surviving winner
  *   terminal uint8 [B]   out: alive <= 1
  *   winners  uint8 [B]   out: bitmask of alive players if terminal, else 0 (reference: None) */
@@ -91,7 +92,7 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
                   const int8_t *actions, int8_t *rewards, uint8_t *terminal, uint8_t *winners,
                   uint32_t flags, void *stream);
 
-/* per-env rollout bookkeeping, all DEVICE arrays (any may NOT be NULL) */
+/* per-env rollout bookkeeping, all DEVICE arrays (none may be NULL except `results`) */
 typedef struct {
     uint32_t *tcount;       /* [B] rollout steps this env has taken so far = the RNG counter */
     uint32_t *tstep;        /* [B] steps taken in the current episode */
@@ -101,6 +102,9 @@ typedef struct {
     int32_t  *ret_sum;      /* [P][B] sum of rewards */
     uint8_t  *last_winners; /* [B] */
     uint16_t *last_len;     /* [B] */
+    int32_t  *results;      /* [B][3+2P] or NULL: the per-game row the end-of-rollout gather ships, rewritten by every
+                             * launch from the running totals above: n_episodes, len_sum, last_winners, win_count[P],
+                             * ret_sum[P] (no separate packing pass over the SoA arrays) */
 } crl_tron_stats;
 
 /* T fused env-steps per env with a uniform random agent and auto-reset (the benchmark loop of
@@ -114,7 +118,9 @@ typedef struct {
  * byte-per-cell slab, larger ones (T >= 256) on an occupancy bitboard whose unfinished episode is replayed with
  * owners at the end of the launch; boards above 40x40, or flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / CRL_ROLLOUT_BITS pin
  * one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
- * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player. */
+ * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player; callers
+ * that upload hand-made states run crl_tron_check_state first (heads outside the board are clamped onto it, so a
+ * broken state gives wrong results, never a wild access). */
 int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                      crl_tron_stats stats, uint32_t flags, void *stream);
@@ -134,7 +140,8 @@ int crl_tron_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 
 /* replaces CyTronGrid.relative_player_inplace (CyTronGrid.pyx:65-71) + the rolls of
  * TronGridEnvironment.state_to_observation (TronGridEnvironment.py:385-405), fully observable branch.
- * player int8 [B]: observer of env b.  Outputs have the shapes of the state arrays. */
+ * player int8 [B]: observer of env b (an id outside 0..P-1 observes as player 0).  Outputs have the shapes of the
+ * state arrays. */
 int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads,
                      const int8_t *dirs, const int8_t *deaths, const int8_t *player,
                      int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream);
@@ -145,6 +152,21 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
 int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, const int8_t *dirs,
                          const int8_t *deaths, int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
                          void *stream);
+
+/* One launch for what a self-play learner does every step: [sample ->] next_state -> state_to_observation of every
+ * player, i.e. TronGridEnvironment.next_state (TronGridEnvironment.py:265-323, called per tick from match_server.py:201-203)
+ * followed by state_to_observation (:363-420, match_server.py:218) for all P observers.  Exactly equivalent to
+ *   [crl_tron_sample(..., advance = 1);]  crl_tron_step(..., flags);  crl_tron_observe_all(...)
+ * with actions == NULL meaning "draw them with the rollout's random agent at tcount[b] and advance tcount" (tcount may be
+ * NULL when actions are given; it is not touched then).  The boards are read from HBM once (coalesced, into LDS),
+ * stepped there, and the P relabelled copies streamed out: N*N bytes in + P*N*N bytes out per game.  Boards with
+ * N*N % 16 != 0, P = 8, or boards too large for LDS take the three separate kernels internally (actions required). */
+int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                          int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                          const int8_t *actions, uint32_t *tcount,
+                          int8_t *rewards, uint8_t *terminal, uint8_t *winners,
+                          int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
+                          uint32_t flags, void *stream);
 
 /* replaces TronGridEnvironment.compute_ranking (TronGridEnvironment.py:483-508) for B games:
  * rank int8 [P][B], 0 = best; trail-length scores, the mutual-kill tie rule (with its deaths[-1] read for
@@ -179,6 +201,7 @@ typedef struct {
     uint32_t *win_count;   /* [P][B] */
     uint32_t *draw_count;  /* [B] */
     uint32_t *len_sum;     /* [B] */
+    int32_t  *results;     /* [B][3+P] or NULL: packed row n_episodes, len_sum, draw_count, win_count[P] (as crl_tron_stats) */
 } crl_ttt_stats;
 /* random agent, one Philox call per 4 steps: with c = tcount,
  *   r = mulhi32(Philox(ctr={g, c >> 2, 0, 0x54540000}, seed)[c & 3], n_empty); r-th empty cell in row-major order */
@@ -236,6 +259,7 @@ typedef struct {
     uint32_t *win_count;   /* [4][B] */
     uint32_t *len_sum;     /* [B] */
     int32_t  *score_sum;   /* [4][B] final scores summed over finished episodes */
+    int32_t  *results;     /* [B][10] or NULL: packed row n_episodes, len_sum, win_count[4], score_sum[4] (as crl_tron_stats) */
 } crl_blokus_stats;
 /* random agent: the mover plays the r-th action of valid_actions() (reference order), r = mulhi32(w, n), '' if n = 0;
  * w = Philox(ctr={g, c >> 2, 0, 0x424c0000}, seed)[c & 3] with c = tcount; auto-reset on terminal */

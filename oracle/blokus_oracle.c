@@ -106,6 +106,27 @@ static int valid_corner(const blk_env *e, int color, int row, int col)
 /* board.py:170-193 get_all_valid_moves, flattened in BlokusEnvironment.valid_actions order (:453-500).
  * ids (may be NULL) receives encoded actions ((piece*400 + y*20 + x)*8 + orient)*5 + shift; returns
  * the number of actions; stops early once `limit` have been found (limit <= 0: no limit). */
+/* Work counter for bench.py: the number of (piece, anchor, orientation, shift) placements the REFERENCE tests for the
+ * calls restated here -- get_all_valid_moves has no early exit (board.py:184-189), and ai.check_moves (ai.py:31-42,
+ * called per player by next_state :424 until one of them has a move) runs that full enumeration too.  So every
+ * enumerate_moves() call counts n_anchor * sum over held pieces of 8 * cells, whatever `limit` lets this code skip. */
+static uint64_t g_placement_tests = 0;
+uint64_t orc_blokus_placement_tests(int reset)
+{
+    uint64_t v;
+#ifdef _OPENMP
+#pragma omp atomic read
+#endif
+    v = g_placement_tests;
+    if (reset) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+        g_placement_tests = 0;
+    }
+    return v;
+}
+
 static int enumerate_moves(const blk_env *e, int player, int round, uint32_t inv, int32_t *ids, int cap, int limit)
 {
     static const int CORNER_X[4] = {0, BN - 1, 0, BN - 1}, CORNER_Y[4] = {0, 0, BN - 1, BN - 1};   /* board.py:50 */
@@ -116,6 +137,15 @@ static int enumerate_moves(const blk_env *e, int player, int round, uint32_t inv
         for (int row = 0; row < BN; ++row)
             for (int col = 0; col < BN; ++col)
                 if (e->board[row][col] == 0 && valid_corner(e, color, row, col)) { ax[n_anchor] = col; ay[n_anchor] = row; n_anchor++; }
+    }
+    {
+        uint64_t combos = 0;
+        for (int piece = 0; piece < NP; ++piece) if ((inv >> piece) & 1u) combos += 8u * (uint64_t)PIECE_CELLS[piece];
+        combos *= (uint64_t)n_anchor;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        g_placement_tests += combos;
     }
     for (int piece = 0; piece < NP; ++piece) {            /* board.py:184 inventory order */
         if (!((inv >> piece) & 1u)) continue;

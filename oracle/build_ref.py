@@ -1,18 +1,20 @@
-"""Build recipe for ``oracle/_ref`` -- TEST INFRASTRUCTURE, never shipped or measured as product.
+"""Build recipe for the reference's Cython kernel -- TEST INFRASTRUCTURE, never shipped or measured as product.
 
 Compiles the reference's only first-party native file,
 ``/root/reference/colosseumrl/envs/tron/CyTronGrid.pyx`` (79 lines of Cython),
 from where it lies, with the locally installed Cython + gcc.  Outputs (generated
-C and the extension ``.so``) go ONLY into ``oracle/_ref/`` (git-ignored, but it
-travels to the GPU box with the snapshot).  No reference source is copied into
-the repository: Cython reads the ``.pyx`` in place and the generated C stays
-under the ignored ``_ref`` directory.
+C and the extension ``.so``) go ONLY into a scratch directory OUTSIDE the repository
+(``$TMPDIR/colosseumrl_ref_<uid>``): a Python reference must not travel to the GPU
+box in any form, compiled or not, and ``gpurun`` ships the whole work tree.  No
+reference source is copied anywhere: Cython reads the ``.pyx`` in place and the
+generated C is deleted after the compile.
 
 The shipped ``CyTronGrid.c`` (Cython 0.29.13) does not compile against CPython
 3.10, so the ``.pyx`` is the build input.
 
-If ``/root/reference`` is absent (the GPU box) this is a no-op: the prebuilt
-``.so`` is used when present.
+If ``/root/reference`` is absent (the GPU box) there is nothing to build and nothing
+to load: ``build()`` returns None.  ``oracle/ref_loader.load()`` builds on demand;
+``__graft_entry__.build()`` does NOT call this.
 """
 import glob
 import os
@@ -20,9 +22,10 @@ import shutil
 import subprocess
 import sys
 import sysconfig
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_DIR = os.path.join(HERE, "_ref")
+REF_DIR = os.path.join(tempfile.gettempdir(), "colosseumrl_ref_%d" % os.getuid())   # never inside the repo
 PYX = "/root/reference/colosseumrl/envs/tron/CyTronGrid.pyx"
 
 
@@ -32,9 +35,9 @@ def built_path():
 
 
 def build(force=False):
-    """Compile CyTronGrid.pyx -> oracle/_ref/CyTronGrid.<abi>.so.  Returns the path or None."""
+    """Compile CyTronGrid.pyx -> <scratch>/CyTronGrid.<abi>.so.  Returns the path, or None without /root/reference."""
     if not os.path.exists(PYX):
-        return built_path()
+        return None
     os.makedirs(REF_DIR, exist_ok=True)
     so = built_path()
     if so and not force and os.path.getmtime(so) >= os.path.getmtime(PYX):

@@ -295,6 +295,42 @@ def ttt_observe_cases(R, which, E, seed):
                 player=np.array(players, np.int8), obs_board=np.array(obs, np.int8))
 
 
+def ttt_current_rewards_cases(R, which, E, seed):
+    """current_rewards (reference 2p:219-238, 3p:220-239, 4p:250-269) on states the reference itself reaches: random
+    games played through next_state, sampled before and after somebody has won, plus a drawn (full, no winner) board
+    when the game produces one."""
+    env = R[which]()
+    shape = env.observation_shape["board"]
+    P = env.max_players
+    n_cells = int(np.prod(shape))
+    rng = np.random.default_rng(seed)
+    boards, winners, rewards = [], [], []
+    for e in range(E):
+        state, players = env.new_state()
+        for t in range(n_cells + 2):
+            boards.append(state[0].ravel().copy())
+            winners.append(-1 if state[1] is None else int(state[1]))
+            rewards.append([int(r) for r in env.current_rewards(state)])
+            empty = np.flatnonzero(state[0].ravel() == -1)
+            if len(empty) == 0:
+                break
+            cell = int(empty[int(rng.integers(0, len(empty)))])
+            astr = str(tuple(int(i) for i in np.unravel_index(cell, shape)))
+            state, players, _, terminal, _ = env.next_state(state, players, [astr])
+            if terminal and rng.random() < 0.5:
+                boards.append(state[0].ravel().copy())
+                winners.append(-1 if state[1] is None else int(state[1]))
+                rewards.append([int(r) for r in env.current_rewards(state)])
+                break
+    return dict(shape=np.array(shape, np.int32), P=P, board=np.array(boards, np.int8), winner=np.array(winners, np.int8),
+                rewards=np.array(rewards, np.int8))
+
+
+def gen_ttt_rewards(R):
+    for which, name in (("ttt2", "2p"), ("ttt3", "3p"), ("ttt4", "4p")):
+        np.savez_compressed(os.path.join(OUT, "ttt_rewards_%s.npz" % name), **ttt_current_rewards_cases(R, which, 24, 11))
+
+
 def gen_ttt(R):
     for which, name in (("ttt2", "2p"), ("ttt3", "3p"), ("ttt4", "4p")):
         for ar in (True, False):
@@ -314,6 +350,8 @@ def main(argv):
         gen_tron(R)
     if "ttt" in what:
         gen_ttt(R)
+    if "ttt" in what or "ttt_rewards" in what:
+        gen_ttt_rewards(R)
     if "blokus" in what:
         from . import gen_golden_blokus
         gen_golden_blokus.gen(R, OUT)

@@ -310,6 +310,13 @@ def blokus_step(st, action, n_threads=1):
     return reward, terminal, winners
 
 
+def blokus_placement_tests(reset=False):
+    """Reference-equivalent placement tests counted by the oracle since the last reset (see blokus_oracle.c)."""
+    f = lib().orc_blokus_placement_tests
+    f.restype = C.c_uint64
+    return int(f(C.c_int(1 if reset else 0)))
+
+
 def blokus_rollout(st, seed, first_env_id, T, n_threads=1):
     stats = _BlokusStats(*[_p(getattr(st, n)) for n, _ in _BlokusStats._fields_])
     f = lib().orc_blokus_rollout

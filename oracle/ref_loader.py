@@ -56,7 +56,7 @@ def load():
 
     so = build_ref.build()
     if so is None:
-        raise RuntimeError("oracle/_ref/CyTronGrid*.so could not be built")
+        raise RuntimeError("the reference's CyTronGrid.pyx could not be built")
 
     base = os.path.join(REF_ROOT, "colosseumrl")
     _shell("colosseumrl", base)

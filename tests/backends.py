@@ -173,6 +173,12 @@ class OracleBlokus:
         self.st.round[:] = rnd
         self.st.to_move[:] = to_move
 
+    def reset(self, mask=None):
+        fresh = O.BlokusState(self.B)
+        m = np.ones(self.B, bool) if mask is None else np.asarray(mask).astype(bool)
+        for k in ("occ", "inv", "score", "round", "to_move"):
+            getattr(self.st, k)[m] = getattr(fresh, k)[m]
+
     def valid(self, cap, player=None):
         return O.blokus_valid(self.st, player=player, cap=cap, n_threads=8)
 

@@ -24,6 +24,40 @@ def pytest_sessionstart(session):
         _native.build()
     from oracle import oracle as O
     O.build()
+    # helper for the tests that need fresh processes; started now, while this process has not initialised the GPU
+    global _launcher
+    import subprocess
+    _launcher = subprocess.Popen([sys.executable, "-u", os.path.join(ROOT, "tests", "_launcher.py")], stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
+_launcher = None
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _launcher
+    if _launcher is not None:
+        try:
+            _launcher.stdin.close()
+            _launcher.wait(timeout=10)
+        except Exception:  # noqa: BLE001
+            _launcher.kill()
+        _launcher = None
+
+
+@pytest.fixture(scope="session")
+def run_fresh():
+    """run_fresh(cmd, env=None, cwd=None, timeout=600) -> (returncode, output): runs `cmd` in a fresh process started by
+    tests/_launcher.py, a helper forked at session start, BEFORE this process touched the GPU (see its docstring)."""
+    import json
+
+    def run(cmd, env=None, cwd=None, timeout=600):
+        assert _launcher is not None and _launcher.poll() is None, "tests/_launcher.py is not running"
+        _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "cwd": cwd, "timeout": timeout}) + "\n")
+        _launcher.stdin.flush()
+        rep = json.loads(_launcher.stdout.readline())
+        return rep["rc"], rep["out"]
+    return run
 
 
 @pytest.fixture(scope="session")

@@ -69,12 +69,19 @@ def test_rollout_vs_oracle(B, chunks):
     ost = O.BlokusState(B)
     for T in chunks:
         bb.rollout(T, seed)
-        O.blokus_rollout(ost, seed, first, T, n_threads=8)
+        O.blokus_rollout(ost, seed, first, T, n_threads=16)
     for k in ("occ", "inv", "score", "round", "to_move", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum"):
         want = getattr(ost, k)
         assert np.array_equal(getattr(bb, k).cpu().numpy().view(want.dtype), want), k
     if sum(chunks) >= 80:
         assert ost.n_episodes.sum() > 0
+    assert torch.equal(bb.results(), bb.results_from_columns())      # the row the kernel packs == the column statistics
+
+
+def test_rollout_full_size_vs_oracle():
+    """BASELINE config 4 at FULL size (B = 16,384) against the oracle itself: the first plies of every game (the oracle
+    plays ~600 plies/s per core, so the full batch affords a handful of plies; longer games run at small B above)."""
+    test_rollout_vs_oracle(16384, (5, 2))
 
 
 def test_rollout_full_size_properties():
@@ -179,3 +186,39 @@ def test_dropin_observation_golden(golden):
         assert np.array_equal(obs["board"], g["obs_board"][i]) and obs["board"].shape == (20, 20)
         assert np.array_equal(obs["pieces"], g["obs_pieces"][i]) and obs["pieces"].dtype == np.uint8
         assert np.array_equal(obs["score"], g["obs_score"][i]) and obs["player"].tolist() == [int(g["player"][i])]
+
+
+def test_vector_env_adapter_vs_oracle():
+    """BlokusVectorEnv (reference envs/wrappers/rllib.py:37-55 reset/step contract) played next to the oracle
+    in lockstep until games finish and restart: observation of the mover, mover, legal-action counts, reward, done, winners."""
+    import torch
+    from colosseumrl_amd.vector import BlokusVectorEnv
+    B = 24
+    env = BlokusVectorEnv(B)
+    orc = OracleBlokus(B)
+    obs, mover, n_valid = env.reset()
+    assert obs["board"].shape == (B, 20, 20) and int(n_valid[0]) == 116 and mover.tolist() == [0] * B
+    rng = np.random.default_rng(1)
+    finished = 0
+    for t in range(100):
+        c2, ids2 = orc.valid(2048)
+        assert np.array_equal(n_valid.cpu().numpy(), c2), t
+        act = np.full(B, -1, np.int32)
+        for e in range(B):
+            if c2[e]:
+                # bias towards big pieces so that games end within the test
+                act[e] = ids2[e, int(c2[e] - 1 - rng.integers(0, max(1, c2[e] // 3)))]
+        if t == 0:
+            assert np.array_equal(env.sample_valid(3).cpu().numpy() >= 0, c2 > 0)
+        obs, mover, n_valid, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        r2, t2, w2 = orc.step(act)
+        assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(done.cpu().numpy(), t2) and np.array_equal(info["winners"].cpu().numpy(), w2), t
+        if t2.any():
+            finished += int(t2.sum())
+            orc.reset(t2)
+        s2 = orc.state()
+        assert np.array_equal(mover.cpu().numpy(), s2["to_move"].astype(np.int8)), t
+        ob, op, osc = O.blokus_observe(orc.st, s2["to_move"].astype(np.int8))
+        assert np.array_equal(obs["board"].cpu().numpy(), ob) and np.array_equal(obs["pieces"].cpu().numpy(), op)
+        assert np.array_equal(obs["score"].cpu().numpy(), osc)
+    assert finished > 0

@@ -1,0 +1,68 @@
+"""The RCCL path of the end-of-rollout gather, executed on the hardware a 1-GPU box has: a world of ONE rank.
+
+colosseumrl_amd.parallel runs its single collective (all_gather_into_tensor, backend "nccl" = RCCL) whenever a process
+group is initialised, so a one-rank group exercises exactly the code the 8-GPU run uses (communicator creation, the
+device-buffer collective on the stepper's stream, the preallocated receive buffer).  The child process creates the group
+before it touches the GPU in any other way.  Multi-rank logic (shard bounds, ragged shards, global RNG ids) is covered
+on CPU by tests/test_parallel_gloo.py (gloo, world 2 and 3)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))     # RCCL communicator first, before any kernel
+from colosseumrl_amd.batched import TronBatch, TTTBatch
+from colosseumrl_amd.parallel import ShardedRollout, gather_results
+assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+B = 4096 + 7
+sr = ShardedRollout(lambda batch, first_env_id: TronBatch(20, 4, batch, device="cuda:0", first_env_id=first_env_id), B)
+sr.rollout(48, seed=3, chunk=20)
+got = sr.gather()                                                         # all_gather_into_tensor over RCCL
+want = sr.stepper.results_from_columns()
+assert got.data_ptr() != sr.stepper.results().data_ptr(), "gather() must have gone through the collective's receive buffer"
+assert torch.equal(got, want), "gathered rows differ from the local rows"
+assert int(got[:, 0].sum()) > B
+ref = TronBatch(20, 4, B, device="cuda:0")
+ref.rollout(48, seed=3)
+assert torch.equal(ref.results(), got)
+st = ShardedRollout(lambda batch, first_env_id: TTTBatch((3, 5), 3, 3, batch, device="cuda:0", first_env_id=first_env_id), 1000)
+st.rollout(40, seed=1, chunk=40)
+assert torch.equal(st.gather(), st.stepper.results_from_columns())
+t = torch.ones(8, device="cuda:0")
+dist.all_reduce(t)
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl-world1-ok")
+"""
+
+
+def test_gather_through_rccl_world_of_one(run_fresh):
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rc, out = run_fresh([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, timeout=300)
+    assert rc == 0 and "rccl-world1-ok" in out, out[-3000:]
+
+
+def test_bench_under_torchrun_world_of_one(run_fresh):
+    """bench.py launched the way the driver launches the multi-GPU case (torch.distributed.run), with one rank: the
+    process group is created, the timed region contains the RCCL gather, and the JSON line says so."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--only-headline", "--no-cpu-baseline"]
+    rc, out = run_fresh(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, timeout=600)
+    assert rc == 0, out[-3000:]
+    line = [l for l in out.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["config"]["gather"].startswith("rccl") and rec["value"] > 1e8

@@ -81,6 +81,8 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
         want = getattr(ost, k)
         have = v.cpu().numpy().view(want.dtype)
         assert np.array_equal(have, want), k
+    import torch
+    assert torch.equal(tb.results(), tb.results_from_columns())      # the row the kernel packs == the column statistics
     return ost
 
 
@@ -148,6 +150,15 @@ def test_rollout_full_size_properties(N, T):
     half.rollout(T, seed)
     assert torch.equal(half.board, tb.board[B // 2:]) and torch.equal(half.ret_sum, tb.ret_sum[:, B // 2:])
     assert torch.equal(half.n_episodes, tb.n_episodes[B // 2:])
+
+
+@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "bits"), (40, (32,), "auto"), (40, (300,), "auto")])
+def test_rollout_full_size_vs_oracle(N, chunks, kernel):
+    """BASELINE config 2 / the config-5 shard at FULL size (B = 65,536, P = 4) against the oracle itself, not only through
+    invariants: every state array and every statistic, bit for bit (the oracle needs ~10-100 ms per launch on 8 threads).
+    T = 300 on 40x40 is the bitboard kernel with its replay epilogue; 20x20 'bits' pins the bitboard kernel there."""
+    ost = _rollout_pair(N, 4, 65536, chunks, seed=20261004, first=3 * 65536, kernel=kernel)
+    assert ost.n_episodes.sum() > 65536
 
 
 def test_dropin_env_golden(golden):
@@ -278,3 +289,69 @@ def test_observe_all_matches_per_player_observe(N, P, B):
         assert torch.equal(allobs["board"][p], one["board"]) and torch.equal(allobs["heads"][p], one["heads"])
         assert np.array_equal(allobs["heads"][p].cpu().numpy(), oh) and np.array_equal(allobs["directions"][p].cpu().numpy(), od)
         assert np.array_equal(allobs["deaths"][p].cpu().numpy(), ok)
+
+
+@pytest.mark.parametrize("N,P,B", [(20, 4, 5000 + 3), (40, 4, 1000), (12, 3, 300), (28, 7, 130), (8, 2, 65), (4, 2, 70),
+                                   (9, 6, 777), (13, 8, 300), (16, 8, 200)])
+def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
+    """crl_tron_step_observe (one launch: [sample ->] next_state -> state_to_observation of all P players) equals
+    crl_tron_sample + crl_tron_step + crl_tron_observe_all on a twin batch and the oracle stepped in lockstep: 64 and 16
+    games per workgroup (LDS limit), ragged batches, auto-reset on and off, external and sampled actions, and the
+    boards / player counts that take the unfused path internally (N*N % 16 != 0, P = 8)."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    seed, first = 77, 900
+    fused_path = (N * N) % 16 == 0 and P <= 7
+    a, b = TronBatch(N, P, B, first_env_id=first), TronBatch(N, P, B, first_env_id=first)
+    sh, sd = O.tron_start_positions(N, P)
+    orc = OracleTron(N, P, B, sh, sd)
+    ost = orc.st
+    rng = np.random.default_rng(N * 10 + P)
+    out = None
+    resets = 0
+    for t in range(26):
+        auto = (t % 5) != 4
+        sampled = fused_path and (t % 2 == 0)
+        if sampled:
+            act = b.sample(seed)                                     # advances b.tcount; the fused call advances a.tcount
+            out = a.step_observe(None, seed=seed, auto_reset=auto, out=out)
+        else:
+            act = torch.from_numpy(rng.integers(-1, 2, size=(P, B)).astype(np.int8)).cuda()
+            out = a.step_observe(act, seed=seed, auto_reset=auto, out=out)
+        rew, term, win = b.step(act, auto_reset=auto)
+        obs = b.observe_all()
+        for k in ("board", "heads", "dirs", "deaths", "tcount"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (k, t)
+        assert torch.equal(out["rewards"], rew) and torch.equal(out["terminal"], term) and torch.equal(out["winners"], win), t
+        for k in ("board", "heads", "directions", "deaths"):
+            assert torch.equal(out[k], obs[k]), (k, t)
+        r2, t2, w2 = orc.step(act.cpu().numpy(), auto_reset=auto)
+        assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(term.cpu().numpy(), t2) and np.array_equal(win.cpu().numpy(), w2)
+        if auto:
+            resets += int(t2.sum())
+        assert np.array_equal(a.board.cpu().numpy(), ost.board) and np.array_equal(a.heads.cpu().numpy(), ost.heads), t
+        assert np.array_equal(a.deaths.cpu().numpy(), ost.deaths) and np.array_equal(a.dirs.cpu().numpy(), ost.dirs), t
+        for p in (0, P - 1):
+            ob, oh, od, ok = O.tron_observe(ost, np.full(B, p, np.int8))
+            assert np.array_equal(out["board"][p].reshape(B, -1).cpu().numpy(), ob) and np.array_equal(out["heads"][p].cpu().numpy(), oh)
+            assert np.array_equal(out["directions"][p].cpu().numpy(), od) and np.array_equal(out["deaths"][p].cpu().numpy(), ok)
+    assert resets > 0
+    if not fused_path:
+        from colosseumrl_amd import _native
+        with pytest.raises(_native.NativeError):
+            a.step_observe(None, seed=seed)                          # the unfused path needs explicit actions
+
+
+def test_step_observe_full_size_equals_rollout():
+    """BASELINE config 2 at full size: T x fused step_observe(sampled actions) leaves the state crl_tron_rollout(T) leaves."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    B, T, seed = 65536, 24, 5
+    a, b = TronBatch(20, 4, B), TronBatch(20, 4, B)
+    out = None
+    for _ in range(T):
+        out = a.step_observe(None, seed=seed, out=out)
+    b.rollout(T, seed)
+    for k in ("board", "heads", "dirs", "deaths", "tcount"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(out["board"], b.observe_all()["board"])

@@ -57,6 +57,14 @@ def test_rollout_vs_oracle(dims, K, P, B, chunks):
         want = getattr(ost, k)
         assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
     assert ost.n_episodes.sum() > B
+    import torch
+    assert torch.equal(tb.results(), tb.results_from_columns())      # the row the kernel packs == the column statistics
+
+
+@pytest.mark.parametrize("dims,K,P", [((5, 5), 4, 3), ((3, 5), 3, 3)])
+def test_rollout_full_size_vs_oracle(dims, K, P):
+    """BASELINE config 3 at FULL size (B = 262,144; 5x5 K4 and the reference-pinned 3x5 K3) against the oracle itself."""
+    test_rollout_vs_oracle(dims, K, P, 262144, (24, 8))
 
 
 def test_rollout_full_size_properties():
@@ -119,24 +127,55 @@ def test_observation_golden(golden, name, env_name):
         assert np.array_equal(obs["board"].ravel(), want)
 
 
-def test_vector_env_adapters():
+def test_vector_env_adapters_vs_oracle():
+    """The vector-env adapters (colosseumrl_amd.vector; reference envs/wrappers/rllib.py:37-55 reset/step contract) played
+    for whole episodes next to the oracle stepped in lockstep: observations, rewards, dones, winners, auto-reset."""
     import torch
+    from backends import OracleTron
     from colosseumrl_amd.vector import TicTacToeVectorEnv, TronVectorEnv
-    env = TronVectorEnv(12, 4, 256)
+    N, P, B = 12, 4, 256 + 9
+    env = TronVectorEnv(N, P, B)
+    sh, sd = O.tron_start_positions(N, P)
+    orc = OracleTron(N, P, B, sh, sd)
     obs = env.reset()
-    assert obs[0]["board"].shape == (256, 12, 12) and int(obs[2]["board"].max()) == 4
+    assert obs[0]["board"].shape == (B, N, N) and int(obs[2]["board"].max()) == P
+    rng = np.random.default_rng(0)
     done_total = 0
-    for t in range(30):
-        a = torch.randint(-1, 2, (4, 256), dtype=torch.int8, device="cuda")
-        obs, rew, done, info = env.step(a)
-        done_total += int(done.sum())
-        assert rew.shape == (4, 256) and ((info["winners"] == 0) | (done == 1)).all()
-    assert done_total > 0
-    tenv = TicTacToeVectorEnv((3, 3), 3, 2, 512)
+    for t in range(40):
+        a = rng.integers(-1, 2, size=(P, B)).astype(np.int8)
+        obs, rew, done, info = env.step(torch.from_numpy(a).cuda())
+        r2, t2, w2 = orc.step(a, auto_reset=True)
+        assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(done.cpu().numpy(), t2)
+        assert np.array_equal(info["winners"].cpu().numpy(), w2)
+        for p in range(P):
+            ob, oh, od, ok = O.tron_observe(orc.st, np.full(B, p, np.int8))
+            assert np.array_equal(obs[p]["board"].reshape(B, -1).cpu().numpy(), ob) and np.array_equal(obs[p]["heads"].cpu().numpy(), oh)
+            assert np.array_equal(obs[p]["directions"].cpu().numpy(), od) and np.array_equal(obs[p]["deaths"].cpu().numpy(), ok)
+        done_total += int(t2.sum())
+    assert done_total > B
+
+    dims, K, PT, BT = (3, 5), 3, 3, 512 + 3
+    tenv = TicTacToeVectorEnv(dims, K, PT, BT)
+    ot = OracleTTT(dims, K, PT, BT)
     obs, mover, valid = tenv.reset()
-    assert int(valid[0]) == 0x1ff and obs["board"].shape == (512, 9)
-    for t in range(12):
+    assert int(valid[0]) == (1 << 15) - 1 and obs["board"].shape == (BT, 15)
+    finished = 0
+    for t in range(40):
         empties = valid.cpu().numpy().view(np.uint32)
-        act = np.array([int(np.log2(int(e) & -int(e))) if e else -1 for e in empties], dtype=np.int8)   # first empty cell
+        assert np.array_equal(empties, ot.valid())
+        act = np.full(BT, -1, np.int8)
+        for e in range(BT):
+            cells = [c for c in range(15) if (int(empties[e]) >> c) & 1]
+            if cells and rng.random() < 0.95:
+                act[e] = cells[int(rng.integers(0, len(cells)))]
+            elif rng.random() < 0.5:
+                act[e] = int(rng.integers(0, 15))                      # sometimes an occupied cell: a no-op that passes the turn
         obs, mover, valid, rew, done, info = tenv.step(torch.from_numpy(act).cuda())
-    assert int(tenv.batch.n_episodes.sum()) == 0 and int(done.sum()) >= 0
+        r2, t2, w2 = ot.step(act, auto_reset=True)
+        assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(done.cpu().numpy(), t2) and np.array_equal(info["winners"].cpu().numpy(), w2)
+        assert np.array_equal(mover.cpu().numpy(), ot.to_move())
+        ab = ot.board().reshape(BT, -1).astype(np.int64)                # absolute ids; the observation is relative to the mover
+        want = np.where(ab >= 0, (ab - ot.to_move().astype(np.int64)[:, None]) % PT, -1)     # reference 2p:26-27,382-407
+        assert np.array_equal(obs["board"].cpu().numpy().astype(np.int64), want)
+        finished += int(t2.sum())
+    assert finished > BT

@@ -109,3 +109,32 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
                 assert "/root/reference" not in text, f
+
+
+def test_no_compiled_reference_inside_the_repo():
+    """A Python reference must not travel to the GPU box in any form: oracle/build_ref.py compiles the reference's
+    Cython kernel into a scratch directory outside the repository and __graft_entry__.build() does not build it."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = [p for p in glob.glob(os.path.join(root, "**", "CyTronGrid*"), recursive=True)]
+    assert hits == [], hits
+    from oracle import build_ref
+    assert not os.path.abspath(build_ref.REF_DIR).startswith(root + os.sep)
+
+
+@pytest.mark.parametrize("name,env_name", [("2p", "tictactoe"), ("3p", "tictactoe_3p"), ("4p", "tictactoe_4p")])
+def test_tictactoe_current_rewards_golden(golden, name, env_name):
+    """current_rewards (reference tictactoe_2p_env.py:219-238, 3p :220-239, 4p :250-269) against values the
+    reference itself returned on states of its own games (tests/golden/ttt_rewards_*.npz, oracle/gen_golden.py).
+    Pure host logic: no GPU involved."""
+    g = golden("ttt_rewards_" + name)
+    env = colosseumrl_amd.get_environment(env_name)()
+    shape = tuple(int(x) for x in g["shape"])
+    assert env.max_players == int(g["P"])
+    seen = set()
+    for board, winner, want in zip(g["board"], g["winner"], g["rewards"]):
+        state = (board.reshape(shape), None if winner < 0 else int(winner))
+        got = env.current_rewards(state)
+        assert got == want.tolist() and all(isinstance(r, int) for r in got)
+        seen.add(int(winner))
+    assert seen == set(range(-1, env.max_players))          # undecided states and every possible winner are covered

@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B the Blokus kernels' register budget on the GPU box: rebuild blokus.o with different waves/SIMD and bench.
-set -e
-cd colosseumrl_amd/csrc
+# A/B the Blokus kernels' register budget on the GPU box: one scratch build per waves/SIMD (tools/diag_build.sh), loaded
+# through CRL_LIB_PATH; the in-tree objects and the shipped library are never touched.
+set -euo pipefail
 for occ in 4 5 6 8; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DBLK_WAVES_PER_SIMD=$occ -c blokus.hip -o blokus.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libcolosseum_hip.so capi.o tron.o ttt.o blokus.o
+  LIB=$(tools/diag_build.sh occ$occ -DBLK_WAVES_PER_SIMD=$occ)
   echo "== waves/SIMD $occ"
-  (cd ../.. && python bench.py --workload blokus_p4_b16384 --steps 256 --warmup 32 --chunk 64 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,1), 'M env-steps/s', round(d['ms_per_step'],4), 'ms/step')")
+  CRL_LIB_PATH=$LIB python3 bench.py --workload blokus_p4_b16384 --steps 256 --warmup 32 --chunk 64 --only-headline --no-cpu-baseline 2>/dev/null \
+    | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,1), 'M env-steps/s', round(d['ms_per_step'],4), 'ms/step')"
 done

@@ -1,11 +1,10 @@
 #!/bin/bash
 # Diagnostic (GPU box): build blokus.hip with -DBLK_STAMPS, run a rollout, print per-phase cycle shares.
-set -e
-cd colosseumrl_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DBLK_STAMPS -c blokus.hip -o blokus.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libcolosseum_hip.so capi.o tron.o ttt.o blokus.o
-cd ../..
-python - <<'PY'
+# The instrumented library is built into a scratch directory and loaded through CRL_LIB_PATH: the in-tree objects and
+# the shipped libcolosseum_hip.so are never touched.
+set -euo pipefail
+export CRL_LIB_PATH=$(tools/diag_build.sh stamps -DBLK_STAMPS)
+python3 - <<'PY'
 import ctypes as C, torch
 from colosseumrl_amd import _native
 from colosseumrl_amd.batched import BlokusBatch

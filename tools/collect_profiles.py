@@ -2,7 +2,7 @@
 """Copy the summaries tools/profile_bench.sh left under gpurun_out/prof_<tag>/ into profiles/<prefix>_* and, for
 bench workloads, write profiles/traffic_<workload>.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes,
 FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).
-usage: tools/collect_profiles.py <tag> <prefix> [<workload> <kernel substring> <steps_per_launch>]"""
+usage: tools/collect_profiles.py <tag> <prefix> [<workload> <kernel substring> <steps_per_launch> [<games>]]"""
 import glob
 import json
 import os
@@ -33,13 +33,28 @@ if len(sys.argv) > 3:
             return find(counter)[1]
         except SystemExit:
             return None
-    out = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip(), "workload": workload,
+    games = int(sys.argv[6]) if len(sys.argv) > 6 else None
+    rec = {"kernel": name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip(),
            "steps_per_launch": spl, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
            "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
            "valu_insts_per_launch": opt("SQ_INSTS_VALU"), "salu_insts_per_launch": opt("SQ_INSTS_SALU"),
            "lds_insts_per_launch": opt("SQ_INSTS_LDS"), "waves_per_launch": opt("SQ_WAVES"),
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-dispatch average over %d-step launches; "
-                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B); source: profiles/%s_rocprofv3_summary.json"
-                   % (spl, prefix)}
-    json.dump(out, open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
-    print(json.dumps(out))
+           "source": "profiles/%s_rocprofv3_summary.json" % prefix}
+    if games:
+        rec["games"] = games
+    path = os.path.join(dst, "traffic_%s.json" % workload)
+    try:
+        out = json.load(open(path))
+    except Exception:
+        out = {}
+    if "launch_shapes" not in out:                       # round-1 format (one launch shape per file) -> keep it as a shape
+        old = {k: v for k, v in out.items() if k not in ("workload", "note")}
+        out = {"workload": workload, "launch_shapes": ({str(old["steps_per_launch"]): old} if old.get("steps_per_launch") else {})}
+    out["workload"] = workload
+    out["note"] = ("per launch shape (env-steps fused into one launch): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and SQ "
+                   "instruction counters, per-dispatch averages of the workload's dominant kernel; hbm_bytes_per_launch = "
+                   "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-B requests as 64 B); "
+                   "bench.py attaches a shape's record only to launches of exactly that many steps")
+    out["launch_shapes"][str(spl)] = rec
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(rec))

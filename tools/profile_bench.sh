@@ -1,12 +1,14 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel trace + PMC passes for one bench workload.
 # Usage: tools/profile_bench.sh <tag> [bench args...]; writes CSV summaries under gpurun_out/prof_<tag>/
+# (bench.py runs with --only-headline: just the contract's timed region of ONE workload, so every dispatch of the dominant
+#  kernel in a pass has the same launch shape; pass --only-step-api instead of a workload to profile the per-step API)
 set -e
 TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--no-cpu-baseline $@"
+ARGS="--no-cpu-baseline --only-headline $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py $ARGS > $OUT/bench_pmc_sq2.log 2>&1

@@ -1,18 +1,79 @@
-// Micro-benchmark: sustained integer VALU issue rate per SIMD vs waves per SIMD on gfx950.
-// Build: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o valu_rate ; run on the GPU box.
+// Calibration micro-benchmark for the `valu_issue` roofline of bench.py (gfx950 / MI355X).
+//
+// Measures, at 1 / 2 / 4 / 8 waves per SIMD on every CU, how many wave64 instructions per second the chip issues for
+//   mix "valu"  : independent 32-bit integer VALU instructions only (v_add_u32 / v_xor_b32 on 8 chains);
+//   mix "tron"  : the instruction mix of the Tron rollout loop per PMC (profiles/r1_tron_n20: 175 VALU : 30 SALU : 16 LDS
+//                 per wave-step): per block 11 VALU (2 of them v_cmp -> SGPR pair, 2 v_cndmask reading one), 2 SALU
+//                 (s_and_b64 / s_or_b64 on lane masks) and 1 ds_read_u8, the LDS result consumed at the block's end.
+// The shader clock is measured in the kernel (s_memtime ticks per s_memrealtime tick x 100 MHz), so the result is
+// quoted both as wave-instructions per second (what bench.py divides by) and as cycles per instruction per SIMD.
+// Everything is inline asm so the compiler can neither fuse nor drop instructions.
+//
+// Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// Prints one JSON object (committed as profiles/r2_valu_issue_calibration.json).
 #include <hip/hip_runtime.h>
-#include <stdio.h>
 #include <stdint.h>
+#include <stdio.h>
 
-__global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, int iters)
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int kValuPerIter = 64;      // mix "valu": 64 VALU per loop iteration
+constexpr int kBlocksPerIter = 8;     // mix "tron": 8 blocks of (11 VALU + 2 SALU + 1 LDS) per loop iteration
+
+__global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *clk, int iters)
 {
     uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t c = blockIdx.x | 1u;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {   // 64 independent-ish 32-bit adds/xors per iteration (8 chains)
-            a0 = (a0 ^ a1) + 0x9e3779b9u; a1 = (a1 ^ a2) + 0x7f4a7c15u; a2 = (a2 ^ a3) + 0x85ebca6bu; a3 = (a3 ^ a4) + 0xc2b2ae35u;
-            a4 = (a4 ^ a5) + 0x27d4eb2fu; a5 = (a5 ^ a6) + 0x165667b1u; a6 = (a6 ^ a7) + 0xd3a2646cu; a7 = (a7 ^ a0) + 0xfd7046c5u;
-        }
+        asm volatile(
+            ".rept 4\n"
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            "v_xor_b32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+            "v_xor_b32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+            ".endr\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+__global__ void __launch_bounds__(256) tron_mix_kernel(uint32_t *out, uint64_t *clk, int iters)
+{
+    __shared__ uint32_t cells[256 * 5];              // odd dword stride per lane, like the rollout's slabs
+    for (int j = 0; j < 5; ++j) cells[threadIdx.x * 5 + j] = threadIdx.x + j;
+    __syncthreads();
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = 0, a7 = 0;
+    const uint32_t c = blockIdx.x | 1u;
+    uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)cells + threadIdx.x * 20;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(
+            ".rept 8\n"
+            "ds_read_u8 %6, %9\n"                                            // 1 LDS (byte probe)
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n"      // 7 plain VALU
+            "v_bfe_i32 %3, %3, 3, 8\n v_xor_b32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_and_b32 %3, 0xff, %3\n"
+            "v_cmp_eq_u32 s[20:21], %0, %1\n"                                // 2 compares into SGPR pairs
+            "v_cmp_lt_u32 s[22:23], %2, %4\n"
+            "s_and_b64 s[20:21], s[20:21], s[22:23]\n"                       // 2 SALU on lane masks
+            "s_or_b64 s[22:23], s[22:23], exec\n"
+            "v_cndmask_b32 %5, %5, %0, s[20:21]\n"                           // 2 selects reading them
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_cndmask_b32 %7, %7, %6, s[22:23]\n"                           // consumes the LDS byte
+            ".endr\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+            : "v"(c), "v"(addr)
+            : "s20", "s21", "s22", "s23", "scc", "memory");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
@@ -20,23 +81,44 @@ __global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, int iters)
 int main()
 {
     uint32_t *out;
-    hipMalloc(&out, 256 * 8 * 256 * 4 * sizeof(uint32_t));
-    const int iters = 20000;
-    const double ops_per_thread = (double)iters * 8 * 8 * 2;   // xor + add
-    for (int wps = 1; wps <= 8; wps *= 2) {
-        const int blocks = 256 * wps;                          // 256 CUs x wps blocks of 4 waves = wps waves per SIMD
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, 100);
-        hipDeviceSynchronize();
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double wave_instr_per_simd = ops_per_thread * wps;                 // each SIMD runs wps waves
-        const double cycles = ms * 1e-3 * 2.4e9;
-        printf("waves/SIMD %d: %.3f ms, %.2f cycles per wave64 VALU instruction per SIMD (at 2.4 GHz)\n", wps, ms, cycles / wave_instr_per_simd);
+    uint64_t *clk;
+    CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(uint32_t)));
+    CHECK(hipMalloc(&clk, 2 * sizeof(uint64_t)));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int iters = 40000;
+    printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"note\": \"wave64 instructions per second, whole chip; "
+           "cycles = shader cycles per instruction per SIMD at the in-kernel clock\", \"mixes\": {", prop.gcnArchName, cus, cus * 4);
+    for (int mix = 0; mix < 2; ++mix) {
+        printf("%s\"%s\": [", mix ? ", " : "", mix ? "tron" : "valu");
+        for (int wps = 1; wps <= 8; wps *= 2) {
+            const int blocks = cus * wps;                          // wps blocks of 4 waves per CU = wps waves per SIMD
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            for (int rep = 0; rep < 2; ++rep) {                    // rep 0 warms up (clock ramp), rep 1 is timed
+                CHECK(hipEventRecord(e0));
+                if (mix == 0) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+                else hipLaunchKernelGGL(tron_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+            }
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            uint64_t h[2];
+            CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+            const double ghz = (double)h[0] / (double)h[1] * 0.1;
+            const double valu_per_wave = (double)iters * (mix ? kBlocksPerIter * 11 : kValuPerIter);
+            const double all_per_wave = (double)iters * (mix ? kBlocksPerIter * 14 : kValuPerIter);
+            const double waves = (double)blocks * 4;
+            const double s = ms * 1e-3;
+            printf("%s{\"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"valu_wave_insts_per_s\": %.4e, "
+                   "\"all_wave_insts_per_s\": %.4e, \"cycles_per_valu_per_simd\": %.3f, \"cycles_per_inst_per_simd\": %.3f}",
+                   wps > 1 ? ", " : "", wps, ms, ghz, valu_per_wave * waves / s, all_per_wave * waves / s,
+                   s * ghz * 1e9 / (valu_per_wave * wps), s * ghz * 1e9 / (all_per_wave * wps));
+        }
+        printf("]");
     }
+    printf("}}\n");
     return 0;
 }
