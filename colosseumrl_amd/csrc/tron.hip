@@ -679,36 +679,49 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
         asm volatile("" : "+v"(rowpat[j]));
     }
     // ---- copy in: walls everywhere, then the cells.  Canonical HBM cells are tag 0.
-    for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
+    // The wave streams its 64 boards as one contiguous run, 16 bytes per lane and load (coalesced), and scatters the
+    // dwords into the owners' slabs (a 16-byte piece never straddles two boards, its dwords may change row).  A lone
+    // wave per SIMD hides HBM latency only through its own loads in flight, so the first kCopyBatch loads (all 25 of a
+    // 20x20 launch) are issued BEFORE the wall fill and scattered after it; short launches are dominated by this copy.
+    constexpr int kCopyBatch = 26;
+    const int8_t *gslab_in = board + env0 * NN;
+    const int slab0_in = mine - lane * pad.stride;
+    const int bytes_in = n_env * NN;
+    uint4 cin[kCopyBatch];
     if (wide) {
-        // the wave streams its 64 boards as one contiguous run, 16 bytes per lane and load (coalesced), and scatters
-        // the dwords into the owners' slabs (a 16-byte piece never straddles two boards, its dwords may change row)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wall fill above vs other lanes' cell writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int8_t *gslab = board + env0 * NN;
-        const int slab0 = mine - lane * pad.stride;
-        const int bytes = n_env * NN;
-#pragma unroll 5
-        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+#pragma unroll
+        for (int k = 0; k < kCopyBatch; ++k) {
+            const int off = lane * 16 + k * (CRL_WAVE * 16);
+            cin[k] = off < bytes_in ? *reinterpret_cast<const uint4 *>(gslab_in + off) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wall fill above vs other lanes' cell writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wide) {
+        auto scatter = [&](const uint4 &v, const int off) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
             const int cq = (off - e * NN) >> 2;                 // first cell dword of the piece
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                *(lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
+                *(lds_u32 *)(uintptr_t)(uint32_t)(slab0_in + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
             }
+        };
+#pragma unroll
+        for (int k = 0; k < kCopyBatch; ++k) {
+            const int off = lane * 16 + k * (CRL_WAVE * 16);
+            if (off < bytes_in) scatter(cin[k], off);
         }
+#pragma unroll 5
+        for (int off = lane * 16 + kCopyBatch * (CRL_WAVE * 16); off < bytes_in; off += CRL_WAVE * 16)   // boards above 20x20
+            scatter(*reinterpret_cast<const uint4 *>(gslab_in + off), off);
     } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int8_t *gslab = board + env0 * NN;
-        const int slab0 = mine - lane * pad.stride;
         for (int e = 0; e < n_env; ++e)
             for (int c = lane; c < NN; c += CRL_WAVE) {
                 const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
+                *(lds_u8 *)(uintptr_t)(uint32_t)(slab0_in + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab_in[(int64_t)e * NN + c];
             }
     }
     // heads as LDS addresses
@@ -1546,7 +1559,7 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
         for (int u = 0; u < 4; ++u) {
             const int c = base + u * 256;
             const int cc = c < total ? c : 0;
-            const int e = (int)__umulhi((uint32_t)cc, inv_cp);
+            const int e = cp == 1 ? cc : (int)__umulhi((uint32_t)cc, inv_cp);
             const int off = (cc - e * cp) << 4;
             dst[u] = c < total ? e * SLAB + off : -1;
             v[u] = *reinterpret_cast<const uint4 *>(board + (g0 + e) * NN + off);
@@ -1619,7 +1632,7 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
     }
     const int64_t plane = B * (int64_t)NN;                      // one observer's boards
     for (int c = threadIdx.x; c < total; c += 256) {
-        const int e = (int)__umulhi((uint32_t)c, inv_cp);
+        const int e = cp == 1 ? c : (int)__umulhi((uint32_t)c, inv_cp);
         const int off = (c - e * cp) << 4;
         uint4 v = *reinterpret_cast<const uint4 *>(lds + e * SLAB + off);
         const int64_t gofs = (g0 + e) * NN + off;
@@ -1920,7 +1933,8 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
     const int slab = NN + 16;
     const int G = (64 * slab + 64 <= 48 * 1024) ? 64 : (16 * slab + 16 <= 48 * 1024) ? 16 : 0;
     if ((NN % 16) == 0 && cfg.P <= 7 && G > 0) {
-        const uint32_t inv_cp = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;     // exact for chunk ids < 2^16
+        // floor(2^32 / chunks per board) + 1: exact quotients for chunk ids < 2^16 (one chunk per board: unused)
+        const uint32_t inv_cp = NN == 16 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;
         const size_t lds_bytes = (size_t)G * slab + G;
         const dim3 grid(blocks_for(B, G));
         switch (cfg.P) {
