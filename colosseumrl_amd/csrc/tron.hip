@@ -644,6 +644,29 @@ struct LdsBoard {
     __device__ __forceinline__ void put(const int a, const int who) const { *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)(tagbits | (uint32_t)who); }
 };
 
+// Slab byte offsets (relative to the slab start) of the four dwords of a 16-byte piece of a board whose first cell
+// dword is cq: cell dword d = row d / nq, dword d % nq of that row (nq = N / 4); slab rows are RS bytes apart and
+// row 0 is wall.  One exact division for the piece; its other dwords follow by carry (a piece crosses at most one
+// row boundary when a row has at least 4 dwords), which is what keeps the copy loops short.
+template <int RS>
+__device__ __forceinline__ void tron_piece_offsets(const int cq, const int nq, const uint32_t inv_nq, int (&o)[4])
+{
+    const int y0 = (int)__umulhi((uint32_t)cq, inv_nq);
+    const int r0 = cq - y0 * nq;
+    const int base = (y0 + 1) * RS + 4 * r0;
+    if (nq >= 4) {                                              // wave-uniform
+        const int wrap = RS - 4 * nq;                           // extra bytes on entering the next row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = base + 4 * q + ((r0 + q >= nq) ? wrap : 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int y = (int)__umulhi((uint32_t)(cq + q), inv_nq);
+            o[q] = (y + 1) * RS + 4 * (cq + q - y * nq);
+        }
+    }
+}
+
 template <int P, int RS>
 __global__ void __launch_bounds__(256)
 tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
@@ -702,12 +725,11 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
         auto scatter = [&](const uint4 &v, const int off) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-            const int cq = (off - e * NN) >> 2;                 // first cell dword of the piece
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            const int sb = slab0_in + e * pad.stride;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                *(lds_u32 *)(uintptr_t)(uint32_t)(slab0_in + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
-            }
+            for (int q = 0; q < 4; ++q) *(lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]) = w[q];
         };
 #pragma unroll
         for (int k = 0; k < kCopyBatch; ++k) {
@@ -822,13 +844,14 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
 #pragma unroll 5
         for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
             const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-            const int cq = (off - e * NN) >> 2;
-            const uint32_t trep = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + pad.junk) * 0x01010101u;
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            const int sb = slab0 + e * pad.stride;
+            const uint32_t trep = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk) * 0x01010101u;
             uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
+                const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]);
                 const uint32_t diff = ((c4 >> OB) & TM) ^ trep;                  // per byte: 0 iff the tag matches
                 const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u; // per byte: 1 iff diff != 0 (diff <= 0x1f)
                 w[q] = c4 & OM & ~(stale * 0xffu);
@@ -1219,13 +1242,11 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
                 const int bytes = n_out * NN;
                 for (int off = (int)threadIdx.x * 16; off < bytes; off += 256 * 16) {
                     const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                    const int cq = (off - e * NN) >> 2;
+                    int o[4];
+                    tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
                     uint32_t w[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                        w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2)));
-                    }
+                    for (int q = 0; q < 4; ++q) w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + o[q]);
                     *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             } else {

@@ -20,12 +20,15 @@
 constexpr int kValuPerIter = 64;      // mix "valu": 64 VALU per loop iteration
 constexpr int kBlocksPerIter = 8;     // mix "tron": 8 blocks of (11 VALU + 2 SALU + 1 LDS) per loop iteration
 
-__global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *clk, int iters)
+// `half` != 0: only lanes 0..31 of every wave execute the loop (EXEC = 0x00000000ffffffff) -- does a half-empty wave64
+// issue faster on the SIMD-32 (i.e. is the second 32-lane pass skipped)?
+__global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *clk, int iters, int half)
 {
     uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const uint32_t c = blockIdx.x | 1u;
     uint64_t t0 = 0, r0 = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (half && (threadIdx.x & 32)) iters = 0;
     for (int i = 0; i < iters; ++i) {
         asm volatile(
             ".rept 4\n"
@@ -90,15 +93,15 @@ int main()
     const int iters = 40000;
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"note\": \"wave64 instructions per second, whole chip; "
            "cycles = shader cycles per instruction per SIMD at the in-kernel clock\", \"mixes\": {", prop.gcnArchName, cus, cus * 4);
-    for (int mix = 0; mix < 2; ++mix) {
-        printf("%s\"%s\": [", mix ? ", " : "", mix ? "tron" : "valu");
+    for (int mix = 0; mix < 3; ++mix) {
+        printf("%s\"%s\": [", mix ? ", " : "", mix == 1 ? "tron" : mix == 2 ? "valu_half_exec" : "valu");
         for (int wps = 1; wps <= 8; wps *= 2) {
             const int blocks = cus * wps;                          // wps blocks of 4 waves per CU = wps waves per SIMD
             hipEvent_t e0, e1;
             CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; ++rep) {                    // rep 0 warms up (clock ramp), rep 1 is timed
                 CHECK(hipEventRecord(e0));
-                if (mix == 0) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+                if (mix != 1) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 2);
                 else hipLaunchKernelGGL(tron_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
@@ -108,8 +111,8 @@ int main()
             uint64_t h[2];
             CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
             const double ghz = (double)h[0] / (double)h[1] * 0.1;
-            const double valu_per_wave = (double)iters * (mix ? kBlocksPerIter * 11 : kValuPerIter);
-            const double all_per_wave = (double)iters * (mix ? kBlocksPerIter * 14 : kValuPerIter);
+            const double valu_per_wave = (double)iters * (mix == 1 ? kBlocksPerIter * 11 : kValuPerIter);
+            const double all_per_wave = (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
             const double waves = (double)blocks * 4;
             const double s = ms * 1e-3;
             printf("%s{\"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"valu_wave_insts_per_s\": %.4e, "
