@@ -897,7 +897,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
 // on boards above 20x20 (where bitboards fit four times the games of byte slabs into a CU's LDS).
 // A 32-bit row holds boards up to 30x30, but the replay slabs limit it to the byte kernel's sizes (20 / 40).
 struct TronBits {
-    int stride;      // bytes per bit slab: kMaxW pattern words + junk, a multiple of 16 (the reset stores 16 bytes at a time)
+    int stride;      // bytes per game: two bit slabs of kMaxW pattern words + junk, a multiple of 16 (16-byte rewrite stores)
     uint32_t inv_s;  // floor(2^32 / (N + 1)) + 1
 };
 
@@ -948,11 +948,18 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
     __syncthreads();
     // ... and the start layout (walls + heads) in registers, for resets
+    // Two bit slabs per game: the one being played on (`cur`) and a spare that always holds -- or is on its way to
+    // holding -- the start layout.  A reset is a swap of the two; the slab just retired is rewritten with the start
+    // layout by ALL lanes together, one quarter per step (kPerGroup 16-byte stores), so it is fresh again four steps
+    // later, before the shortest episode can end.  (Rewriting a whole slab at every reset, as the first version did,
+    // costs kChunks exec-masked 16-byte stores per wave-step -- some lane of a wave resets on practically every step --
+    // each at the price of a full-width store: the LDS pipe was 41 % busy with them.)
+    constexpr int kChunks = kMaxW / 4, kPerGroup = (kChunks + 3) / 4, kSlab = kMaxW * 4;
     uint32_t fresh[kMaxW];
 #pragma unroll
     for (int j = 0; j < kMaxW; ++j) {
         uint32_t w = wall_words[j];
-        *(lds_u32 *)(uintptr_t)(uint32_t)(mine + 4 * j) = w;    // this lane's slab starts out empty
+        *(lds_u32 *)(uintptr_t)(uint32_t)(mine + 4 * j) = w;    // this lane's first slab starts out empty
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int fh = cfg.start_heads[p];
@@ -962,8 +969,12 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         }
         fresh[j] = w;
         asm volatile("" : "+v"(fresh[j]));                      // VGPRs, not SGPRs: the reset stores them as they are
+        *(lds_u32 *)(uintptr_t)(uint32_t)(mine + kSlab + 4 * j) = w;   // the spare slab: start layout
     }
-    const int junk_row = mine + 4 * kMaxW;                      // a word nobody reads
+    const int junk_row = mine + 2 * kSlab;                      // a word nobody reads
+    int cur = mine;                                             // slab in play; the spare is cur ^ flip
+    const int flip = mine ^ (mine + kSlab);
+    uint32_t clean = 0xfu;                                      // quarters of the spare rewritten since the last swap
     // ---- copy in: the wave ORs the occupied cells of its 64 boards into the slabs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1016,7 +1027,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         dead[p] = __builtin_amdgcn_ballot_w64(valid ? (deaths[p * B + bb] != 0) : true);
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
-        fresh_pos[p] = 8 * mine + (fy + 1) * S + (fh - fy * N);
+        fresh_pos[p] = (fy + 1) * S + (fh - fy * N);             // bit index inside a slab
         fresh_dir[p] = cfg.start_dirs[p];
         asm volatile("" : "+v"(fresh_pos[p]), "+v"(fresh_dir[p]));
     }
@@ -1078,19 +1089,48 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         }
         const uint64_t term_m = __builtin_amdgcn_ballot_w64(alive <= 1) & valid_m;      // TronGridEnvironment.py:309-321
         acc.ts += 1;
-        if (term_m) {                                           // some game of the wave ended
-            if (__builtin_amdgcn_inverse_ballot_w64(term_m)) {  // new_state: the whole board from the register pattern
-                last_alive = (int)alive_bits;
+        // every lane rewrites quarter (t & 3) of its spare slab with the start layout (wave-uniform quarter: the
+        // pattern words are plain register operands)
+        auto rewrite = [&](const int grp, const int base) {
 #pragma unroll
-                for (int j = 0; j < kMaxW; j += 4)
-                    *(lds_u128 *)(uintptr_t)(uint32_t)(mine + 4 * j) = (u32x4){fresh[j], fresh[j + 1], fresh[j + 2], fresh[j + 3]};
+            for (int c = 0; c < kPerGroup; ++c) {
+                const int j = 4 * (grp * kPerGroup + c);
+                if (j < kMaxW)
+                    *(lds_u128 *)(uintptr_t)(uint32_t)(base + 4 * j) = (u32x4){fresh[j], fresh[j + 1], fresh[j + 2], fresh[j + 3]};
+            }
+        };
+        {
+            const int spare = cur ^ flip;
+            switch (t & 3) {
+                case 0: rewrite(0, spare); break;
+                case 1: rewrite(1, spare); break;
+                case 2: rewrite(2, spare); break;
+                default: rewrite(3, spare); break;
+            }
+            clean |= 1u << (t & 3);
+        }
+        if (term_m) {                                           // some game of the wave ended
+            const bool me = __builtin_amdgcn_inverse_ballot_w64(term_m);
+            // an episode shorter than four steps: the quarters of the spare not rewritten yet, now (rare)
+            const uint32_t missing = me ? (~clean & 0xfu) : 0u;
+            if (__builtin_amdgcn_ballot_w64(missing != 0u)) {
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp)
+                    if (__builtin_amdgcn_ballot_w64((missing >> grp) & 1u)) {
+                        if ((missing >> grp) & 1u) rewrite(grp, cur ^ flip);
+                    }
+            }
+            if (me) {                                           // new_state: swap the slabs
+                last_alive = (int)alive_bits;
+                cur ^= flip;
+                clean = 0u;
                 acc.n_ep += 1;
                 acc.last_len = (int)acc.ts;
                 acc.ts = 0;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     acc.wins[p] += alive01[p];
-                    pos[p] = fresh_pos[p]; dir_[p] = fresh_dir[p];
+                    pos[p] = 8 * cur + fresh_pos[p]; dir_[p] = fresh_dir[p];
                 }
             }
 #pragma unroll
@@ -1448,6 +1488,65 @@ tron_ranking_kernel(const int NN, const int64_t B, const int8_t *__restrict__ bo
             for (int q = 0; q < P; ++q) higher += score[q] > score[i];
             rank[i * B + b] = (int8_t)higher;
         }
+    }
+}
+
+// compute_ranking for boards made of whole 16-byte chunks: a workgroup takes 64 games, streams their boards with
+// coalesced 16-byte loads (the one-wave-per-game kernel above reads 64 single bytes per load), counts the cells of every
+// player per chunk with byte-parallel compares (bit 7 of ((x & 0x7f..) + 0x7f..) | x is set iff byte x != 0, x = cell ^ id),
+// adds the chunk counts into per-game LDS counters, and one lane per game then applies the same tie rule and ranking.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_ranking_wide_kernel(const int NN, const uint32_t inv_cp, const int64_t B, const int8_t *__restrict__ board,
+                         const int8_t *__restrict__ deaths, int8_t *__restrict__ rank)
+{
+    constexpr int G = 64;
+    __shared__ uint32_t cnt[G][CRL_TRON_MAX_P];
+    for (int i = threadIdx.x; i < G * CRL_TRON_MAX_P; i += 256) (&cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int cp = NN >> 4;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);
+    const int total = n_game * cp;
+    for (int c = threadIdx.x; c < total; c += 256) {
+        const int e = cp == 1 ? c : (int)__umulhi((uint32_t)c, inv_cp);
+        const uint4 v = *reinterpret_cast<const uint4 *>(board + g0 * NN + (int64_t)c * 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            uint32_t n = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = w[q] ^ (0x01010101u * (uint32_t)(p + 1));
+                const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 per NON-matching byte
+                n += 4u - (uint32_t)__popc(nz);
+            }
+            if (n) atomicAdd(&cnt[e][p], n);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= n_game) return;
+    const int64_t b = g0 + threadIdx.x;
+    int score[P], k[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { score[p] = (int)cnt[threadIdx.x][p]; k[p] = deaths[p * B + b]; }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                // :492-495, ascending like np.where
+        const int via = k[i] > 0 ? k[i] - 1 : P - 1;            // python index -1 = the last player
+        int kvia = 0, other = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            kvia = (q == via) ? k[q] : kvia;
+            other = (k[i] > 0 && q == k[i] - 1) ? score[q] : other;   // alive: scores[-1] is a missing key -> 0
+        }
+        if (kvia == i + 1 && other < score[i]) score[i] = other;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                // :497-506 competition ranking
+        int higher = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) higher += score[q] > score[i];
+        rank[i * B + b] = (int8_t)higher;
     }
 }
 
@@ -1818,7 +1917,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     {
         const int max_n = small ? kLdsMaxNSmall : kLdsMaxNLarge;
         const int max_w = (((max_n + 2) * (max_n + 1) + 31) / 32 + 3) & ~3;
-        bits.stride = (max_w + 4) * 4;                                  // pattern words + a junk word, 16-byte multiple
+        bits.stride = (2 * max_w + 4) * 4;                              // two slabs of pattern words + a junk word, 16-byte multiple
         bits.inv_s = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(cfg.N + 1)) + 1u;
     }
     const int threads = (use_bits || small) ? 256 : 64;
@@ -1989,9 +2088,16 @@ int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     TRON_CTX_CHECK("crl_tron_ranking");
     CRL_REQUIRE(board && deaths && rank, "crl_tron_ranking: NULL pointer");
     const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    const bool wide = (NN % 16) == 0 && (((uintptr_t)board & 15) == 0);
+    const uint32_t inv_cp = (!wide || NN == 16) ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;
     TRON_DISPATCH_P(cfg.P, {
-        hipLaunchKernelGGL((tron_ranking_kernel<PP>), dim3(blocks_for(B, 4)), dim3(256), 0, (hipStream_t)stream,
-                           cfg.N * cfg.N, B, board, deaths, rank);
+        if (wide)
+            hipLaunchKernelGGL((tron_ranking_wide_kernel<PP>), dim3(blocks_for(B, 64)), dim3(256), 0, (hipStream_t)stream,
+                               NN, inv_cp, B, board, deaths, rank);
+        else
+            hipLaunchKernelGGL((tron_ranking_kernel<PP>), dim3(blocks_for(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                               NN, B, board, deaths, rank);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
