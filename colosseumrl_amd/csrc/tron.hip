@@ -954,7 +954,10 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     // later, before the shortest episode can end.  (Rewriting a whole slab at every reset, as the first version did,
     // costs kChunks exec-masked 16-byte stores per wave-step -- some lane of a wave resets on practically every step --
     // each at the price of a full-width store: the LDS pipe was 41 % busy with them.)
-    constexpr int kChunks = kMaxW / 4, kPerGroup = (kChunks + 3) / 4, kSlab = kMaxW * 4;
+    // The two slabs of a game lie a multiple of 128 bytes apart: a lane's 16-byte stores then fall on the same four LDS
+    // banks whichever slab is its spare, and the eight lanes a ds_write_b128 services together stay on distinct banks
+    // (per-game stride = 4 dwords mod 32).
+    constexpr int kChunks = kMaxW / 4, kPerGroup = (kChunks + 3) / 4, kSlab = (kMaxW * 4 + 127) & ~127;
     uint32_t fresh[kMaxW];
 #pragma unroll
     for (int j = 0; j < kMaxW; ++j) {
@@ -974,7 +977,6 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const int junk_row = mine + 2 * kSlab;                      // a word nobody reads
     int cur = mine;                                             // slab in play; the spare is cur ^ flip
     const int flip = mine ^ (mine + kSlab);
-    uint32_t clean = 0xfu;                                      // quarters of the spare rewritten since the last swap
     // ---- copy in: the wave ORs the occupied cells of its 64 boards into the slabs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1044,7 +1046,8 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     int act[P];
     __syncthreads();                                            // action table
     rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
-    for (int t = 0; t < T; ++t) {
+    auto one_step = [&](auto grp_tag) {
+        constexpr int GRP = decltype(grp_tag)::value;
         // positions are linear bit addresses, so the 32-bit word holding a cell is (pos >> 3) & ~3 whatever the row width
         int np[P], nd[P], ra[P];
         uint32_t roww[P];
@@ -1056,6 +1059,20 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         }
 #pragma unroll
         for (int i = 0; i < P; ++i) roww[i] = *(const lds_u32 *)(uintptr_t)(uint32_t)ra[i];
+        // every lane rewrites quarter GRP of its spare slab with the start layout.  GRP is a compile-time constant (the
+        // step loop is unrolled four times below): as a run-time `switch (t & 3)` the compiler merged the four cases
+        // into one set of stores fed by ~16 register copies per step, which cost more than the burst resets had.
+        auto rewrite = [&](const int grp, const int base) {
+#pragma unroll
+            for (int c = 0; c < kPerGroup; ++c) {
+                const int j = 4 * (grp * kPerGroup + c);
+                if (j < kMaxW)
+                    *(lds_u128 *)(uintptr_t)(uint32_t)(base + 4 * j) = (u32x4){fresh[j], fresh[j + 1], fresh[j + 2], fresh[j + 3]};
+            }
+        };
+        // Issued right behind the probes: the LDS serves a wave's requests in order, so here the stores run while the
+        // wave waits for its probe words anyway; at the end of the step they would sit in front of the NEXT step's probes.
+        rewrite(GRP, cur ^ flip);
         acc.tc += 1;
         rng.next_lut(gid, acc.tc, seed_lo, seed_hi, act_lut, act);
 #pragma unroll
@@ -1089,41 +1106,20 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         }
         const uint64_t term_m = __builtin_amdgcn_ballot_w64(alive <= 1) & valid_m;      // TronGridEnvironment.py:309-321
         acc.ts += 1;
-        // every lane rewrites quarter (t & 3) of its spare slab with the start layout (wave-uniform quarter: the
-        // pattern words are plain register operands)
-        auto rewrite = [&](const int grp, const int base) {
-#pragma unroll
-            for (int c = 0; c < kPerGroup; ++c) {
-                const int j = 4 * (grp * kPerGroup + c);
-                if (j < kMaxW)
-                    *(lds_u128 *)(uintptr_t)(uint32_t)(base + 4 * j) = (u32x4){fresh[j], fresh[j + 1], fresh[j + 2], fresh[j + 3]};
-            }
-        };
-        {
-            const int spare = cur ^ flip;
-            switch (t & 3) {
-                case 0: rewrite(0, spare); break;
-                case 1: rewrite(1, spare); break;
-                case 2: rewrite(2, spare); break;
-                default: rewrite(3, spare); break;
-            }
-            clean |= 1u << (t & 3);
-        }
         if (term_m) {                                           // some game of the wave ended
             const bool me = __builtin_amdgcn_inverse_ballot_w64(term_m);
-            // an episode shorter than four steps: the quarters of the spare not rewritten yet, now (rare)
-            const uint32_t missing = me ? (~clean & 0xfu) : 0u;
-            if (__builtin_amdgcn_ballot_w64(missing != 0u)) {
+            // The spare has been rewritten completely iff four steps have passed since this lane's last swap (acc.ts,
+            // the length of the episode that just ended) -- or no swap happened in this launch yet (the set-up left it
+            // fresh).  An episode of fewer than four steps: rewrite all of it now (rare).
+            if (__builtin_amdgcn_ballot_w64(me && acc.ts < 4u && acc.n_ep > 0u)) {
+                if (me && acc.ts < 4u && acc.n_ep > 0u) {
 #pragma unroll
-                for (int grp = 0; grp < 4; ++grp)
-                    if (__builtin_amdgcn_ballot_w64((missing >> grp) & 1u)) {
-                        if ((missing >> grp) & 1u) rewrite(grp, cur ^ flip);
-                    }
+                    for (int grp = 0; grp < 4; ++grp) rewrite(grp, cur ^ flip);
+                }
             }
             if (me) {                                           // new_state: swap the slabs
                 last_alive = (int)alive_bits;
                 cur ^= flip;
-                clean = 0u;
                 acc.n_ep += 1;
                 acc.last_len = (int)acc.ts;
                 acc.ts = 0;
@@ -1136,6 +1132,17 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
 #pragma unroll
             for (int p = 0; p < P; ++p) dead[p] &= ~term_m;
         }
+    
+    };
+    for (int t = 0;;) {                                         // four steps per trip, one per quarter of the spare slab
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 0>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 1>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 2>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 3>{}); ++t;
     }
     acc.len_sum = ts_at_entry + (uint32_t)T - acc.ts;
     if (acc.n_ep > 0) acc.last_w = last_alive;
@@ -1917,7 +1924,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     {
         const int max_n = small ? kLdsMaxNSmall : kLdsMaxNLarge;
         const int max_w = (((max_n + 2) * (max_n + 1) + 31) / 32 + 3) & ~3;
-        bits.stride = (2 * max_w + 4) * 4;                              // two slabs of pattern words + a junk word, 16-byte multiple
+        bits.stride = 2 * ((max_w * 4 + 127) & ~127) + 16;              // two 128-byte-aligned slabs of pattern words + a junk word
         bits.inv_s = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(cfg.N + 1)) + 1u;
     }
     const int threads = (use_bits || small) ? 256 : 64;
