@@ -260,8 +260,11 @@ __device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, c
     const bool held = lane < NPIECE && ((inv >> lane) & 1u);
     const uint32_t nu = held ? T.nuniq[lane] : 0u;
     const uint32_t incl = wave_scan_incl(nu, lane);
-    int pos = (int)(incl - nu);
-    for (uint32_t k = 0; k < nu; ++k) L.items[pos++] = (uint8_t)((lane << 3) | (int)k);
+    const int pos = (int)(incl - nu);
+    // plain byte stores, one per distinct orientation (<= 8 trips): left to itself the compiler vectorises this into
+    // 16-byte stores fed by a register-resident {0..7} table that it then SPILLS to scratch in the rollout kernel
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (uint32_t k = 0; k < nu; ++k) L.items[pos + (int)k] = (uint8_t)((lane << 3) | (int)k);
     wave_sync();
     return __builtin_amdgcn_readlane((int)incl, NPIECE - 1);
 }
