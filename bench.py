@@ -9,9 +9,10 @@ The workload is BASELINE.json configs[1]: 4-player 20x20 Tron, 65,536 games per 
 the counter-based RNG, auto-reset on terminal.  State is resident in HBM before the timed region; the timed region is W
 untimed + exactly K timed steps, issued as fused launches of min(--chunk, remaining) steps, bracketed by barrier +
 synchronize; the time is the max over ranks.  With N > 1 each rank owns the games [rank*B, (rank+1)*B) (weak scaling,
-no data-path collective) and the per-game result rows (written by the rollout kernel itself) are gathered once with a
-single RCCL all_gather at the end, inside the timed region (colosseumrl_amd.parallel.ShardedRollout; the collective also
-runs in a world of one rank when a process group exists, e.g. under `torchrun --nproc-per-node 1`).
+no data-path collective) and the per-game result rows (written by the rollout kernel itself) are gathered once to rank 0
+with a single RCCL gather at the end, inside the timed region (colosseumrl_amd.parallel.ShardedRollout; the collective
+also runs in a world of one rank when a process group exists, e.g. under `torchrun --nproc-per-node 1`).  The clock of a
+rank stops when its own work incl. the collective is complete; the value uses the MAX over ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --only-headline):
   roofline      measured HBM bytes per launch (rocprofv3 PMC of the SAME launch shape, profiles/traffic_*.json; a
@@ -266,17 +267,21 @@ def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
 
 
 # ---------------------------------------------------------------------------------------------- measurements
-def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None):
-    """The contract's timed region: exactly `steps` env-steps + the gather, wall clock between two barriers."""
+def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None):
+    """The contract's timed region: exactly `steps` env-steps + the gather of the per-game results, bracketed by
+    barrier + synchronize on both sides.  The clock stops when THIS rank's work (incl. the collective, which itself waits
+    for the other ranks' shards) has completed on the device; the closing barrier follows, and the caller takes the MAX of
+    the per-rank times -- the time of the slowest rank, without the latency of the closing barrier itself."""
     ev0, ev1 = events or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     barrier()
     t0 = time.perf_counter()
     ev0.record()                                           # same stream the kernels are launched on
     launches = sr.rollout(steps, seed, chunk)
     ev1.record()
-    gathered = sr.gather()                                 # the one collective: per-game results to every rank
-    barrier()
+    gathered = sr.gather(dst=dst)                          # the one collective: per-game results to rank `dst`
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     return elapsed, ev0.elapsed_time(ev1) * 1e-3, launches, gathered
 
 
@@ -456,18 +461,18 @@ def main():
     # The W warm-up steps go through the very function that is timed afterwards (same events, launch path, gather and
     # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
     if args.warmup > 0:
-        timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events)
+        timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events, dst)
     else:
-        sr.gather()
-    elapsed, kernel_s, launches, gathered = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, events)
+        sr.gather(dst=dst)
+    elapsed, kernel_s, launches, gathered = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, events, dst)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    mean_len, n_ep = mean_episode_len(gathered)
-
     if rank == 0:
+        mean_len, n_ep = mean_episode_len(gathered)
         copy_gbs = measure_copy_bandwidth(torch, device) if world == 1 else None
         value = world * batch * args.steps / elapsed
         # launches of the timed region are equal-sized when steps % chunk == 0; otherwise the roofline describes the
@@ -483,7 +488,7 @@ def main():
                        "steps_per_launch": steps_per_launch, "launches": launches,
                        "agent": "uniform random (Philox-4x32-10), auto-reset",
                        "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
-                       "gather": "rccl all_gather_into_tensor" if use_dist else "none (single process, no process group)"},
+                       "gather": "rccl gather to rank 0 (torch.distributed.gather)" if use_dist else "none (single process, no process group)"},
             "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
             "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),
         }
@@ -495,8 +500,8 @@ def main():
                 sr.stepper.reset()
                 sr.stepper.reset_stats()
                 if args.warmup > 0:
-                    timed_rollout(torch, sr, args.warmup, s, args.chunk, barrier, events)
-                e, _, _, g = timed_rollout(torch, sr, args.steps, s, args.chunk, barrier, events)
+                    timed_rollout(torch, sr, args.warmup, s, args.chunk, barrier, events, dst)
+                e, _, _, g = timed_rollout(torch, sr, args.steps, s, args.chunk, barrier, events, dst)
                 seeds[str(s)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
             vals = [v["value"] for v in seeds.values()]
             seeds["spread"] = (max(vals) - min(vals)) / (sum(vals) / len(vals))

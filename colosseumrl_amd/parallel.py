@@ -4,8 +4,8 @@ Every game is independent, so the only parallelism is over the batch axis (SURVE
 owns the contiguous block of global game ids ``shard_bounds(G, r, W)`` and runs the same kernels on
 it; the random agent's RNG is keyed by the GLOBAL game id, so results do not depend on W.  There is
 no data-path collective while stepping.  The single exchange is at the end of a rollout: the per-game
-result records are concatenated across ranks with ONE ``all_gather`` (RCCL over xGMI with the
-``nccl`` backend; ~13-44 bytes per game, latency-bound).  The reference has no counterpart (it has no
+result records are concatenated across ranks with ONE collective -- a ``gather`` to one rank or an ``all_gather``
+(RCCL over xGMI with the ``nccl`` backend; 44 bytes per game for 4-player Tron, latency-bound).  The reference has no counterpart (it has no
 device code at all).
 
 The collective layer is backend-agnostic (``gloo`` on CPU tensors in the tests).
@@ -26,14 +26,17 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def gather_results(local: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Concatenate per-game result rows [n_local, k] of all ranks, in global game order, on every rank.
+                   out: Optional[torch.Tensor] = None, dst: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Concatenate per-game result rows [n_local, k] of all ranks in global game order: on every rank (``dst=None``,
+    one ``all_gather_into_tensor``) or on rank `dst` only (one ``gather``; the other ranks get ``None``).
 
-    One collective: shards are padded to the largest shard so a single ``all_gather_into_tensor`` moves
-    everything (a ring over the 7 xGMI links per GPU is ample for a few MB).  The collective runs whenever a
-    process group is initialised -- also for a world of one rank (``torchrun --nproc-per-node 1``), so the RCCL
-    path is the same code at every world size.  `out` (``[world * ceil(total / world), k]``, same dtype / device)
-    is an optional preallocated receive buffer."""
+    ONE collective either way; shards are padded to the largest shard so a single call moves everything.  The gather
+    to one rank is what an episode-end statistics sink needs and what bench.py times: over RCCL it is a set of
+    point-to-point transfers, so on the fully connected xGMI mesh of an 8-GPU node the 7 shards travel over 7 different
+    links at once (~40 us for 2.9 MB each), where a ring all_gather needs 7 serial hops.  The collective runs whenever
+    a process group is initialised -- also for a world of one rank (``torchrun --nproc-per-node 1``), so the RCCL path
+    is the same code at every world size.  `out` (``[world * ceil(total / world), k]``, same dtype / device) is an
+    optional preallocated receive buffer."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -45,10 +48,18 @@ def gather_results(local: torch.Tensor, total: int, group: Optional[dist.Process
     if local.shape[0] != widest:
         padded = torch.zeros((widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded[: local.shape[0]] = local
+    padded = padded.contiguous()
     shape = (world * widest,) + tuple(local.shape[1:])
-    if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
+    receiver = dst is None or rank == dst
+    if receiver and (out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device):
         out = torch.empty(shape, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if dst is None:
+        dist.all_gather_into_tensor(out, padded, group=group)
+    else:
+        pieces = [out[r * widest: (r + 1) * widest] for r in range(world)] if receiver else None
+        dist.gather(padded, pieces, dst=dst, group=group)
+        if not receiver:
+            return None
     if total == world * widest:
         return out
     pieces = []
@@ -86,10 +97,12 @@ class ShardedRollout:
             launches += 1
         return launches
 
-    def gather(self) -> torch.Tensor:
-        """Per-game results of ALL games on every rank (the one collective of a rollout)."""
+    def gather(self, dst: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Per-game results of ALL games (the one collective of a rollout): on every rank, or with `dst` on that rank
+        only (``None`` elsewhere)."""
         local = self.stepper.results()
-        if self._recv is None and dist.is_available() and dist.is_initialized():
+        receiver = dst is None or self.rank == dst
+        if self._recv is None and receiver and dist.is_available() and dist.is_initialized():
             widest = -(-self.total // self.world)
             self._recv = torch.empty((self.world * widest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        return gather_results(local, self.total, self.group, out=self._recv)
+        return gather_results(local, self.total, self.group, out=self._recv, dst=dst)

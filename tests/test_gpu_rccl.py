@@ -35,6 +35,8 @@ assert int(got[:, 0].sum()) > B
 ref = TronBatch(20, 4, B, device="cuda:0")
 ref.rollout(48, seed=3)
 assert torch.equal(ref.results(), got)
+rooted = sr.gather(dst=0)                                                 # torch.distributed.gather: what bench.py times
+assert rooted is not None and torch.equal(rooted, want)
 st = ShardedRollout(lambda batch, first_env_id: TTTBatch((3, 5), 3, 3, batch, device="cuda:0", first_env_id=first_env_id), 1000)
 st.rollout(40, seed=1, chunk=40)
 assert torch.equal(st.gather(), st.stepper.results_from_columns())

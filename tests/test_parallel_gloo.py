@@ -52,9 +52,14 @@ def _worker(rank, world, port, total, out_dir):
         assert (sr.lo, sr.hi) == shard_bounds(total, rank, world)
         launches = sr.rollout(70, seed=5, chunk=32)
         assert launches == 3
-        allres = sr.gather()
+        allres = sr.gather().clone()                      # (the receive buffer is reused by the next gather)
         assert allres.shape[0] == total
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), allres.numpy())
+        dst = world - 1                                   # the gather to ONE rank (what bench.py times)
+        rooted = sr.gather(dst=dst)
+        assert (rooted is None) == (rank != dst)
+        if rank == dst:
+            assert torch.equal(rooted, allres)
     finally:
         dist.destroy_process_group()
 
