@@ -18,18 +18,25 @@ def test_calls_are_graph_capturable():
         tb.rollout(4, 1)
         tb.step(act)
     torch.cuda.synchronize()
+    oa, ob = a.step_observe(None, seed=1), b.step_observe(None, seed=1)   # also allocates the observation buffers
+    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         a.rollout(16, 1)
         a.step(act, auto_reset=True)
+        a.step_observe(None, seed=1, out=oa)        # the fused per-step call (sampled actions advance tcount)
+        a.step_observe(act, out=oa)
     for _ in range(3):
         g.replay()
     for _ in range(3):                      # capture itself does not execute: 3 replays == 3 eager rounds
         b.rollout(16, 1)
         b.step(act, auto_reset=True)
+        b.step_observe(None, seed=1, out=ob)
+        b.step_observe(act, out=ob)
     torch.cuda.synchronize()
     assert torch.equal(a.board, b.board) and torch.equal(a.heads, b.heads) and torch.equal(a.ret_sum, b.ret_sum)
-    assert torch.equal(a.tcount, b.tcount) and int(a.tcount[0]) == 4 + 3 * 16
+    assert torch.equal(a.tcount, b.tcount) and int(a.tcount[0]) == 4 + 1 + 3 * 17
+    assert torch.equal(oa["board"], ob["board"]) and torch.equal(a.results(), b.results())
 
 
 def test_side_stream_ordering():
@@ -128,3 +135,40 @@ def test_tron_check_state():
     tb.heads[1, 11] = 399
     tb.board[11, 399] = 0
     assert tb.check_state() == 2
+
+
+@pytest.mark.parametrize("kernel", ["bytes", "bits"])
+def test_hand_made_states_with_wild_heads_stay_inside_the_slab(kernel):
+    """Heads outside the board (a hand-uploaded or corrupted state) are clamped onto it by the LDS rollout kernels: the
+    results of such games are unspecified, but the launch completes, reports no error, and every OTHER game of the batch
+    still equals an untouched twin (no write outside the broken game's own slab)."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    a, b = TronBatch(20, 4, 1024), TronBatch(20, 4, 1024)
+    bad = [5, 64, 700]
+    for e in bad:
+        a.heads[1, e] = 30000
+        a.heads[3, e] = -7
+    assert a.check_state() == len(bad)
+    a.rollout(64, 3, kernel=kernel)
+    b.rollout(64, 3, kernel=kernel)
+    torch.cuda.synchronize()
+    keep = torch.ones(1024, dtype=torch.bool, device="cuda")
+    keep[bad] = False
+    assert torch.equal(a.board[keep], b.board[keep]) and torch.equal(a.heads[:, keep], b.heads[:, keep])
+    assert torch.equal(a.n_episodes[keep], b.n_episodes[keep])
+
+
+def test_observe_with_out_of_range_player_ids():
+    """An observer id outside 0..P-1 observes as player 0 (documented in the header) instead of reading a wild table entry."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    tb = TronBatch(20, 4, 512)
+    tb.rollout(9, 1)
+    pl = torch.zeros((512,), dtype=torch.int8, device="cuda")
+    ref = tb.observe(pl)
+    pl[::3] = 9
+    pl[1::3] = -2
+    got = tb.observe(pl)
+    for k in ("board", "heads", "directions", "deaths"):
+        assert torch.equal(ref[k], got[k]), k

@@ -15,7 +15,7 @@ _native.lib().crl_blokus_stamps(buf, 1)
 bb.rollout(256, 1)
 torch.cuda.synchronize()
 _native.lib().crl_blokus_stamps(buf, 1)
-names = ["loop/outcome", "prep", "count", "rng", "select", "apply", "exists", "-"]
+names = ["loop/outcome", "prep", "count", "rng+select", "apply", "exists", "rest", "-"]   # BLK_STAMP(k) closes segment k
 tot = sum(buf)
 for n, v in zip(names, buf):
     print("%-14s %6.1f %%   %8.0f cycles/wave-step" % (n, 100.0 * v / tot, v / 16384 / 256))
