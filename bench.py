@@ -247,12 +247,14 @@ def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs):
 
 
 def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
-    """On-box device copy ceiling (read + write bytes / time; SURVEY 8d's second peak): the best of the runtime's
-    device-to-device copy and two vectorised streaming kernels (16 bytes per lane) over a 1 GiB buffer."""
+    """On-box streaming ceiling (HBM bytes moved / time; SURVEY 8d's second peak): the best of the runtime's
+    device-to-device copy, two vectorised read+write kernels (16 bytes per lane) and a pure write stream over a 1 GiB
+    buffer.  (The per-step kernels write four times what they read, so a balanced copy alone is not their ceiling.)"""
     src = torch.empty(nbytes // 4, dtype=torch.int32, device=device).fill_(1)
     dst = torch.empty_like(src)
     best = 0.0
-    for op in (lambda: dst.copy_(src), lambda: torch.add(src, 1, out=dst), lambda: torch.bitwise_xor(src, 1, out=dst)):
+    for op, moved in ((lambda: dst.copy_(src), 2.0 * nbytes), (lambda: torch.add(src, 1, out=dst), 2.0 * nbytes),
+                      (lambda: torch.bitwise_xor(src, 1, out=dst), 2.0 * nbytes), (lambda: dst.fill_(3), 1.0 * nbytes)):
         op()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -261,7 +263,7 @@ def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
             op()
         e1.record()
         torch.cuda.synchronize()
-        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9)
+        best = max(best, moved / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9)
     del src, dst
     return best
 
