@@ -435,19 +435,30 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
     }
 }
 
-// per-lane rollout bookkeeping shared by both rollout kernels
+// per-lane rollout bookkeeping shared by the rollout kernels.  The running totals a launch adds to are read at kernel
+// entry (with every other global load of the prologue), not in the epilogue: a short launch otherwise ends on a chain
+// of exposed load -> add -> store round trips.
 template <int P>
 struct TronAcc {
     int ret[P];
     uint32_t wins[P];
     uint32_t tc, ts, n_ep, len_sum;
     int last_w, last_len;
-    __device__ __forceinline__ void load(const crl_tron_stats &st, const bool valid, const int64_t b)
+    int old_ret[P];
+    uint32_t old_wins[P], old_n_ep, old_len_sum, old_last_w;
+    __device__ __forceinline__ void load(const crl_tron_stats &st, const bool valid, const int64_t b, const int64_t B)
     {
 #pragma unroll
-        for (int p = 0; p < P; ++p) { ret[p] = 0; wins[p] = 0; }
+        for (int p = 0; p < P; ++p) {
+            ret[p] = 0; wins[p] = 0;
+            old_ret[p] = valid ? st.ret_sum[p * B + b] : 0;
+            old_wins[p] = valid ? st.win_count[p * B + b] : 0u;
+        }
         tc = valid ? st.tcount[b] : 0;
         ts = valid ? st.tstep[b] : 0;
+        old_n_ep = valid ? st.n_episodes[b] : 0u;
+        old_len_sum = valid ? st.len_sum[b] : 0u;
+        old_last_w = valid ? st.last_winners[b] : 0u;
         n_ep = 0; len_sum = 0; last_w = -1; last_len = 0;
     }
     __device__ __forceinline__ void finish_episode(const int wm)
@@ -467,15 +478,15 @@ struct TronAcc {
         int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int r = st.ret_sum[p * B + b] + ret[p];
-            const uint32_t w = st.win_count[p * B + b] + wins[p];
+            const int r = old_ret[p] + ret[p];
+            const uint32_t w = old_wins[p] + wins[p];
             st.ret_sum[p * B + b] = r;
             st.win_count[p * B + b] = w;
             if (row) { row[3 + p] = (int32_t)w; row[3 + P + p] = r; }
         }
         st.tcount[b] = tc;
         st.tstep[b] = ts;
-        const uint32_t ne = st.n_episodes[b] + n_ep, ls = st.len_sum[b] + len_sum;
+        const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + len_sum;
         st.n_episodes[b] = ne;
         st.len_sum[b] = ls;
         if (last_w >= 0) {
@@ -485,7 +496,7 @@ struct TronAcc {
         if (row) {
             row[0] = (int32_t)ne;
             row[1] = (int32_t)ls;
-            row[2] = last_w >= 0 ? last_w : (int32_t)st.last_winners[b];
+            row[2] = last_w >= 0 ? last_w : (int32_t)old_last_w;
         }
     }
 };
@@ -523,7 +534,7 @@ tron_rollout_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B, c
         asm volatile("" : "+v"(fresh.h[p]), "+v"(fresh.x[p]), "+v"(fresh.y[p]), "+v"(fresh.d[p]));
     }
     TronAcc<P> acc;
-    acc.load(st, valid, bb);
+    acc.load(st, valid, bb, B);
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
@@ -713,11 +724,22 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     uint4 cin[kCopyBatch];
     if (wide) {
 #pragma unroll
-        for (int k = 0; k < kCopyBatch; ++k) {
-            const int off = lane * 16 + k * (CRL_WAVE * 16);
-            cin[k] = off < bytes_in ? *reinterpret_cast<const uint4 *>(gslab_in + off) : make_uint4(0, 0, 0, 0);
-        }
+        for (int k = 0; k < kCopyBatch; ++k) {                  // unconditional loads (a piece beyond the wave's boards
+            const int off = lane * 16 + k * (CRL_WAVE * 16);    // re-reads piece 0): no exec branches between them, so the
+            cin[k] = *reinterpret_cast<const uint4 *>(gslab_in + (off < bytes_in ? off : 0));   // scatter below can wait for
+        }                                                       // them one by one (vmcnt(N)) instead of for all (vmcnt(0))
     }
+    // the per-player state and the step counters are requested now as well, so that every global load of the prologue
+    // is in flight together (their latency used to be exposed one after the other behind the board copy)
+    int h_in[P], d_in[P], k_in[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        h_in[p] = valid ? heads[p * B + bb] : 0;
+        d_in[p] = valid ? dirs[p * B + bb] : 0;
+        k_in[p] = valid ? deaths[p * B + bb] : 1;
+    }
+    TronAcc<P> acc;
+    acc.load(st, valid, bb, B);
     for (int off = 0; off < pad.stride; off += 4) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wall fill above vs other lanes' cell writes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -751,12 +773,11 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     int act[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        int h = valid ? heads[p * B + bb] : 0;
-        h = min(max(h, 0), NN - 1);                             // a hand-made state must not turn into a wild LDS address
+        const int h = min(max(h_in[p], 0), NN - 1);             // a hand-made state must not turn into a wild LDS address
         const int y = (int)__umulhi((uint32_t)h, g.inv_n);
         s.h[p] = mine + (y + 1) * RS + (h - y * N);
-        s.d[p] = valid ? dirs[p * B + bb] & 3 : 0;
-        s.k[p] = valid ? deaths[p * B + bb] : 1;
+        s.d[p] = d_in[p] & 3;
+        s.k[p] = k_in[p];
         const int fh = cfg.start_heads[p];
         const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
         fresh.h[p] = mine + (fy + 1) * RS + (fh - fy * N);
@@ -767,8 +788,6 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     const int junk = mine + pad.junk;
     int sweep = mine + RS;                                      // next row of the rolling rewrite
     const int sweep_end = mine + (N + 1) * RS;
-    TronAcc<P> acc;
-    acc.load(st, valid, bb);
     const uint32_t ts_at_entry = acc.ts;
     uint32_t alive_steps[P];
     int last_k[P];                                              // deaths at the latest terminal step
@@ -1034,7 +1053,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         asm volatile("" : "+v"(fresh_pos[p]), "+v"(fresh_dir[p]));
     }
     TronAcc<P> acc;
-    acc.load(st, valid, bb);
+    acc.load(st, valid, bb, B);
     const uint32_t ts_at_entry = acc.ts;
     uint32_t alive_steps[P];
     int last_alive = 0;                                         // who was alive at this lane's latest terminal step
