@@ -80,6 +80,7 @@ PROTOTYPES = {
     "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
     "crl_ttt_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _I, _VP, _VP]),
+    "crl_ttt_step_observe": (_I, [_VP, _I64, _U64, _U64] + [_VP] * 10 + [_I, _U32, _VP]),
     "crl_blokus_create": (_I, [C.POINTER(_VP)]),
     "crl_blokus_placement": (_I, [_I, _I, _I, _VP]),
     "crl_blokus_stamps": (_I, [_VP, _I]),

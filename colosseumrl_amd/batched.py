@@ -357,6 +357,26 @@ class TTTBatch:
         """state_to_observation for all games: board with ids relative to player[b] (reference 2p:382-407)."""
         return {"board": self.board(player, rel_mod)}
 
+    def step_observe(self, action: Optional[torch.Tensor] = None, seed: int = 0, auto_reset: bool = True,
+                     rel_mod: Optional[int] = None, out: Optional[dict] = None):
+        """One ply of every game in ONE launch: plays `action` (int8 [B]; None = the rollout's random agent at each
+        game's step counter, which then advances) and returns what the next mover needs:
+        {'board' int8 [B, cells] relative to the player to move next, 'valid' int32 [B] empties mask, 'mover' int8 [B],
+        'reward', 'terminal', 'winners'}.  Equals ``step(...); valid_mask(); board(to_move, rel_mod)``."""
+        if action is not None:
+            _want(action, torch.int8, (self.B,), self.device, "action")
+        if out is None:
+            out = {"board": torch.empty((self.B, self.n_cells), dtype=torch.int8, device=self.device),
+                   "valid": torch.empty((self.B,), dtype=torch.int32, device=self.device)}
+        with _DevGuard(self.device):
+            check(self._lib.crl_ttt_step_observe(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id,
+                                                 _ptr(self.occ), _ptr(self.winner), _ptr(self.to_move), _ptr(action),
+                                                 _ptr(self.tcount), _ptr(self.reward), _ptr(self.terminal), _ptr(self.winners),
+                                                 _ptr(out["board"]), _ptr(out["valid"]), int(rel_mod if rel_mod else self.P),
+                                                 CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()), "crl_ttt_step_observe")
+        out["mover"], out["reward"], out["terminal"], out["winners"] = self.to_move, self.reward, self.terminal, self.winners
+        return out
+
     def _stats(self):
         return TTTStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
                                                   self.draw_count, self.len_sum, self._results)])

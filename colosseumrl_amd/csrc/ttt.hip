@@ -174,6 +174,99 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = (int32_t)dr; }
 }
 
+// ---- fused per-step call: [sample ->] next_state (auto-reset) -> valid_actions mask + state_to_observation of the
+// player to move next.  What a learner / vector env runs every ply (tictactoe_2p_env.py:240-315, :317-348, :382-407);
+// as separate launches (crl_ttt_sample, crl_ttt_step, crl_ttt_valid, crl_ttt_board) the launch boundaries cost more than
+// the work.  One lane per game plays the move; the post-move masks go through LDS so that the int8 [B][cells] observation
+// is produced a dword per thread and written coalesced (a lane writing its own game's 9..27 bytes would not be).
+template <int P, int ND>
+__global__ void __launch_bounds__(256)
+ttt_step_observe_kernel(const ttt_dirs dd, const uint32_t inv_cells, const int64_t B, const uint32_t seed_lo,
+                        const uint32_t seed_hi, const uint64_t first_env_id, uint32_t *__restrict__ occ,
+                        int8_t *__restrict__ winner, int8_t *__restrict__ to_move, const int8_t *__restrict__ action,
+                        uint32_t *__restrict__ tcount, int8_t *__restrict__ reward, uint8_t *__restrict__ terminal,
+                        int8_t *__restrict__ winners, int8_t *__restrict__ obs, uint32_t *__restrict__ valid,
+                        const int rel_mod, const uint32_t flags)
+{
+    __shared__ uint32_t s_occ[P][256];
+    __shared__ int s_mover[256];
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t b = g0 + threadIdx.x;
+    uint32_t o[P];
+    int tm = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) o[p] = 0u;
+    if (b < B) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = occ[p * B + b];
+        int w = winner[b];
+        tm = to_move[b];
+        int act;
+        if (action) {
+            act = action[b];
+        } else {                                    // the rollout's random agent at this game's step counter
+            uint32_t all = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) all |= o[p];
+            const uint32_t empty = dd.full & ~all, c = tcount[b];
+            const int n_empty = __popc(empty);
+            const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+            const uint32_t sel = c & 3u;
+            const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+            act = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
+            tcount[b] = c + 1u;
+        }
+        int r, t, ws;
+        ttt_step_core<P, ND>(dd, o, w, tm, act, r, t, ws);
+        reward[b] = (int8_t)r;
+        terminal[b] = (uint8_t)t;
+        winners[b] = (int8_t)ws;
+        if (t && (flags & CRL_STEP_AUTO_RESET)) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) o[p] = 0;
+            w = -1; tm = 0;
+        }
+        uint32_t all = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { occ[p * B + b] = o[p]; all |= o[p]; }
+        winner[b] = (int8_t)w;
+        to_move[b] = (int8_t)tm;
+        valid[b] = dd.full & ~all;                  // tictactoe_2p_env.py:317-348 for the player to move next
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) s_occ[p][threadIdx.x] = o[p];
+    s_mover[threadIdx.x] = tm;
+    __syncthreads();
+    // observation bytes [g0 * cells, (g0 + n_game) * cells): one dword per thread and trip
+    const int cells = dd.n_cells;
+    const int n_game = (int)((B - g0) < 256 ? (B - g0) : 256);
+    const int total = n_game * cells;
+    int8_t *out = obs + g0 * cells;
+    for (int d = threadIdx.x; d * 4 < total; d += 256) {
+        int e = cells == 1 ? d * 4 : (int)__umulhi((uint32_t)(d * 4), inv_cells);
+        int c = d * 4 - e * cells;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ee = e < 256 ? e : 255;       // bytes past the last game of the block are never stored
+            int v = -1;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v = ((s_occ[p][ee] >> c) & 1u) ? p : v;
+            if (v >= 0) {                           // _relative_player_id (2p:26-27): python's non-negative modulo
+                const int rr = (v - s_mover[ee]) % rel_mod;
+                v = rr < 0 ? rr + rel_mod : rr;
+            }
+            word |= (uint32_t)(v & 0xff) << (8 * k);
+            if (++c == cells) { c = 0; ++e; }
+        }
+        if (d * 4 + 4 <= total) {
+            *reinterpret_cast<uint32_t *>(out + d * 4) = word;
+        } else {
+            for (int k = 0; d * 4 + k < total; ++k) out[d * 4 + k] = (int8_t)(word >> (8 * k));
+        }
+    }
+}
+
 // the rollout's random agent for one step
 __global__ void __launch_bounds__(256)
 ttt_sample_kernel(const int P, const uint32_t full, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
@@ -390,6 +483,34 @@ int crl_ttt_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_
     const ttt_dirs dd = dirs_of(ctx);
     hipLaunchKernelGGL(ttt_sample_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, ctx->ttt.P, dd.full, B,
                        (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, occ, tcount, advance, action);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                         uint32_t *occ, int8_t *winner, int8_t *to_move, const int8_t *action, uint32_t *tcount,
+                         int8_t *reward, uint8_t *terminal, int8_t *winners, int8_t *obs_board, uint32_t *valid,
+                         int rel_mod, uint32_t flags, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_step_observe");
+    CRL_REQUIRE(occ && winner && to_move, "crl_ttt_step_observe: NULL state pointer");
+    CRL_REQUIRE(action || tcount, "crl_ttt_step_observe: action and tcount are both NULL (nothing to play)");
+    CRL_REQUIRE(reward && terminal && winners && obs_board && valid, "crl_ttt_step_observe: NULL output pointer");
+    CRL_REQUIRE(rel_mod >= 1, "crl_ttt_step_observe: rel_mod must be >= 1");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_ttt_step_observe: unknown flags 0x%x", flags);
+    CRL_REQUIRE((((uintptr_t)obs_board) & 3) == 0, "crl_ttt_step_observe: obs_board must be 4-byte aligned");
+    const ttt_dirs dd = dirs_of(ctx);
+    const uint32_t inv_cells = dd.n_cells == 1 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)dd.n_cells) + 1u;
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        if (dd.n_dirs <= 4)
+            hipLaunchKernelGGL((ttt_step_observe_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd,
+                               inv_cells, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, occ, winner, to_move, action,
+                               tcount, reward, terminal, winners, obs_board, valid, rel_mod, flags);
+        else
+            hipLaunchKernelGGL((ttt_step_observe_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd,
+                               inv_cells, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, occ, winner, to_move, action,
+                               tcount, reward, terminal, winners, obs_board, valid, rel_mod, flags);
+    });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

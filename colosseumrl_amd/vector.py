@@ -50,11 +50,10 @@ class TicTacToeVectorEnv:
 
     def step(self, action: torch.Tensor):
         """-> (obs for the next mover, next mover int8 [B], empties bitmask int32 [B], reward int8 [B] of the
-        player who just moved, done uint8 [B], info)."""
-        reward, terminal, winners = self.batch.step(action, auto_reset=True)
-        reward, done, winners = reward.clone(), terminal.clone(), winners.clone()
-        mover = self.batch.to_move
-        return self.batch.observe(mover), mover.clone(), self.batch.valid_mask(), reward, done, {"winners": winners}
+        player who just moved, done uint8 [B], info).  One launch (``TTTBatch.step_observe``)."""
+        o = self.batch.step_observe(action, auto_reset=True)
+        return ({"board": o["board"]}, o["mover"].clone(), o["valid"], o["reward"].clone(), o["terminal"].clone(),
+                {"winners": o["winners"].clone()})
 
 
 class BlokusVectorEnv:

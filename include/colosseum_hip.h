@@ -196,6 +196,15 @@ int crl_ttt_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, uint32_t *
  * (reference _relative_player_id, tictactoe_2p_env.py:26-27, modulus given by rel_mod) */
 int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, int rel_mod,
                   int8_t *board, void *stream);
+/* One launch for a ply of every game, as a learner / vector env needs it: [sample ->] next_state -> valid_actions and
+ * state_to_observation of the player to move NEXT.  Exactly equivalent to
+ *   [crl_ttt_sample(..., advance = 1);]  crl_ttt_step(..., flags);  crl_ttt_valid(...);  crl_ttt_board(..., player = to_move, rel_mod)
+ * with action == NULL meaning "draw it with the rollout's random agent at tcount[b] and advance tcount" (tcount may be NULL
+ * when actions are given).  obs_board int8 [B][cells] (4-byte aligned), valid uint32 [B]. */
+int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                         uint32_t *occ, int8_t *winner, int8_t *to_move, const int8_t *action, uint32_t *tcount,
+                         int8_t *reward, uint8_t *terminal, int8_t *winners, int8_t *obs_board, uint32_t *valid,
+                         int rel_mod, uint32_t flags, void *stream);
 typedef struct {
     uint32_t *tcount, *tstep, *n_episodes;   /* tcount = the env's rollout step count (RNG counter) */
     uint32_t *win_count;   /* [P][B] */

@@ -179,3 +179,33 @@ def test_vector_env_adapters_vs_oracle():
         assert np.array_equal(obs["board"].cpu().numpy().astype(np.int64), want)
         finished += int(t2.sum())
     assert finished > BT
+
+
+@pytest.mark.parametrize("dims,K,P,B,rel_mod", [((3, 3), 3, 2, 1000 + 7, None), ((3, 5), 3, 3, 513, None), ((3, 3, 3), 3, 4, 300, 3),
+                                                ((5, 5), 4, 3, 4096 + 1, None), ((1, 1), 2, 2, 70, None), ((4, 8), 4, 5, 257, None)])
+def test_step_observe_fused_matches_separate_calls(dims, K, P, B, rel_mod):
+    """crl_ttt_step_observe (one launch: [sample ->] next_state -> valid mask + observation of the next mover) equals
+    crl_ttt_sample + crl_ttt_step + crl_ttt_valid + crl_ttt_board on a twin batch: sampled and external actions (incl.
+    occupied cells and passes), auto-reset on and off, ragged batches, the 4-player `% 3` observation quirk, a one-cell board."""
+    import torch
+    from colosseumrl_amd.batched import TTTBatch
+    seed, first = 31, 4000
+    a, b = TTTBatch(dims, K, P, B, first_env_id=first), TTTBatch(dims, K, P, B, first_env_id=first)
+    n_cells = int(np.prod(dims))
+    rng = np.random.default_rng(n_cells + P)
+    out = None
+    for t in range(3 * n_cells + 5):
+        auto = (t % 4) != 3
+        if t % 2 == 0:
+            act = b.sample(seed)
+            out = a.step_observe(None, seed=seed, auto_reset=auto, rel_mod=rel_mod, out=out)
+        else:
+            act = torch.from_numpy(rng.integers(-1, n_cells, size=B).astype(np.int8)).cuda()
+            out = a.step_observe(act, seed=seed, auto_reset=auto, rel_mod=rel_mod, out=out)
+        r, tm, w = b.step(act, auto_reset=auto)
+        for k in ("occ", "winner", "to_move", "tcount"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (k, t)
+        assert torch.equal(out["reward"], r) and torch.equal(out["terminal"], tm) and torch.equal(out["winners"], w), t
+        assert torch.equal(out["valid"], b.valid_mask()), t
+        assert torch.equal(out["board"], b.board(b.to_move, rel_mod)), t
+    assert int(b.terminal.sum()) >= 0
