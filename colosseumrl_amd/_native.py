@@ -91,6 +91,7 @@ PROTOTYPES = {
     "crl_blokus_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, _VP, BlokusStats, _VP]),
     "crl_blokus_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
+    "crl_blokus_step_observe": (_I, [_VP, _I64, _U64, _U64] + [_VP] * 15 + [_U32, _VP]),
 }
 
 

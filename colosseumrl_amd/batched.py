@@ -489,6 +489,31 @@ class BlokusBatch:
                                                _ptr(player), _ptr(ob), _ptr(op), _ptr(osc), _stream()), "crl_blokus_observe")
         return {"board": ob, "pieces": op, "score": osc, "player": player.view(self.B, 1)}
 
+    def step_observe(self, action: Optional[torch.Tensor] = None, seed: int = 0, auto_reset: bool = True,
+                     out: Optional[dict] = None):
+        """One ply of every game in ONE launch: plays `action` (int32 [B] dense ids; None = the rollout's random agent
+        at each game's step counter, which then advances) and returns what the next mover needs:
+        {'board' int8 [B, 20, 20], 'pieces' uint8 [B, 4, 21], 'score' int32 [B, 4], 'player' int8 [B, 1] (its observation),
+        'n_valid' int32 [B] (its number of legal actions), 'reward', 'terminal', 'winners'}.
+        Equals ``step(...); valid(); observe(to_move)``."""
+        if action is not None:
+            _want(action, torch.int32, (self.B,), self.device, "action")
+        if out is None:
+            out = {"board": torch.empty((self.B, 20, 20), dtype=torch.int8, device=self.device),
+                   "pieces": torch.empty((self.B, 4, 21), dtype=torch.uint8, device=self.device),
+                   "score": torch.empty((self.B, 4), dtype=torch.int32, device=self.device),
+                   "player": torch.empty((self.B, 1), dtype=torch.int8, device=self.device),
+                   "n_valid": torch.empty((self.B,), dtype=torch.int32, device=self.device)}
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_step_observe(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id,
+                                                    *self._state(), _ptr(action), _ptr(self.tcount), _ptr(self.reward),
+                                                    _ptr(self.terminal), _ptr(self.winners), _ptr(out["n_valid"]),
+                                                    _ptr(out["board"]), _ptr(out["pieces"]), _ptr(out["score"]),
+                                                    _ptr(out["player"]), CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()),
+                  "crl_blokus_step_observe")
+        out["reward"], out["terminal"], out["winners"] = self.reward, self.terminal, self.winners
+        return out
+
     def board(self):
         out = torch.empty((self.B, 20, 20), dtype=torch.int8, device=self.device)
         with torch.cuda.device(self.device):

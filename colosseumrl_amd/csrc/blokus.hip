@@ -627,6 +627,113 @@ blokus_sample_kernel(const BlkTables *__restrict__ tables, const int64_t B, cons
     }
 }
 
+// ---- fused per-ply call: [sample ->] next_state (auto-reset) -> len(valid_actions) and state_to_observation of the player
+// to move next.  What BlokusVectorEnv / a learner runs every ply (BlokusEnvironment.py:357-451, :453-500, :721-768); as
+// separate launches (sample, step, valid, observe) every one of them reloads the board into LDS and rebuilds the allowed /
+// corner rows.  Here the wave that owns the game does all of it on its LDS copy.
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+blokus_step_observe_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
+                           const uint64_t first_env_id, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv_g,
+                           int32_t *__restrict__ score_g, int32_t *__restrict__ round_g, int32_t *__restrict__ to_move_g,
+                           const int32_t *__restrict__ action, uint32_t *__restrict__ tcount, int8_t *__restrict__ reward,
+                           uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners, int32_t *__restrict__ n_valid,
+                           int8_t *__restrict__ obs_board, uint8_t *__restrict__ obs_pieces, int32_t *__restrict__ obs_score,
+                           int8_t *__restrict__ obs_player, const uint32_t flags)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
+    blk_prep(L, lane, round);                                    // allowed / corner rows of the PRE-move board (:424)
+    int id;
+    if (action) {
+        id = __builtin_amdgcn_readfirstlane(action[b]);
+    } else {                                                     // the rollout's random agent at this game's step counter
+        uint32_t ip = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
+        const uint32_t total = blk_count(T, L, pl, ip, lane);
+        const uint32_t tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)tcount[b]);
+        const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
+        const uint32_t sel = tc & 3u;
+        const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+        id = -1;
+        if (total > 0) {
+            const BlkMove mv = blk_select(T, L, pl, ip, __umulhi(word, total), lane);
+            id = ((mv.piece * 400 + mv.y * BN + mv.x) * 8 + mv.orient) * 5 + mv.shift;
+        }
+        if (lane == 0) tcount[b] = tc + 1u;
+    }
+    if (id >= 0 && id < ACTION_IDS) {                            // '' (pass) otherwise (:418)
+        const BlkMove mv = blk_decode(id);
+        blk_apply(T, L, pl, mv, inv, score, lane);
+    }
+    bool any_move = false;
+    for (int q = 0; q < 4 && !any_move; ++q) {                   // old board, old round, NEW inventories (:424)
+        uint32_t iq = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+        any_move = blk_exists(T, L, q, iq, lane);
+    }
+    const BlkOutcome out = blk_outcome(any_move, pl, score);
+    round += (pl == 3) ? 1 : 0;                                  // :446-447
+    pl = (pl + 1) & 3;
+    if (lane == 0) {
+        reward[b] = (int8_t)out.reward;
+        terminal[b] = (uint8_t)out.terminal;
+        winners[b] = (uint8_t)out.winners;
+    }
+    if (out.terminal && (flags & CRL_STEP_AUTO_RESET)) {
+        blk_fresh(L, lane, inv, score);
+        round = 0;
+        pl = 0;
+    }
+    blk_store_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    if (lane == 0) { round_g[b] = round; to_move_g[b] = pl; }
+    // ---- what the next mover needs: its number of legal actions on the NEW board ...
+    blk_prep(L, lane, round);
+    uint32_t ip = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
+    const uint32_t total = blk_count(T, L, pl, ip, lane);
+    if (lane == 0) { n_valid[b] = (int32_t)total; obs_player[b] = (int8_t)pl; }
+    // ... and its observation (:752-768): board relative to it and rotated by np.rot90(k=-pl), four cells per lane and trip
+    for (int d = lane; d < BN * BN / 4; d += 64) {
+        const int i = d / (BN / 4), j0 = (d - i * (BN / 4)) * 4;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            int y, x;                                            // source cell of np.rot90(m, k=-pl)[i][j]
+            switch (pl) {
+                case 0: y = i; x = j; break;
+                case 1: y = BN - 1 - j; x = i; break;
+                case 2: y = BN - 1 - i; x = BN - 1 - j; break;
+                default: y = j; x = BN - 1 - i; break;
+            }
+            int v = -1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = ((L.occ[c][y] >> x) & 1u) ? ((c - pl) & 3) : v;
+            word |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(obs_board + b * (BN * BN))[d] = word;
+    }
+    for (int cell = lane; cell < 4 * NPIECE; cell += 64) {       // pieces[r][piece] of player (r + observer) % 4
+        const int r = cell / NPIECE, piece = cell - r * NPIECE;
+        uint32_t iv = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) iv = (c == ((r + pl) & 3)) ? inv[c] : iv;
+        obs_pieces[b * 4 * NPIECE + cell] = (uint8_t)((iv >> piece) & 1u);
+    }
+    if (lane < 4) {                                              // np.roll(score, -observer)
+        int sc = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc = (c == ((lane + pl) & 3)) ? score[c] : sc;
+        obs_score[b * 4 + lane] = sc;
+    }
+}
+
 __global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
                       const uint64_t first_env_id, const int T_steps, uint32_t *__restrict__ occ, uint32_t *__restrict__ inv_g,
@@ -919,6 +1026,27 @@ int crl_blokus_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t fir
     hipLaunchKernelGGL(blokus_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const BlkTables *)ctx->blokus, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id,
                        occ, inv, score, round, to_move, tcount, advance, action);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                            uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                            const int32_t *action, uint32_t *tcount, int8_t *reward, uint8_t *terminal, uint8_t *winners,
+                            int32_t *n_valid, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, int8_t *obs_player,
+                            uint32_t flags, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_step_observe");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_step_observe: NULL state pointer");
+    CRL_REQUIRE(action || tcount, "crl_blokus_step_observe: action and tcount are both NULL (nothing to play)");
+    CRL_REQUIRE(reward && terminal && winners && n_valid, "crl_blokus_step_observe: NULL step output pointer");
+    CRL_REQUIRE(obs_board && obs_pieces && obs_score && obs_player, "crl_blokus_step_observe: NULL observation pointer");
+    CRL_REQUIRE((((uintptr_t)obs_board) & 3) == 0, "crl_blokus_step_observe: obs_board must be 4-byte aligned");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_blokus_step_observe: unknown flags 0x%x", flags);
+    hipLaunchKernelGGL(blokus_step_observe_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id,
+                       occ, inv, score, round, to_move, action, tcount, reward, terminal, winners, n_valid,
+                       obs_board, obs_pieces, obs_score, obs_player, flags);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -85,8 +85,8 @@ class BlokusVectorEnv:
 
     def step(self, action: torch.Tensor):
         """-> (obs for the next mover, next mover int8 [B], its number of legal actions int32 [B], reward int8 [B] of the
-        player who just moved, done uint8 [B], info); finished games restart (obs / mover / counts are of the new game)."""
-        reward, terminal, winners = self.batch.step(action, auto_reset=True)
-        reward, done, winners = reward.clone(), terminal.clone(), winners.clone()
-        mover = self._mover()
-        return self.batch.observe(mover), mover, self.batch.valid(), reward, done, {"winners": winners}
+        player who just moved, done uint8 [B], info); finished games restart (obs / mover / counts are of the new game).
+        One launch (``BlokusBatch.step_observe``)."""
+        o = self.batch.step_observe(action, auto_reset=True)
+        obs = {"board": o["board"], "pieces": o["pieces"], "score": o["score"], "player": o["player"]}
+        return obs, o["player"].view(-1), o["n_valid"], o["reward"].clone(), o["terminal"].clone(), {"winners": o["winners"].clone()}

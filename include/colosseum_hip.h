@@ -263,6 +263,18 @@ int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const
                        const int8_t *player, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, void *stream);
 /* Board.board_contents as int8 [B][20][20] (0 empty, else colour) */
 int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t *board, void *stream);
+/* One launch for a ply of every game, as a learner / vector env needs it: [sample ->] next_state -> number of legal actions and
+ * state_to_observation of the player to move NEXT.  Exactly equivalent to
+ *   [crl_blokus_sample(..., advance = 1);]  crl_blokus_step(..., flags);  crl_blokus_valid(..., player = NULL, count, NULL);
+ *   crl_blokus_observe(..., player = to_move, ...)
+ * with action == NULL meaning "play the rollout's random agent at tcount[b] and advance tcount" (tcount may be NULL when
+ * actions are given).  n_valid int32 [B]; obs_* as crl_blokus_observe (obs_board 4-byte aligned); obs_player int8 [B] = the
+ * observer = the player to move. */
+int crl_blokus_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
+                            uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,
+                            const int32_t *action, uint32_t *tcount, int8_t *reward, uint8_t *terminal, uint8_t *winners,
+                            int32_t *n_valid, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, int8_t *obs_player,
+                            uint32_t flags, void *stream);
 typedef struct {
     uint32_t *tcount, *tstep, *n_episodes;
     uint32_t *win_count;   /* [4][B] */

@@ -222,3 +222,34 @@ def test_vector_env_adapter_vs_oracle():
         assert np.array_equal(obs["board"].cpu().numpy(), ob) and np.array_equal(obs["pieces"].cpu().numpy(), op)
         assert np.array_equal(obs["score"].cpu().numpy(), osc)
     assert finished > 0
+
+
+def test_step_observe_fused_matches_separate_calls():
+    """crl_blokus_step_observe (one launch: [sample ->] next_state -> legal-action count + observation of the next mover)
+    equals crl_blokus_sample + crl_blokus_step + crl_blokus_valid + crl_blokus_observe on a twin batch, through whole games:
+    sampled and external (legal) actions, passes, auto-reset on and off, a ragged batch (not a multiple of 4 games)."""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    B, seed, first = 45, 17, 300
+    a, b = BlokusBatch(B, first_env_id=first), BlokusBatch(B, first_env_id=first)
+    out = None
+    finished = 0
+    for t in range(120):
+        auto = (t % 7) != 6
+        act = b.sample(seed)                       # a legal action (or -1) for every game; advances b.tcount
+        if t % 3 == 0:
+            out = a.step_observe(None, seed=seed, auto_reset=auto, out=out)      # the fused call samples the same action itself
+        else:
+            a.tcount.copy_(b.tcount)                                              # external actions do not touch the counter
+            out = a.step_observe(act, seed=seed, auto_reset=auto, out=out)
+        r, tm, w = b.step(act, auto_reset=auto)
+        for k in ("occ", "inv", "score", "round", "to_move", "tcount"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (k, t)
+        assert torch.equal(out["reward"], r) and torch.equal(out["terminal"], tm) and torch.equal(out["winners"], w), t
+        assert torch.equal(out["n_valid"], b.valid()), t
+        mover = b.to_move.to(torch.int8)
+        assert torch.equal(out["player"].view(-1), mover), t
+        o2 = b.observe(mover)
+        assert torch.equal(out["board"], o2["board"]) and torch.equal(out["pieces"], o2["pieces"]) and torch.equal(out["score"], o2["score"]), t
+        finished += int(tm.sum())
+    assert finished > 0
