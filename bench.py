@@ -388,6 +388,18 @@ def step_api_rates(torch, device, copy_gbs):
     wall, gpu = rate(lambda: tt.step(a, auto_reset=True), 1000)
     out["ttt_3x5_step_auto_reset"] = {"env_steps_per_s": Bt / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
                                       "algorithmic_GBs": 26 * Bt / gpu / 1e9, "games": Bt}
+
+    def ttt_unfused():
+        tt.step(tt.sample(3), auto_reset=True)
+        tt.valid_mask()
+        tt.board(tt.to_move)
+    wall, gpu = rate(ttt_unfused, 500)
+    out["ttt_3x5_sample_step_valid_board_4calls"] = {"env_steps_per_s": Bt / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6}
+    if hasattr(tt, "step_observe"):
+        to = tt.step_observe(None, seed=3)
+        wall, gpu = rate(lambda: tt.step_observe(None, seed=3, out=to), 500)
+        out["ttt_3x5_step_observe_fused"] = {"env_steps_per_s": Bt / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                             "what": "ONE launch: sample -> next_state (auto-reset) -> valid mask + observation of the next mover"}
     del tt
     Bb = 16384
     bb = BlokusBatch(Bb, device=device)
@@ -406,6 +418,18 @@ def step_api_rates(torch, device, copy_gbs):
     pl = torch.zeros((Bb,), dtype=torch.int8, device=device)
     wall, gpu = rate(lambda: bb.observe(pl), 100)
     out["blokus_observe"] = {"obs_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6}
+
+    def blokus_unfused():
+        bb.step(bb.sample(5), auto_reset=True)
+        bb.valid()
+        bb.observe(bb.to_move.to(torch.int8))
+    wall, gpu = rate(blokus_unfused, 100)
+    out["blokus_sample_step_valid_observe_4calls"] = {"env_steps_per_s": Bb / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6}
+    if hasattr(bb, "step_observe"):
+        bo = bb.step_observe(None, seed=5)
+        wall, gpu = rate(lambda: bb.step_observe(None, seed=5, out=bo), 100)
+        out["blokus_step_observe_fused"] = {"env_steps_per_s": Bb / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
+                                            "what": "ONE launch: sample -> next_state (auto-reset) -> legal-action count + observation of the next mover"}
     return out
 
 
