@@ -247,14 +247,15 @@ def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs):
 
 
 def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
-    """On-box streaming ceiling (HBM bytes moved / time; SURVEY 8d's second peak): the best of the runtime's
-    device-to-device copy, two vectorised read+write kernels (16 bytes per lane) and a pure write stream over a 1 GiB
-    buffer.  (The per-step kernels write four times what they read, so a balanced copy alone is not their ceiling.)"""
+    """On-box streaming ceilings over a 1 GiB buffer (HBM bytes moved / time; SURVEY 8d's second peak):
+    `copy` = the best of the runtime's device-to-device copy and two vectorised read+write kernels (16 bytes per lane);
+    `write` = a pure write stream (the per-step kernels write four times what they read, so a balanced copy alone is not
+    their ceiling).  Returns (copy GB/s, write GB/s)."""
     src = torch.empty(nbytes // 4, dtype=torch.int32, device=device).fill_(1)
     dst = torch.empty_like(src)
-    best = 0.0
-    for op, moved in ((lambda: dst.copy_(src), 2.0 * nbytes), (lambda: torch.add(src, 1, out=dst), 2.0 * nbytes),
-                      (lambda: torch.bitwise_xor(src, 1, out=dst), 2.0 * nbytes), (lambda: dst.fill_(3), 1.0 * nbytes)):
+    best = [0.0, 0.0]
+    for which, op, moved in ((0, lambda: dst.copy_(src), 2.0 * nbytes), (0, lambda: torch.add(src, 1, out=dst), 2.0 * nbytes),
+                             (0, lambda: torch.bitwise_xor(src, 1, out=dst), 2.0 * nbytes), (1, lambda: dst.fill_(3), 1.0 * nbytes)):
         op()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,9 +264,9 @@ def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
             op()
         e1.record()
         torch.cuda.synchronize()
-        best = max(best, moved / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9)
+        best[which] = max(best[which], moved / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9)
     del src, dst
-    return best
+    return best[0], best[1]
 
 
 # ---------------------------------------------------------------------------------------------- measurements
@@ -324,8 +325,9 @@ def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
     return out
 
 
-def step_api_rates(torch, device, copy_gbs):
+def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     """The per-step batched API (external or sampled actions, every output written every step)."""
+    stream_gbs = max(copy_gbs or 0.0, write_gbs or 0.0) or None
     from colosseumrl_amd.batched import BlokusBatch, TronBatch, TTTBatch
     out = {}
 
@@ -358,6 +360,7 @@ def step_api_rates(torch, device, copy_gbs):
     out["tron_n20_observe_all"] = {"games_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
                                    "GBs": nbytes / gpu / 1e9, "frac_of_hbm_peak": nbytes / gpu / 1e9 / HBM_PEAK_GBS,
                                    "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None,
+                                   "frac_of_stream": nbytes / gpu / 1e9 / stream_gbs if stream_gbs else None,
                                    "bytes_per_call": nbytes, "what": "N*N in + P*N*N out per game (all P observers)"}
 
     def unfused():
@@ -376,6 +379,7 @@ def step_api_rates(torch, device, copy_gbs):
         out["tron_n20_step_observe_fused"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
                                               "GBs": nbytes / gpu / 1e9, "frac_of_hbm_peak": nbytes / gpu / 1e9 / HBM_PEAK_GBS,
                                               "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None,
+                                              "frac_of_stream": nbytes / gpu / 1e9 / stream_gbs if stream_gbs else None,
                                               "bytes_per_call": nbytes,
                                               "what": "ONE launch: sample -> next_state (auto-reset) -> state_to_observation of all P observers; "
                                                       "bytes counted = N*N in + P*N*N out per game"}
@@ -463,7 +467,9 @@ def main():
     use_dist = dist.is_initialized()
 
     if args.only_step_api:
-        print(json.dumps({"step_api": step_api_rates(torch, device, measure_copy_bandwidth(torch, device))}))
+        copy_gbs, write_gbs = measure_copy_bandwidth(torch, device)
+        print(json.dumps({"copy_peak_GBs": copy_gbs, "write_stream_peak_GBs": write_gbs,
+                          "step_api": step_api_rates(torch, device, copy_gbs, write_gbs)}))
         return
 
     game, kw, batch, default_chunk = WORKLOADS[args.workload][:4]
@@ -499,7 +505,7 @@ def main():
         elapsed = float(tt.item())
     if rank == 0:
         mean_len, n_ep = mean_episode_len(gathered)
-        copy_gbs = measure_copy_bandwidth(torch, device) if world == 1 else None
+        copy_gbs, write_gbs = measure_copy_bandwidth(torch, device) if world == 1 else (None, None)
         value = world * batch * args.steps / elapsed
         # launches of the timed region are equal-sized when steps % chunk == 0; otherwise the roofline describes the
         # dominant (first) launch shape and uses the mean launch time only as an approximation -- flagged below
@@ -539,7 +545,9 @@ def main():
                     continue
                 others[wl] = steady_state(torch, wl, device, args.seed, copy_gbs)
             out["others"] = others
-            out["step_api"] = step_api_rates(torch, device, copy_gbs)
+            out["step_api"] = step_api_rates(torch, device, copy_gbs, write_gbs)
+            out["stream_peaks"] = {"copy_GBs": copy_gbs, "write_GBs": write_gbs,
+                                   "what": "measured in this run over 1 GiB: best read+write copy, pure write stream"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
             if "placement_tests_per_env_step" in out["cpu_baseline"]:
