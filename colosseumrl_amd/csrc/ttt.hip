@@ -174,6 +174,44 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = (int32_t)dr; }
 }
 
+// int8 [B][cells] boards of the 256 games of a workgroup from their occupancy masks in LDS: -1 empty, else the owner's
+// id -- relative to s_rel[game] when that is >= 0 (_relative_player_id, tictactoe_2p_env.py:26-27: python's non-negative
+// modulo by rel_mod).  One dword (four cells) per thread and trip, written coalesced; the bytes of a workgroup start at
+// a multiple of 256 * cells, so dword stores are aligned whenever the buffer is.
+template <int P>
+__device__ __forceinline__ void ttt_write_boards(const uint32_t (&s_occ)[P][256], const int (&s_rel)[256], const int cells,
+                                                 const uint32_t inv_cells, const int rel_mod, const int64_t g0, const int64_t B,
+                                                 int8_t *__restrict__ obs)
+{
+    const int n_game = (int)((B - g0) < 256 ? (B - g0) : 256);
+    const int total = n_game * cells;
+    int8_t *out = obs + g0 * cells;
+    for (int d = threadIdx.x; d * 4 < total; d += 256) {
+        int e = cells == 1 ? d * 4 : (int)__umulhi((uint32_t)(d * 4), inv_cells);
+        int c = d * 4 - e * cells;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ee = e < 256 ? e : 255;       // bytes past the last game of the block are never stored
+            int v = -1;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v = ((s_occ[p][ee] >> c) & 1u) ? p : v;
+            const int rel = s_rel[ee];
+            if (v >= 0 && rel >= 0) {
+                const int rr = (v - rel) % rel_mod;
+                v = rr < 0 ? rr + rel_mod : rr;
+            }
+            word |= (uint32_t)(v & 0xff) << (8 * k);
+            if (++c == cells) { c = 0; ++e; }
+        }
+        if (d * 4 + 4 <= total) {
+            *reinterpret_cast<uint32_t *>(out + d * 4) = word;
+        } else {
+            for (int k = 0; d * 4 + k < total; ++k) out[d * 4 + k] = (int8_t)(word >> (8 * k));
+        }
+    }
+}
+
 // ---- fused per-step call: [sample ->] next_state (auto-reset) -> valid_actions mask + state_to_observation of the
 // player to move next.  What a learner / vector env runs every ply (tictactoe_2p_env.py:240-315, :317-348, :382-407);
 // as separate launches (crl_ttt_sample, crl_ttt_step, crl_ttt_valid, crl_ttt_board) the launch boundaries cost more than
@@ -237,34 +275,7 @@ ttt_step_observe_kernel(const ttt_dirs dd, const uint32_t inv_cells, const int64
     for (int p = 0; p < P; ++p) s_occ[p][threadIdx.x] = o[p];
     s_mover[threadIdx.x] = tm;
     __syncthreads();
-    // observation bytes [g0 * cells, (g0 + n_game) * cells): one dword per thread and trip
-    const int cells = dd.n_cells;
-    const int n_game = (int)((B - g0) < 256 ? (B - g0) : 256);
-    const int total = n_game * cells;
-    int8_t *out = obs + g0 * cells;
-    for (int d = threadIdx.x; d * 4 < total; d += 256) {
-        int e = cells == 1 ? d * 4 : (int)__umulhi((uint32_t)(d * 4), inv_cells);
-        int c = d * 4 - e * cells;
-        uint32_t word = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ee = e < 256 ? e : 255;       // bytes past the last game of the block are never stored
-            int v = -1;
-#pragma unroll
-            for (int p = 0; p < P; ++p) v = ((s_occ[p][ee] >> c) & 1u) ? p : v;
-            if (v >= 0) {                           // _relative_player_id (2p:26-27): python's non-negative modulo
-                const int rr = (v - s_mover[ee]) % rel_mod;
-                v = rr < 0 ? rr + rel_mod : rr;
-            }
-            word |= (uint32_t)(v & 0xff) << (8 * k);
-            if (++c == cells) { c = 0; ++e; }
-        }
-        if (d * 4 + 4 <= total) {
-            *reinterpret_cast<uint32_t *>(out + d * 4) = word;
-        } else {
-            for (int k = 0; d * 4 + k < total; ++k) out[d * 4 + k] = (int8_t)(word >> (8 * k));
-        }
-    }
+    ttt_write_boards<P>(s_occ, s_mover, dd.n_cells, inv_cells, rel_mod, g0, B, obs);
 }
 
 // the rollout's random agent for one step
@@ -308,23 +319,21 @@ ttt_valid_kernel(const int P, const uint32_t full, const int64_t B, const uint32
     valid[b] = full & ~all;
 }
 
-// one thread per output byte: coalesced int8 [B][cells] writes, occ words come from L1/L2
+// board export / state_to_observation for 256 games per workgroup: masks into LDS (coalesced), then ttt_write_boards
+template <int P>
 __global__ void __launch_bounds__(256)
-ttt_board_kernel(const int P, const int n_cells, const int64_t B, const uint32_t *__restrict__ occ,
+ttt_board_kernel(const int n_cells, const uint32_t inv_cells, const int64_t B, const uint32_t *__restrict__ occ,
                  const int8_t *__restrict__ player, const int rel_mod, int8_t *__restrict__ board)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * n_cells) return;
-    const int64_t b = i / n_cells;
-    const int c = (int)(i - b * n_cells);
-    int v = -1;
-    for (int p = 0; p < P; ++p) v = ((occ[p * B + b] >> c) & 1u) ? p : v;
-    if (player && v >= 0) {
-        // _relative_player_id (2p:26-27): (abs - current) % rel_mod with Python's non-negative modulo
-        int r = (v - (int)player[b]) % rel_mod;
-        v = r < 0 ? r + rel_mod : r;
-    }
-    board[i] = (int8_t)v;
+    __shared__ uint32_t s_occ[P][256];
+    __shared__ int s_rel[256];
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t b = g0 + threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < P; ++p) s_occ[p][threadIdx.x] = b < B ? occ[p * B + b] : 0u;
+    s_rel[threadIdx.x] = (player && b < B) ? (int)player[b] : -1;
+    __syncthreads();
+    ttt_write_boards<P>(s_occ, s_rel, n_cells, inv_cells, rel_mod, g0, B, board);
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -469,8 +478,13 @@ int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8
     TTT_CTX_CHECK("crl_ttt_board");
     CRL_REQUIRE(occ && board, "crl_ttt_board: NULL pointer");
     CRL_REQUIRE(player == nullptr || rel_mod >= 1, "crl_ttt_board: rel_mod must be >= 1 when player is given");
-    hipLaunchKernelGGL(ttt_board_kernel, dim3(blocks_for(B * ctx->ttt.n_cells, 256)), dim3(256), 0, (hipStream_t)stream,
-                       ctx->ttt.P, ctx->ttt.n_cells, B, occ, player, rel_mod, board);
+    CRL_REQUIRE((((uintptr_t)board) & 3) == 0, "crl_ttt_board: board must be 4-byte aligned");
+    const int cells = ctx->ttt.n_cells;
+    const uint32_t inv_cells = cells == 1 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)cells) + 1u;
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        hipLaunchKernelGGL((ttt_board_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cells, inv_cells, B, occ, player, rel_mod < 1 ? 1 : rel_mod, board);
+    });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

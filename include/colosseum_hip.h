@@ -192,7 +192,7 @@ int crl_ttt_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, int8_t *winner, i
                  uint32_t flags, void *stream);
 /* replaces TicTacToe*.valid_actions (tictactoe_2p_env.py:317-348): empties bitmask uint32 [B] */
 int crl_ttt_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, uint32_t *valid, void *stream);
-/* int8 [B][cells] board in the reference encoding (-1 empty), relative to `player` when player != NULL
+/* int8 [B][cells] board (4-byte aligned) in the reference encoding (-1 empty), relative to `player` when player != NULL
  * (reference _relative_player_id, tictactoe_2p_env.py:26-27, modulus given by rel_mod) */
 int crl_ttt_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, int rel_mod,
                   int8_t *board, void *stream);
