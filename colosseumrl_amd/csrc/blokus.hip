@@ -627,6 +627,48 @@ blokus_sample_kernel(const BlkTables *__restrict__ tables, const int64_t B, cons
     }
 }
 
+// state_to_observation of game b for observer pl (BlokusEnvironment.py:752-768) by the wave that holds the game's row
+// bitboards in LDS: board = -1 empty else (owner - observer) % 4, rotated by np.rot90(k=-pl), four cells (one dword) per
+// lane and trip; pieces[r][i] = inventory bit i of player (r + observer) % 4; score rolled by -observer.
+__device__ __forceinline__ void blk_write_observation(const uint32_t (&occ)[4][BN], const uint32_t (&inv)[4], const int (&score)[4],
+                                                      const int pl, const int64_t b, const int lane, int8_t *__restrict__ obs_board,
+                                                      uint8_t *__restrict__ obs_pieces, int32_t *__restrict__ obs_score)
+{
+    for (int d = lane; d < BN * BN / 4; d += 64) {
+        const int i = d / (BN / 4), j0 = (d - i * (BN / 4)) * 4;
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            int y, x;                                            // source cell of np.rot90(m, k=-pl)[i][j]
+            switch (pl) {
+                case 0: y = i; x = j; break;
+                case 1: y = BN - 1 - j; x = i; break;
+                case 2: y = BN - 1 - i; x = BN - 1 - j; break;
+                default: y = j; x = BN - 1 - i; break;
+            }
+            int v = -1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = ((occ[c][y] >> x) & 1u) ? ((c - pl) & 3) : v;
+            word |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(obs_board + b * (BN * BN))[d] = word;
+    }
+    for (int cell = lane; cell < 4 * NPIECE; cell += 64) {       // pieces[r][piece] of player (r + observer) % 4
+        const int r = cell / NPIECE, piece = cell - r * NPIECE;
+        uint32_t iv = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) iv = (c == ((r + pl) & 3)) ? inv[c] : iv;
+        obs_pieces[b * 4 * NPIECE + cell] = (uint8_t)((iv >> piece) & 1u);
+    }
+    if (lane < 4) {                                              // np.roll(score, -observer)
+        int sc = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc = (c == ((lane + pl) & 3)) ? score[c] : sc;
+        obs_score[b * 4 + lane] = sc;
+    }
+}
+
 // ---- fused per-ply call: [sample ->] next_state (auto-reset) -> len(valid_actions) and state_to_observation of the player
 // to move next.  What BlokusVectorEnv / a learner runs every ply (BlokusEnvironment.py:357-451, :453-500, :721-768); as
 // separate launches (sample, step, valid, observe) every one of them reloads the board into LDS and rebuilds the allowed /
@@ -698,40 +740,8 @@ blokus_step_observe_kernel(const BlkTables *__restrict__ tables, const int64_t B
     for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
     const uint32_t total = blk_count(T, L, pl, ip, lane);
     if (lane == 0) { n_valid[b] = (int32_t)total; obs_player[b] = (int8_t)pl; }
-    // ... and its observation (:752-768): board relative to it and rotated by np.rot90(k=-pl), four cells per lane and trip
-    for (int d = lane; d < BN * BN / 4; d += 64) {
-        const int i = d / (BN / 4), j0 = (d - i * (BN / 4)) * 4;
-        uint32_t word = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + k;
-            int y, x;                                            // source cell of np.rot90(m, k=-pl)[i][j]
-            switch (pl) {
-                case 0: y = i; x = j; break;
-                case 1: y = BN - 1 - j; x = i; break;
-                case 2: y = BN - 1 - i; x = BN - 1 - j; break;
-                default: y = j; x = BN - 1 - i; break;
-            }
-            int v = -1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v = ((L.occ[c][y] >> x) & 1u) ? ((c - pl) & 3) : v;
-            word |= (uint32_t)(v & 0xff) << (8 * k);
-        }
-        reinterpret_cast<uint32_t *>(obs_board + b * (BN * BN))[d] = word;
-    }
-    for (int cell = lane; cell < 4 * NPIECE; cell += 64) {       // pieces[r][piece] of player (r + observer) % 4
-        const int r = cell / NPIECE, piece = cell - r * NPIECE;
-        uint32_t iv = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) iv = (c == ((r + pl) & 3)) ? inv[c] : iv;
-        obs_pieces[b * 4 * NPIECE + cell] = (uint8_t)((iv >> piece) & 1u);
-    }
-    if (lane < 4) {                                              // np.roll(score, -observer)
-        int sc = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sc = (c == ((lane + pl) & 3)) ? score[c] : sc;
-        obs_score[b * 4 + lane] = sc;
-    }
+    // ... and its observation (:752-768)
+    blk_write_observation(L.occ, inv, score, pl, b, lane, obs_board, obs_pieces, obs_score);
 }
 
 __global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
@@ -861,34 +871,30 @@ blokus_board_kernel(const int64_t B, const uint32_t *__restrict__ occ, int8_t *_
     board[i] = (int8_t)v;
 }
 
-// state_to_observation (BlokusEnvironment.py:721-768) for every game: one thread per output board cell, plus
-// the (4, 21) inventory matrix and the rolled scores written by the first threads of each game's slice.
+// state_to_observation (BlokusEnvironment.py:721-768) for every game: one wave per game -- its 80 row words go through LDS
+// (one coalesced load), then blk_write_observation emits the rotated board a dword per lane (the first version spent one
+// thread, four cached row loads and a byte store on every cell)
 __global__ void __launch_bounds__(256)
 blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const uint32_t *__restrict__ inv,
                       const int32_t *__restrict__ score, const int8_t *__restrict__ player, int8_t *__restrict__ obs_board,
                       uint8_t *__restrict__ obs_pieces, int32_t *__restrict__ obs_score)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * BN * BN) return;
-    const int64_t b = t / (BN * BN);
-    const int cell = (int)(t - b * BN * BN), i = cell / BN, j = cell - i * BN;
-    const int pl = player[b] & 3;
-    int y, x;                                               // source cell of np.rot90(m, k=-pl)[i][j]
-    switch (pl) {
-        case 0: y = i; x = j; break;
-        case 1: y = BN - 1 - j; x = i; break;
-        case 2: y = BN - 1 - i; x = BN - 1 - j; break;
-        default: y = j; x = BN - 1 - i; break;
-    }
-    int v = -1;
+    __shared__ uint32_t s_occ[4][4][BN];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    for (int i = lane; i < 4 * BN; i += 64) s_occ[wave][i / BN][i % BN] = occ[b * 4 * BN + i];
+    uint32_t iv[4];
+    int sc[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v = ((occ[(b * 4 + c) * BN + y] >> x) & 1u) ? ((c - pl) & 3) : v;
-    obs_board[t] = (int8_t)v;
-    if (cell < 4 * NPIECE) {                                // pieces[r][piece] of player (r + observer) % 4
-        const int r = cell / NPIECE, piece = cell - r * NPIECE;
-        obs_pieces[b * 4 * NPIECE + cell] = (uint8_t)((inv[b * 4 + ((r + pl) & 3)] >> piece) & 1u);
+    for (int c = 0; c < 4; ++c) {
+        iv[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv[b * 4 + c]);
+        sc[c] = __builtin_amdgcn_readfirstlane(score[b * 4 + c]);
     }
-    if (cell < 4) obs_score[b * 4 + cell] = score[b * 4 + ((cell + pl) & 3)];   // np.roll(score, -observer)
+    const int pl = __builtin_amdgcn_readfirstlane((int)player[b]) & 3;
+    wave_sync();
+    blk_write_observation(s_occ[wave], iv, sc, pl, b, lane, obs_board, obs_pieces, obs_score);
 }
 
 } // namespace
@@ -1010,8 +1016,8 @@ int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const
     BLK_CTX_CHECK("crl_blokus_observe");
     CRL_REQUIRE(occ && inv && score && player, "crl_blokus_observe: NULL input pointer");
     CRL_REQUIRE(obs_board && obs_pieces && obs_score, "crl_blokus_observe: NULL output pointer");
-    const int64_t n = B * BN * BN;
-    hipLaunchKernelGGL(blokus_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    CRL_REQUIRE((((uintptr_t)obs_board) & 3) == 0, "crl_blokus_observe: obs_board must be 4-byte aligned");
+    hipLaunchKernelGGL(blokus_observe_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        B, occ, inv, score, player, obs_board, obs_pieces, obs_score);
     CRL_LAUNCH_CHECK();
     return CRL_OK;

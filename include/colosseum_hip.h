@@ -257,7 +257,7 @@ int crl_blokus_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, uint32_t *inv,
 int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                      const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *count, uint32_t *mask, void *stream);
 /* replaces BlokusEnvironment.state_to_observation (BlokusEnvironment.py:721-768) for observer player[b]:
- * obs_board int8 [B][20][20] (-1 empty, else (owner - observer) % 4, rotated by np.rot90(k=-observer)),
+ * obs_board int8 [B][20][20], 4-byte aligned (-1 empty, else (owner - observer) % 4, rotated by np.rot90(k=-observer)),
  * obs_pieces uint8 [B][4][21] (row r = player (r + observer) % 4), obs_score int32 [B][4] (rolled by -observer) */
 int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                        const int8_t *player, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, void *stream);
