@@ -18,6 +18,7 @@ CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
 CRL_ROLLOUT_BITS = 8
+CRL_ROLLOUT_QUAD = 16
 
 _lib = None
 _lock = threading.Lock()

@@ -904,6 +904,286 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     }
 }
 
+// ---- quad rollout: one lane per PLAYER, four lanes per game (P <= 4, boards up to 20x20) ---------------------------
+// 65,536 games are 1,024 waves when a lane is a game: one wave per SIMD, and a lone wave issues one instruction per ~5.9
+// cycles where an occupied SIMD issues one per ~2.2-2.9 (profiles/r2_valu_issue_calibration.json).  More waves need
+// more lanes per game, and that pays only if the per-lane work shrinks with it.  It does, because players almost never
+// interact: a player's target is another player's head, or two players target the same cell, in 0.08 % of game-steps
+// (5 % of 64-game wave-steps, 1.3 % of 16-game wave-steps).  So a lane plays ONE player -- probe, decode, die or
+// move, trail write -- and the quad only shares what is per game: the terminal test (two DPP adds), the reset, the
+// random word.  The sequential semantics of the reference (CyTronGrid.pyx:15-62) are needed only when a wave detects an
+// interaction (six DPP xors + min3 per lane); that wave-step then gathers the four players of every quad with DPP
+// broadcasts and runs the same tron_resolve_lds as the lane-per-game kernel, in all four lanes redundantly.
+// Slabs, tags, rolling row rewrite, RNG and copy-in / copy-out are those of tron_rollout_lds_kernel; a workgroup holds
+// 64 games (34 KB of LDS at 20x20), four workgroups fit a CU: 16 waves = 4 per SIMD.  Results are bit-identical.
+template <int CTRL>
+__device__ __forceinline__ int tron_quad(const int v)          // v of the lane quad_perm CTRL selects inside the quad
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+template <int RS>
+__global__ void __launch_bounds__(256, 4)
+tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
+                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                         int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                         int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    constexpr int kGames = 64, kWaveGames = 16;
+    constexpr int kRowDwords = RS / 4;
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    constexpr int OB = 3;                                       // P <= 4: owners 1..4, 5 tag bits
+    constexpr uint32_t kTags = (1u << (8 - OB)) - 1u;           // the all-ones tag is never used: 0xff stays "wall"
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN, P = cfg.P;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int p = lane & 3;                                     // my player
+    const int slot = threadIdx.x >> 2;                          // my game's slab in this workgroup
+    const int64_t b = (int64_t)blockIdx.x * kGames + slot;
+    const bool gvalid = b < B;
+    const bool pvalid = gvalid && p < P;
+    const int64_t bb = gvalid ? b : 0;
+    const int64_t env0 = (int64_t)blockIdx.x * kGames + wave * kWaveGames;   // first game of this wave
+    const int n_env = (int)((B - env0) < kWaveGames ? (B - env0 > 0 ? B - env0 : 0) : kWaveGames);
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const int mine = lds0 + slot * pad.stride;                  // my game's slab
+    const int slab0 = lds0 + wave * kWaveGames * pad.stride;    // first slab of this wave
+    const bool wide = (N & 3) == 0 && N >= 8;
+    // ---- prologue: every global load in flight together (the wave's boards, my player's state, the running totals)
+    constexpr int kCopyBatch = 7;                               // 16 boards of <= 400 bytes = <= 6.25 KiB per wave
+    const int8_t *gslab_in = board + env0 * NN;
+    const int bytes_in = n_env * NN;
+    uint4 cin[kCopyBatch];
+    if (wide) {
+#pragma unroll
+        for (int k = 0; k < kCopyBatch; ++k) {
+            const int off = lane * 16 + k * (CRL_WAVE * 16);
+            cin[k] = *reinterpret_cast<const uint4 *>(gslab_in + (off < bytes_in ? off : 0));
+        }
+    }
+    const int h_in = pvalid ? heads[p * B + bb] : 0;
+    const int d_in = pvalid ? dirs[p * B + bb] : 0;
+    int k = pvalid ? deaths[p * B + bb] : 1;                    // a seat without a player counts as dead for good
+    const int old_ret = pvalid ? st.ret_sum[p * B + bb] : 0;
+    const uint32_t old_wins = pvalid ? st.win_count[p * B + bb] : 0u;
+    uint32_t tc = gvalid ? st.tcount[bb] : 0u, ts = gvalid ? st.tstep[bb] : 0u;
+    const uint32_t old_n_ep = gvalid ? st.n_episodes[bb] : 0u, old_len_sum = gvalid ? st.len_sum[bb] : 0u;
+    const uint32_t old_last_w = gvalid ? st.last_winners[bb] : 0u;
+    // walls everywhere (each lane a quarter of its game's slab), then the cells
+    for (int off = 4 * p; off < pad.stride; off += 16) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wide) {
+#pragma unroll
+        for (int k2 = 0; k2 < kCopyBatch; ++k2) {
+            const int off = lane * 16 + k2 * (CRL_WAVE * 16);
+            if (off < bytes_in) {
+                const uint32_t w[4] = {cin[k2].x, cin[k2].y, cin[k2].z, cin[k2].w};
+                const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                int o[4];
+                tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+                const int sb = slab0 + e * pad.stride;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]) = w[q];
+            }
+        }
+    } else {
+        for (int e = 0; e < n_env; ++e)
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab_in[(int64_t)e * NN + c];
+            }
+    }
+    // ---- my player: head as an LDS address, the start layout for resets
+    const int junk = mine + pad.junk + p;                       // four junk bytes per slab: one per lane of the quad
+    int fh = cfg.start_heads[0], fd = cfg.start_dirs[0];
+    fh = (p == 1) ? cfg.start_heads[1] : fh; fd = (p == 1) ? cfg.start_dirs[1] : fd;
+    fh = (p == 2) ? cfg.start_heads[2] : fh; fd = (p == 2) ? cfg.start_dirs[2] : fd;
+    fh = (p == 3) ? cfg.start_heads[3] : fh; fd = (p == 3) ? cfg.start_dirs[3] : fd;
+    const int fy = (int)__umulhi((uint32_t)(fh < 0 ? 0 : fh), g.inv_n);
+    const int fresh_h = (p < P) ? mine + (fy + 1) * RS + (fh - fy * N) : junk;
+    const int fresh_d = fd, fresh_k = (p < P) ? 0 : 1;
+    int h, d = d_in & 3;
+    {
+        const int hc = min(max(h_in, 0), NN - 1);
+        const int y = (int)__umulhi((uint32_t)hc, g.inv_n);
+        h = pvalid ? mine + (y + 1) * RS + (hc - y * N) : junk;   // a seat without a player never matches a target
+    }
+    // my share of a fresh row (dwords p and p + 4): cells 0, walls 0xff
+    uint32_t rp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = p + 4 * i;
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w |= (4 * j + c < N) ? 0u : (0xffu << (8 * c));
+        rp[i] = w;
+    }
+    int sweep = mine + RS;
+    const int sweep_end = mine + (N + 1) * RS;
+    const int junk_dw = mine + pad.junk;                        // the four junk bytes as one dword
+    uint32_t tagbits = 0, stamp = (uint32_t)(p + 1);
+    const uint32_t ts_at_entry = ts;
+    uint32_t alive_steps = 0, wins = 0, n_ep = 0;
+    int last_len = 0, last_alive = 0;
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+    TronRng<4> rng;                                             // the game's stream, kept by all four lanes of the quad
+    rng.start(gid, tc, seed_lo, seed_hi);
+    __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
+    auto draw = [&](const uint32_t c) -> int {                  // my player's action code (0, 1, 3) of step c, then advance
+        const bool odd = c & 1u;
+        const uint32_t code = act_lut[__umulhi(rng.lo.w0 * (odd ? 81u : 1u), 81u)];
+        rng.advance(gid, c, seed_lo, seed_hi);
+        return (int)((code >> (2 * p)) & 3u);
+    };
+    int act = draw(tc);
+    for (int t = 0; t < T; ++t) {
+        const bool run = k == 0;
+        const int dir = (d + act) & 3;
+        const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir << 3, 8);
+        const int tq = run ? tgt : junk;                        // a dead player probes (and "moves" to) its own junk byte
+        const int raw = *(const lds_u8 *)(uintptr_t)(uint32_t)tq;
+        tc += 1;
+        int act_next = draw(tc);                                // the NEXT step's action, behind the probe
+        // does anything in this wave need the reference's sequential order?  my target against the other players'
+        // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell)
+        const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
+        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq), y3 = tq ^ tron_quad<0x93>(tq);
+        const uint32_t near = min(min((uint32_t)x1, min((uint32_t)x2, (uint32_t)x3)), min((uint32_t)y1, min((uint32_t)y2, (uint32_t)y3)));
+        // (the action table's byte is taken out of the LDS queue here, where the wave waits for the probe anyway: left
+        //  to the compiler the wait lands at the top of the next step as lgkmcnt(0), behind this step's stores)
+        asm volatile("" : "+v"(act_next));
+        act = act_next;
+        if (__builtin_amdgcn_ballot_w64(near == 0u)) {
+            // rare: gather the quad and resolve in the reference's order, redundantly in its four lanes
+            TronRegs<4> s;
+            TronProbe<4> pr;
+            uint32_t stamp4[4];
+            s.h[0] = tron_quad<0x00>(h); s.h[1] = tron_quad<0x55>(h); s.h[2] = tron_quad<0xAA>(h); s.h[3] = tron_quad<0xFF>(h);
+            s.d[0] = tron_quad<0x00>(d); s.d[1] = tron_quad<0x55>(d); s.d[2] = tron_quad<0xAA>(d); s.d[3] = tron_quad<0xFF>(d);
+            s.k[0] = tron_quad<0x00>(k); s.k[1] = tron_quad<0x55>(k); s.k[2] = tron_quad<0xAA>(k); s.k[3] = tron_quad<0xFF>(k);
+            pr.tgt[0] = tron_quad<0x00>(tgt); pr.tgt[1] = tron_quad<0x55>(tgt); pr.tgt[2] = tron_quad<0xAA>(tgt); pr.tgt[3] = tron_quad<0xFF>(tgt);
+            pr.raw[0] = tron_quad<0x00>(raw); pr.raw[1] = tron_quad<0x55>(raw); pr.raw[2] = tron_quad<0xAA>(raw); pr.raw[3] = tron_quad<0xFF>(raw);
+            pr.ndir[0] = tron_quad<0x00>(dir); pr.ndir[1] = tron_quad<0x55>(dir); pr.ndir[2] = tron_quad<0xAA>(dir); pr.ndir[3] = tron_quad<0xFF>(dir);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stamp4[q] = tagbits | (uint32_t)(q + 1);
+            const LdsBoard<OB> bd{tagbits};
+            tron_resolve_lds<4>(bd, s, pr, stamp4, junk);       // trail writes of all four players from every lane: identical
+            h = s.h[0]; d = s.d[0]; k = s.k[0];
+            h = (p == 1) ? s.h[1] : h; d = (p == 1) ? s.d[1] : d; k = (p == 1) ? s.k[1] : k;
+            h = (p == 2) ? s.h[2] : h; d = (p == 2) ? s.d[2] : d; k = (p == 2) ? s.k[2] : k;
+            h = (p == 3) ? s.h[3] : h; d = (p == 3) ? s.d[3] : d; k = (p == 3) ? s.k[3] : k;
+            h = (p < P) ? h : junk;
+        } else {
+            const uint32_t x = (uint32_t)raw ^ tagbits;         // same tag: the tag bits cancel and x IS the owner
+            int v = x < (1u << OB) ? (int)x : 0;
+            v = (raw == kWallCell) ? p + 1 : v;                 // :47-48 a wall kills like the player's own trail
+            const bool moved = run & (v == 0);                  // :60-62
+            k = run ? v : k;                                    // :51-55 (v == 0: still alive)
+            d = run ? dir : d;                                  // :44 committed even if the move dies
+            h = moved ? tgt : h;
+            *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? tgt : junk) = (uint8_t)stamp;
+        }
+        // TronGridEnvironment.py:309-321 for the game: alive players over the quad
+        const int a = (k == 0) ? 1 : 0;
+        int alive = a + tron_quad<0xB1>(a);
+        alive += tron_quad<0x4E>(alive);
+        ts += 1;
+        alive_steps += (uint32_t)a;
+        if (gvalid && alive <= 1) {
+            // new_state: bump the tag, rewrite the next row(s) of the rolling clear, stamp the heads
+            uint32_t tag = (tagbits >> OB) + 1u;
+            tag = (tag == kTags) ? 0u : tag;
+            tagbits = tag << OB;
+            stamp = tagbits | (uint32_t)(p + 1);
+            for (int r = 0; r < pad.sweep_rows; ++r) {
+                *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * p) = rp[0];
+                *(lds_u32 *)(uintptr_t)(uint32_t)((p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw) = rp[1];
+                sweep += RS;
+                sweep = (sweep == sweep_end) ? mine + RS : sweep;
+            }
+            *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
+            n_ep += 1;
+            last_len = (int)ts;
+            ts = 0;
+            wins += (uint32_t)a;                                // the winners are whoever is alive at the terminal step
+            last_alive = a;
+            h = fresh_h; d = fresh_d; k = fresh_k;
+        }
+    }
+    // ---- epilogue: the junk dword hands this board's tag to its copier, boards LDS -> HBM without tags
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (p == 0) *(lds_u8 *)(uintptr_t)(uint32_t)(mine + pad.junk) = (uint8_t)(tagbits >> OB);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);
+    constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);
+    int8_t *gslab = board + env0 * NN;
+    if (wide) {
+        const int bytes = n_env * NN;
+#pragma unroll 7
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            const int sb = slab0 + e * pad.stride;
+            const uint32_t trep = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk) * 0x01010101u;
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]);
+                const uint32_t diff = ((c4 >> OB) & TM) ^ trep;
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                w[q] = c4 & OM & ~(stale * 0xffu);
+            }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int e = 0; e < n_env; ++e) {
+            const uint32_t tb = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + pad.junk) << OB;
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                const uint32_t rawc = *(const lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N));
+                gslab[(int64_t)e * NN + c] = (int8_t)((((rawc ^ tb) >> OB) == 0) ? (rawc & ((1u << OB) - 1u)) : 0u);
+            }
+        }
+    }
+    // ---- per-player state and statistics (my columns), per-game statistics (lane 0 of the quad)
+    int lw = (last_alive & 1) << p;                             // winners of the latest terminal step, over the quad
+    lw |= tron_quad<0xB1>(lw);
+    lw |= tron_quad<0x4E>(lw);
+    const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;   // alive +1, dead -1, alive at a terminal step +10
+    int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    if (pvalid) {
+        const int rel = h - mine;
+        const int rowi = rel / RS;                               // = y + 1
+        heads[p * B + b] = (int16_t)((rowi - 1) * N + (rel - rowi * RS));
+        dirs[p * B + b] = (int8_t)d;
+        deaths[p * B + b] = (int8_t)k;
+        const int rs = old_ret + ret;
+        const uint32_t wc = old_wins + wins;
+        st.ret_sum[p * B + b] = rs;
+        st.win_count[p * B + b] = wc;
+        if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+    }
+    if (gvalid && p == 0) {
+        const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + (ts_at_entry + (uint32_t)T - ts);
+        st.tcount[b] = tc;
+        st.tstep[b] = ts;
+        st.n_episodes[b] = ne;
+        st.len_sum[b] = ls;
+        if (n_ep > 0) {
+            st.last_winners[b] = (uint8_t)lw;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+        if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+    }
+}
+
 // ---- bitboard rollout ---------------------------------------------------------------------------------------
 // For long launches the rollout does not need to know WHO owns a cell while it plays: the owner only decides the
 // value stored in deaths[], and deaths[] / the board bytes of all but the LAST episode of a launch are never
@@ -1924,7 +2204,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
-    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
@@ -1947,6 +2227,15 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
         const int max_w = (((max_n + 2) * (max_n + 1) + 31) / 32 + 3) & ~3;
         bits.stride = 2 * ((max_w * 4 + 127) & ~127) + 16;              // two 128-byte-aligned slabs of pattern words + a junk word
         bits.inv_s = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(cfg.N + 1)) + 1u;
+    }
+    // one lane per player, four per game: boards up to 20x20 with at most 4 players (see tron_rollout_quad_kernel)
+    const bool quad_ok = lds_ok && small && cfg.P <= 4;
+    const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS)) && (flags & CRL_ROLLOUT_QUAD);
+    if (use_quad) {
+        hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, 64)), dim3(256), (size_t)64 * pad.stride, s,
+                           cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+        CRL_LAUNCH_CHECK();
+        return CRL_OK;
     }
     const int threads = (use_bits || small) ? 256 : 64;
     const size_t byte_slabs = (size_t)(small ? 256 : 64) * pad.stride;

@@ -51,6 +51,8 @@ extern "C" {
 #define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
 #define CRL_ROLLOUT_BYTES   4u  /* force the byte-per-cell LDS kernel (default for T < 256) */
 #define CRL_ROLLOUT_BITS    8u  /* force the bitboard LDS kernel with replay epilogue (default for T >= 256) */
+#define CRL_ROLLOUT_QUAD   16u  /* the lane-per-player kernel (four lanes per game) where it applies: boards up to 20x20,
+                                 * at most 4 players; elsewhere the flag is ignored */
 
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 

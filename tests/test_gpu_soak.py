@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle as O
 
 
-@pytest.mark.parametrize("N,P,B,T,kernel", [(20, 4, 4096, 1500, "bits"), (20, 4, 4096, 1500, "bytes"), (20, 4, 2048, 1000, "global"),
+@pytest.mark.parametrize("N,P,B,T,kernel", [(20, 4, 4096, 1500, "quad"), (13, 3, 1024 + 9, 1200, "quad"), (6, 2, 512, 3000, "quad"), (8, 4, 777, 2000, "quad"),
+                                            (20, 4, 4096, 1500, "bits"), (20, 4, 4096, 1500, "bytes"), (20, 4, 2048, 1000, "global"),
                                             (13, 7, 1024, 1200, "bits"), (13, 7, 1024, 1200, "bytes"), (30, 3, 1024, 800, "bits"),
                                             (30, 3, 1024, 800, "bytes"), (6, 2, 512, 3000, "bits"), (6, 2, 512, 3000, "bytes"),
                                             (12, 8, 512, 1500, "bits"), (12, 8, 512, 1500, "bytes"), (23, 4, 512, 1200, "auto"),

@@ -12,7 +12,7 @@ from colosseumrl_amd.batched import TronBatch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 B = 65536
-tbs = {k: TronBatch(N, 4, B) for k in ("bytes", "bits")}
+tbs = {k: TronBatch(N, 4, B) for k in (("quad", "bytes", "bits") if N <= 20 else ("bytes", "bits"))}
 for k, tb in tbs.items():
     tb.rollout(T, 0, kernel=k)
 torch.cuda.synchronize()
@@ -29,4 +29,5 @@ for rnd in range(5):
 for k, v in res.items():
     v = sorted(v)
     print("N=%d T=%d %-5s median %.3f ms  min %.3f ms  -> %.4g env-steps/s" % (N, T, k, v[len(v) // 2], v[0], B * T / (v[len(v) // 2] * 1e-3)))
-assert torch.equal(tbs["bytes"].board, tbs["bits"].board) and torch.equal(tbs["bytes"].ret_sum, tbs["bits"].ret_sum)
+for k in tbs:
+    assert torch.equal(tbs["bytes"].board, tbs[k].board) and torch.equal(tbs["bytes"].ret_sum, tbs[k].ret_sum), k
