@@ -1025,20 +1025,57 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     int sweep = mine + RS;
     const int sweep_end = mine + (N + 1) * RS;
     const int junk_dw = mine + pad.junk;                        // the four junk bytes as one dword
+    int sweep2 = (p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw;   // my second dword of the row to rewrite next
     uint32_t tagbits = 0, stamp = (uint32_t)(p + 1);
     const uint32_t ts_at_entry = ts;
     uint32_t alive_steps = 0, wins = 0, n_ep = 0;
     int last_len = 0, last_alive = 0;
+    if (!gvalid) k = 1;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
-    TronRng<4> rng;                                             // the game's stream, kept by all four lanes of the quad
-    rng.start(gid, tc, seed_lo, seed_hi);
     __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
-    auto draw = [&](const uint32_t c) -> int {                  // my player's action code (0, 1, 3) of step c, then advance
-        const bool odd = c & 1u;
-        const uint32_t code = act_lut[__umulhi(rng.lo.w0 * (odd ? 81u : 1u), 81u)];
-        rng.advance(gid, c, seed_lo, seed_hi);
-        return (int)((code >> (2 * p)) & 3u);
+    // The game's random stream, shared out over the quad.  The contract (include/colosseum_hip.h) gives every step c a
+    // code byte -- four 2-bit actions -- from word (c & 7) >> 1 of Philox block c >> 3.  Computed per lane that is a
+    // Philox call (40 quarter-rate multiplies) every 8 steps in each of the four lanes.  Instead lane q computes block
+    // 4 (c >> 5) + q once per 32 steps, turns its four words into the block's 8 code bytes (two registers: steps 0-3,
+    // 4-7), transposes each register as a 4x4 matrix of 2-bit fields (steps x players -> players x steps: two delta
+    // swaps), so that byte p' holds player p''s four actions, and the quad exchanges them with DPP broadcasts: lane p
+    // ends up with its player's 32 actions in two registers and a step is one select and one bit-field extract.
+    uint32_t a_lo = 0, a_hi = 0;                                // my player's actions of steps 0-15 / 16-31 of the group
+    auto transpose2 = [](uint32_t x) -> uint32_t {              // 4x4 transpose of the 2-bit fields of x (bit 8r + 2c)
+        uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
+        x ^= t ^ (t << 6);
+        t = (x ^ (x >> 12)) & 0x0000F0F0u;
+        x ^= t ^ (t << 12);
+        return x;
     };
+    auto refill = [&](const uint32_t group) {                   // group = c >> 5
+        const philox_out r = philox4x32_10(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
+        uint32_t code[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            code[2 * i] = act_lut[__umulhi(r.w[i], 81u)];
+            code[2 * i + 1] = act_lut[__umulhi(r.w[i] * 81u, 81u)];
+        }
+        const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);   // byte p' = player p', steps 0-3
+        const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);   //                 steps 4-7
+        const uint32_t r01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);   // {lo.b0, hi.b0, lo.b1, hi.b1}: players 0, 1 (16 bits each)
+        const uint32_t r23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);   // {lo.b2, hi.b2, lo.b3, hi.b3}: players 2, 3
+        // (every broadcast runs in all four lanes, THEN the lane picks: a DPP read of a lane that sits out a divergent
+        //  branch returns 0)
+        const int sh = (p & 1) * 16;
+        const int b01[4] = {tron_quad<0x00>((int)r01), tron_quad<0x55>((int)r01), tron_quad<0xAA>((int)r01), tron_quad<0xFF>((int)r01)};
+        const int b23[4] = {tron_quad<0x00>((int)r23), tron_quad<0x55>((int)r23), tron_quad<0xAA>((int)r23), tron_quad<0xFF>((int)r23)};
+        uint32_t s16[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s16[q] = ((uint32_t)(p < 2 ? b01[q] : b23[q]) >> sh) & 0xffffu;
+        a_lo = s16[0] | s16[1] << 16;
+        a_hi = s16[2] | s16[3] << 16;
+    };
+    auto draw = [&](const uint32_t c) -> int {                  // my player's action code (0, 1, 3) of step c
+        const uint32_t a = (c & 16u) ? a_hi : a_lo;
+        return (int)((a >> ((c & 15u) * 2u)) & 3u);
+    };
+    refill(tc >> 5);
     int act = draw(tc);
     for (int t = 0; t < T; ++t) {
         const bool run = k == 0;
@@ -1047,17 +1084,15 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         const int tq = run ? tgt : junk;                        // a dead player probes (and "moves" to) its own junk byte
         const int raw = *(const lds_u8 *)(uintptr_t)(uint32_t)tq;
         tc += 1;
-        int act_next = draw(tc);                                // the NEXT step's action, behind the probe
+        if ((tc & 31u) == 0u) refill(tc >> 5);                  // a quad shares its step counter: whole quads take this branch
+        int act_next = draw(tc);                                // the NEXT step's action
         // does anything in this wave need the reference's sequential order?  my target against the other players'
         // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell)
         const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
         const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq), y3 = tq ^ tron_quad<0x93>(tq);
         const uint32_t near = min(min((uint32_t)x1, min((uint32_t)x2, (uint32_t)x3)), min((uint32_t)y1, min((uint32_t)y2, (uint32_t)y3)));
-        // (the action table's byte is taken out of the LDS queue here, where the wave waits for the probe anyway: left
-        //  to the compiler the wait lands at the top of the next step as lgkmcnt(0), behind this step's stores)
-        asm volatile("" : "+v"(act_next));
         act = act_next;
-        if (__builtin_amdgcn_ballot_w64(near == 0u)) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
             // rare: gather the quad and resolve in the reference's order, redundantly in its four lanes
             TronRegs<4> s;
             TronProbe<4> pr;
@@ -1088,23 +1123,24 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? tgt : junk) = (uint8_t)stamp;
         }
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
-        const int a = (k == 0) ? 1 : 0;
+        int a = (k == 0) ? 1 : 0;
+        asm volatile("" : "+v"(a));                             // a plain 0 / 1 register (not a carry chain): DPP adds below
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
         ts += 1;
         alive_steps += (uint32_t)a;
-        if (gvalid && alive <= 1) {
+        if (alive <= 1) {                                       // (games beyond the batch have no player alive: k_fresh = 1)
             // new_state: bump the tag, rewrite the next row(s) of the rolling clear, stamp the heads
             uint32_t tag = (tagbits >> OB) + 1u;
             tag = (tag == kTags) ? 0u : tag;
             tagbits = tag << OB;
             stamp = tagbits | (uint32_t)(p + 1);
-            for (int r = 0; r < pad.sweep_rows; ++r) {
-                *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * p) = rp[0];
-                *(lds_u32 *)(uintptr_t)(uint32_t)((p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw) = rp[1];
-                sweep += RS;
-                sweep = (sweep == sweep_end) ? mine + RS : sweep;
-            }
+            // one row per reset (boards up to 20x20 with 5 tag bits: crl_tron_rollout checks sweep_rows == 1)
+            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * p) = rp[0];
+            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep2) = rp[1];
+            sweep += RS;
+            sweep = (sweep == sweep_end) ? mine + RS : sweep;
+            sweep2 = (p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw;
             *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
             n_ep += 1;
             last_len = (int)ts;
@@ -2229,7 +2265,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
         bits.inv_s = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(cfg.N + 1)) + 1u;
     }
     // one lane per player, four per game: boards up to 20x20 with at most 4 players (see tron_rollout_quad_kernel)
-    const bool quad_ok = lds_ok && small && cfg.P <= 4;
+    const bool quad_ok = lds_ok && small && cfg.P <= 4 && pad.sweep_rows == 1;
     const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS)) && (flags & CRL_ROLLOUT_QUAD);
     if (use_quad) {
         hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, 64)), dim3(256), (size_t)64 * pad.stride, s,
