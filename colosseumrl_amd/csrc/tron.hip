@@ -1005,31 +1005,31 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     fh = (p == 3) ? cfg.start_heads[3] : fh; fd = (p == 3) ? cfg.start_dirs[3] : fd;
     const int fy = (int)__umulhi((uint32_t)(fh < 0 ? 0 : fh), g.inv_n);
     const int fresh_h = (p < P) ? mine + (fy + 1) * RS + (fh - fy * N) : junk;
-    const int fresh_d = fd, fresh_k = (p < P) ? 0 : 1;
-    int h, d = d_in & 3;
-    {
+    const int fresh_d8 = fd << 3;
+    const bool fresh_run = p < P;
+    int h, d8 = (d_in & 3) << 3;                                // directions live pre-scaled (the bit offset into step4),
+    {                                                           // bits above 4:3 are garbage
         const int hc = min(max(h_in, 0), NN - 1);
         const int y = (int)__umulhi((uint32_t)hc, g.inv_n);
         h = pvalid ? mine + (y + 1) * RS + (hc - y * N) : junk;   // a seat without a player never matches a target
     }
-    // my share of a fresh row (dwords p and p + 4): cells 0, walls 0xff
+    // my share of a fresh row: dwords p and p + 2 of its six (dwords 2 and 3 are stored twice, with the same value)
+    static_assert(kRowDwords == 6, "the row rewrite of the quad kernel shares out six dwords");
     uint32_t rp[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int j = p + 4 * i;
+        const int j = p + 2 * i;
         uint32_t w = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) w |= (4 * j + c < N) ? 0u : (0xffu << (8 * c));
         rp[i] = w;
     }
-    int sweep = mine + RS;
-    const int sweep_end = mine + (N + 1) * RS;
-    const int junk_dw = mine + pad.junk;                        // the four junk bytes as one dword
-    int sweep2 = (p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw;   // my second dword of the row to rewrite next
+    int sweep = mine + RS + 4 * p;                              // my first dword of the row the next reset rewrites
+    const int sweep_end = mine + (N + 1) * RS + 4 * p, sweep_first = mine + RS + 4 * p;
     uint32_t tagbits = 0, stamp = (uint32_t)(p + 1);
-    const uint32_t ts_at_entry = ts;
-    uint32_t alive_steps = 0, wins = 0, n_ep = 0;
-    int last_len = 0, last_alive = 0;
+    uint32_t alive_steps = 0, wn = 0;                           // wn: episodes << 16 | my wins
+    uint32_t marks = 0;                                         // the latest reset in bits 15:0, the one before in 31:16:
+                                                                // (launch steps done at the reset) << 1 | I was alive
     if (!gvalid) k = 1;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
@@ -1039,7 +1039,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     // 4 (c >> 5) + q once per 32 steps, turns its four words into the block's 8 code bytes (two registers: steps 0-3,
     // 4-7), transposes each register as a 4x4 matrix of 2-bit fields (steps x players -> players x steps: two delta
     // swaps), so that byte p' holds player p''s four actions, and the quad exchanges them with DPP broadcasts: lane p
-    // ends up with its player's 32 actions in two registers and a step is one select and one bit-field extract.
+    // ends up with its player's 32 actions in two registers; a step takes the low two bits of `acts` and shifts.
     uint32_t a_lo = 0, a_hi = 0;                                // my player's actions of steps 0-15 / 16-31 of the group
     auto transpose2 = [](uint32_t x) -> uint32_t {              // 4x4 transpose of the 2-bit fields of x (bit 8r + 2c)
         uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
@@ -1071,35 +1071,55 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         a_lo = s16[0] | s16[1] << 16;
         a_hi = s16[2] | s16[3] << 16;
     };
-    auto draw = [&](const uint32_t c) -> int {                  // my player's action code (0, 1, 3) of step c
-        const uint32_t a = (c & 16u) ? a_hi : a_lo;
-        return (int)((a >> ((c & 15u) * 2u)) & 3u);
-    };
     refill(tc >> 5);
-    int act = draw(tc);
+    uint32_t acts = ((tc & 16u) ? a_hi : a_lo) >> ((tc & 15u) * 2u);   // bits 1:0 = this step's action code (0, 1, 3)
+    // `acts` runs dry after dry2 / 2 steps of this launch; neg2 = 2 (launch steps done) - dry2 counts up to zero
+    uint32_t dry2 = 32u - 2u * (tc & 15u);
+    int neg2 = -(int)dry2;
+    const uint32_t tc_in = tc;
+    bool run = k == 0;                                          // my player is alive; k only says why it is not
+    // Cell decode.  A cell is tag << 3 | owner; walls are 0xff and the tag 31 is never used, so with x = cell ^ tag << 3
+    // and w = cell ^ 0xf8 the cell is occupied for THIS episode iff 1 <= min(x, w) <= 7: x is the owner under the
+    // current tag (>= 8 under a stale one), w is 7 for a wall (>= 8 for every other cell).  That minimum also is what
+    // deaths[] records, except that a wall reads 7 where the reference stores the mover's own id (CyTronGrid.pyx:47-48):
+    // translated once, at the end.
     for (int t = 0; t < T; ++t) {
-        const bool run = k == 0;
-        const int dir = (d + act) & 3;
-        const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir << 3, 8);
-        const int tq = run ? tgt : junk;                        // a dead player probes (and "moves" to) its own junk byte
-        const uint32_t raw = *(const lds_u8 *)(uintptr_t)(uint32_t)tq;
-        tc += 1;
-        if ((tc & 31u) == 0u) refill(tc >> 5);                  // a quad shares its step counter: whole quads take this branch
-        int act_next = draw(tc);                                // the NEXT step's action
+        const int dir8 = (int)((acts << 3) + (uint32_t)d8);     // bits 4:3: (d + action) & 3 (a bit-field offset reads 5 bits)
+        const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir8, 8);
+        const int tq = run ? tgt : junk;                        // a dead player probes its own junk byte
+        // (the probe as inline asm: the compiler would mask the byte it loads with 0xff once more; its own waitcnts stay
+        //  correct, LDS operations retire in order and an extra one in flight only makes them conservative)
+        uint32_t raw;
+        asm volatile("ds_read_u8 %0, %1" : "=v"(raw) : "v"(tq) : "memory");
+        acts >>= 2;
+        neg2 += 2;
+        if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
+            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
+            if ((c & 16u) == 0u) refill(c >> 5);
+            acts = (c & 16u) ? a_hi : a_lo;
+            dry2 += 32u;
+            neg2 = -32;
+        }
         // does anything in this wave need the reference's sequential order?  my target against the other players'
-        // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell)
+        // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell; every pair is seen from
+        // one of its two lanes by the rotations by one and two)
         const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
-        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq), y3 = tq ^ tron_quad<0x93>(tq);
-        const uint32_t near = min(min((uint32_t)x1, min((uint32_t)x2, (uint32_t)x3)), min((uint32_t)y1, min((uint32_t)y2, (uint32_t)y3)));
-        act = act_next;
+        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
+        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw) : : "memory");
+        // both paths end in the same three selects: k = dead ? why : k; d = ran ? dir : d; h = moved ? to : h
+        uint32_t why;
+        int dirE, to;
+        bool dead, ran, moved, alive_now;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
             // rare: gather the quad and resolve in the reference's order, redundantly in its four lanes
             TronRegs<4> s;
             TronProbe<4> pr;
             uint32_t stamp4[4];
+            const int d = (d8 >> 3) & 3, dir = (dir8 >> 3) & 3, kk = run ? 0 : k;
             s.h[0] = tron_quad<0x00>(h); s.h[1] = tron_quad<0x55>(h); s.h[2] = tron_quad<0xAA>(h); s.h[3] = tron_quad<0xFF>(h);
             s.d[0] = tron_quad<0x00>(d); s.d[1] = tron_quad<0x55>(d); s.d[2] = tron_quad<0xAA>(d); s.d[3] = tron_quad<0xFF>(d);
-            s.k[0] = tron_quad<0x00>(k); s.k[1] = tron_quad<0x55>(k); s.k[2] = tron_quad<0xAA>(k); s.k[3] = tron_quad<0xFF>(k);
+            s.k[0] = tron_quad<0x00>(kk); s.k[1] = tron_quad<0x55>(kk); s.k[2] = tron_quad<0xAA>(kk); s.k[3] = tron_quad<0xFF>(kk);
             pr.tgt[0] = tron_quad<0x00>(tgt); pr.tgt[1] = tron_quad<0x55>(tgt); pr.tgt[2] = tron_quad<0xAA>(tgt); pr.tgt[3] = tron_quad<0xFF>(tgt);
             pr.raw[0] = tron_quad<0x00>((int)raw); pr.raw[1] = tron_quad<0x55>((int)raw); pr.raw[2] = tron_quad<0xAA>((int)raw); pr.raw[3] = tron_quad<0xFF>((int)raw);
             pr.ndir[0] = tron_quad<0x00>(dir); pr.ndir[1] = tron_quad<0x55>(dir); pr.ndir[2] = tron_quad<0xAA>(dir); pr.ndir[3] = tron_quad<0xFF>(dir);
@@ -1107,49 +1127,66 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             for (int q = 0; q < 4; ++q) stamp4[q] = tagbits | (uint32_t)(q + 1);
             const LdsBoard<OB> bd{tagbits};
             tron_resolve_lds<4>(bd, s, pr, stamp4, junk);       // trail writes of all four players from every lane: identical
-            h = s.h[0]; d = s.d[0]; k = s.k[0];
-            h = (p == 1) ? s.h[1] : h; d = (p == 1) ? s.d[1] : d; k = (p == 1) ? s.k[1] : k;
-            h = (p == 2) ? s.h[2] : h; d = (p == 2) ? s.d[2] : d; k = (p == 2) ? s.k[2] : k;
-            h = (p == 3) ? s.h[3] : h; d = (p == 3) ? s.d[3] : d; k = (p == 3) ? s.k[3] : k;
-            h = (p < P) ? h : junk;
+            int hS = s.h[0], dS = s.d[0], kS = s.k[0];
+            hS = (p == 1) ? s.h[1] : hS; dS = (p == 1) ? s.d[1] : dS; kS = (p == 1) ? s.k[1] : kS;
+            hS = (p == 2) ? s.h[2] : hS; dS = (p == 2) ? s.d[2] : dS; kS = (p == 2) ? s.k[2] : kS;
+            hS = (p == 3) ? s.h[3] : hS; dS = (p == 3) ? s.d[3] : dS; kS = (p == 3) ? s.k[3] : kS;
+            to = (p < P) ? hS : junk;
+            dirE = dS << 3;
+            why = (uint32_t)kS;
+            int one = 1;
+            asm volatile("" : "+v"(one));                       // (an opaque `true`: keeps the three selects below the join
+            dead = ran = moved = one != 0;                      //  instead of a copy of them per path and register moves)
+            alive_now = kS == 0;
         } else {
-            const uint32_t x = raw ^ tagbits;                   // same tag: the tag bits cancel and x IS the owner
-            int v = x < (1u << OB) ? (int)x : 0;
-            v = (raw == (uint32_t)kWallCell) ? p + 1 : v;       // :47-48 a wall kills like the player's own trail
-            const bool moved = run & (v == 0);                  // :60-62
-            k = run ? v : k;                                    // :51-55 (v == 0: still alive)
-            d = run ? dir : d;                                  // :44 committed even if the move dies
-            h = moved ? tgt : h;
-            *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? tgt : junk) = (uint8_t)stamp;
+            const uint32_t m = min(raw ^ tagbits, raw ^ 0xf8u);
+            why = m;
+            dirE = dir8;
+            to = tgt;
+            ran = run;                                          // :44 the direction is committed even if the move dies
+            dead = run & ((m - 1u) < 7u);                       // :47-57
+            moved = run ^ dead;                                 // :60-62
+            alive_now = moved;
         }
+        k = dead ? (int)why : k;
+        d8 = ran ? dirE : d8;
+        h = moved ? to : h;
+        // the trail: a head cell already holds its player's stamp (new_state / every earlier move put it there), so a
+        // player that stays where it is restamps its own head and the store needs no condition
+        *(lds_u8 *)(uintptr_t)(uint32_t)h = (uint8_t)stamp;
+        run = alive_now;
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
-        int a = (k == 0) ? 1 : 0;
+        int a = run ? 1 : 0;
         asm volatile("" : "+v"(a));                             // a plain 0 / 1 register (not a carry chain): DPP adds below
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
-        ts += 1;
         alive_steps += (uint32_t)a;
-        if (alive <= 1) {                                       // (games beyond the batch have no player alive: k_fresh = 1)
-            // new_state: bump the tag, rewrite the next row(s) of the rolling clear, stamp the heads
-            uint32_t tag = (tagbits >> OB) + 1u;
-            tag = (tag == kTags) ? 0u : tag;
-            tagbits = tag << OB;
+        if (alive <= 1) {                                       // (a game beyond the batch is "over" at every step)
+            // new_state: bump the tag, rewrite the next row of the rolling clear (boards up to 20x20 with 5 tag bits:
+            // crl_tron_rollout checks sweep_rows == 1), stamp the heads
+            tagbits += 1u << OB;
+            tagbits = (tagbits == (kTags << OB)) ? 0u : tagbits;
             stamp = tagbits | (uint32_t)(p + 1);
-            // one row per reset (boards up to 20x20 with 5 tag bits: crl_tron_rollout checks sweep_rows == 1)
-            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4 * p) = rp[0];
-            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep2) = rp[1];
+            *(lds_u32 *)(uintptr_t)(uint32_t)sweep = rp[0];
+            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 8) = rp[1];
             sweep += RS;
-            sweep = (sweep == sweep_end) ? mine + RS : sweep;
-            sweep2 = (p + 4 < kRowDwords) ? sweep + 4 * (p + 4) : junk_dw;
+            sweep = (sweep == sweep_end) ? sweep_first : sweep;
             *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
-            n_ep += 1;
-            last_len = (int)ts;
-            ts = 0;
-            wins += (uint32_t)a;                                // the winners are whoever is alive at the terminal step
-            last_alive = a;
-            h = fresh_h; d = fresh_d; k = fresh_k;
+            wn += 0x10000u + (uint32_t)a;                       // the winners are whoever is alive at the terminal step
+            // (launch steps done = (dry2 + neg2) / 2: no use of the scalar t, which would turn it into a vector register)
+            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a);
+            h = fresh_h; d8 = fresh_d8;
+            run = fresh_run;
         }
     }
+    const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
+    const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
+    tc = tc_in + (uint32_t)T;
+    const uint32_t ts_at_entry = ts;
+    ts = n_ep ? (uint32_t)(T - done_last) : ts_at_entry + (uint32_t)T;
+    const int last_len = (n_ep > 1u) ? done_last - done_prev : (int)ts_at_entry + done_last;
+    k = run ? 0 : (k == 7 ? p + 1 : k);
+    const int d = (d8 >> 3) & 3;
     // ---- epilogue: the junk dword hands this board's tag to its copier, boards LDS -> HBM without tags
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2269,9 +2306,15 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     // the default wherever it applies: 1.42e11 vs 1.24e11 env-steps/s for the lane-per-game byte kernel at 20x20, P = 4
     const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS));
     if (use_quad) {
-        hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, 64)), dim3(256), (size_t)64 * pad.stride, s,
-                           cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
-        CRL_LAUNCH_CHECK();
+        // (the kernel keeps a launch's episode, win and step counts in 14..16 bits: longer rollouts go out as several launches,
+        //  which is the same rollout -- the state and the step counters carry over)
+        constexpr int kQuadMaxT = 16383;
+        for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
+            hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, 64)), dim3(256), (size_t)64 * pad.stride, s,
+                               cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0),
+                               board, heads, dirs, deaths, st);
+            CRL_LAUNCH_CHECK();
+        }
         return CRL_OK;
     }
     const int threads = (use_bits || small) ? 256 : 64;
