@@ -49,16 +49,39 @@ void crl_set_error(const char *fmt, ...);
 #define CRL_LAUNCH_CHECK() CRL_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------- Philox-4x32-10
-// Salmon et al., SC'11 (Random123 constants). 10 rounds, 2 x (mul_lo, mul_hi) per round.
+// Salmon et al., SC'11 (Random123 constants). 10 rounds of two 32 x 32 -> 64-bit products.
+// WIDE: each product is ONE v_mad_u64_u32 instead of the v_mul_lo_u32 + v_mul_hi_u32 pair the compiler picks (it splits
+// a 64-bit product of zero-extended operands into that very pair, hence inline asm).  Measured on gfx950 a v_mad_u64_u32
+// costs what ONE of the pair does (4.4 cycles per wave and SIMD with >= 2 waves, against 2.2 for plain integer VALU:
+// profiles/r2_valu_issue_calibration.json) but has the longer latency, and a Philox round waits for its products: in an
+// A/B on one box (tools/sessions/gpu_session_v.sh) WIDE gained 3 % on the TicTacToe rollouts and 0.5 % on the
+// lane-per-player Tron kernel (>= 4 waves per SIMD cover the latency) and LOST 1-4 % on the lone-wave Tron kernels and
+// 5 % on Blokus.  So it is a per-kernel choice.
 struct philox_out { uint32_t w[4]; };
 
+template <bool WIDE>
+__device__ __forceinline__ void crl_mul_wide(const uint32_t a, const uint32_t b, uint32_t &lo, uint32_t &hi)
+{
+    if constexpr (WIDE) {
+        uint64_t p;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "s"(a), "v"(b) : "vcc");   // a: a constant, in an SGPR
+        lo = (uint32_t)p;
+        hi = (uint32_t)(p >> 32);
+    } else {
+        lo = a * b;
+        hi = __umulhi(a, b);
+    }
+}
+
+template <bool WIDE = false>
 __device__ __forceinline__ philox_out philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                     uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
-        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        uint32_t lo0, hi0, lo1, hi1;
+        crl_mul_wide<WIDE>(0xD2511F53u, c0, lo0, hi0);
+        crl_mul_wide<WIDE>(0xCD9E8D57u, c2, lo1, hi1);
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;

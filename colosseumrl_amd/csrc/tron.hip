@@ -1049,12 +1049,14 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         return x;
     };
     auto refill = [&](const uint32_t group) {                   // group = c >> 5
-        const philox_out r = philox4x32_10(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
+        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
         uint32_t code[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            code[2 * i] = act_lut[__umulhi(r.w[i], 81u)];
-            code[2 * i + 1] = act_lut[__umulhi(r.w[i] * 81u, 81u)];
+            uint32_t frac, first;                               // w * 81 = first : frac (one v_mad_u64_u32)
+            crl_mul_wide<true>(81u, r.w[i], frac, first);
+            code[2 * i] = act_lut[first];
+            code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
         }
         const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);   // byte p' = player p', steps 0-3
         const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);   //                 steps 4-7

@@ -128,7 +128,7 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     int w = winner[b], tm = to_move[b];
     uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
-    philox_out rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    philox_out rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
     for (int t = 0; t < T; ++t) {
         uint32_t all = 0;
 #pragma unroll
@@ -142,7 +142,7 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         word = (sel == 3) ? rnd.w[3] : word;
         const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
         tc += 1;
-        if ((tc & 3u) == 0) rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        if ((tc & 3u) == 0) rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
         int r, term, ws;
         ttt_step_core<P, ND>(dd, o, w, tm, action, r, term, ws);
         ts += 1;
@@ -248,7 +248,7 @@ ttt_step_observe_kernel(const ttt_dirs dd, const uint32_t inv_cells, const int64
             for (int p = 0; p < P; ++p) all |= o[p];
             const uint32_t empty = dd.full & ~all, c = tcount[b];
             const int n_empty = __popc(empty);
-            const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+            const philox_out rnd = philox4x32_10<true>((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
             const uint32_t sel = c & 3u;
             const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
             act = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
@@ -290,7 +290,7 @@ ttt_sample_kernel(const int P, const uint32_t full, const int64_t B, const uint3
     for (int p = 0; p < P; ++p) all |= occ[p * B + b];
     const uint32_t empty = full & ~all, c = tcount[b];
     const int n_empty = __popc(empty);
-    const philox_out rnd = philox4x32_10((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    const philox_out rnd = philox4x32_10<true>((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
     const uint32_t sel = c & 3u;
     const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
     action[b] = (int8_t)(n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1);

@@ -46,6 +46,44 @@ __global__ void __launch_bounds__(256) valu_kernel(uint32_t *out, uint64_t *clk,
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// 32x32 -> 64-bit products (Philox rounds): a v_mul_lo_u32 + v_mul_hi_u32 pair against one v_mad_u64_u32.
+// `wide` = 0: 32 pairs per iteration (64 instructions); 1: 32 v_mad_u64_u32 per iteration.
+__global__ void __launch_bounds__(256) mul_kernel(uint32_t *out, uint64_t *clk, int iters, int wide)
+{
+    uint32_t a0 = threadIdx.x | 1u, a1 = a0 + 2, a2 = a0 + 4, a3 = a0 + 6;
+    uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    const uint32_t c = 0xD2511F53u;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (wide) {
+        uint64_t p0 = a0, p1 = a1, p2 = a2, p3 = a3;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile(
+                ".rept 8\n"
+                "v_mad_u64_u32 %0, vcc, %4, %8, 0\n v_mad_u64_u32 %1, vcc, %5, %8, 0\n"
+                "v_mad_u64_u32 %2, vcc, %6, %8, 0\n v_mad_u64_u32 %3, vcc, %7, %8, 0\n"
+                ".endr\n"
+                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(c) : "vcc");
+        }
+        a0 = (uint32_t)p0; a1 = (uint32_t)p1; a2 = (uint32_t)p2; a3 = (uint32_t)p3;
+        h0 = (uint32_t)(p0 >> 32); h1 = (uint32_t)(p1 >> 32); h2 = (uint32_t)(p2 >> 32); h3 = (uint32_t)(p3 >> 32);
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            asm volatile(
+                ".rept 8\n"
+                "v_mul_hi_u32 %4, %0, %8\n v_mul_lo_u32 %0, %0, %8\n v_mul_hi_u32 %5, %1, %8\n v_mul_lo_u32 %1, %1, %8\n"
+                "v_mul_hi_u32 %6, %2, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_hi_u32 %7, %3, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                ".endr\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3) : "v"(c));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ h0 ^ h1 ^ h2 ^ h3;
+}
+
 __global__ void __launch_bounds__(256) tron_mix_kernel(uint32_t *out, uint64_t *clk, int iters)
 {
     __shared__ uint32_t cells[256 * 5];              // odd dword stride per lane, like the rollout's slabs
@@ -93,15 +131,17 @@ int main()
     const int iters = 40000;
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"note\": \"wave64 instructions per second, whole chip; "
            "cycles = shader cycles per instruction per SIMD at the in-kernel clock\", \"mixes\": {", prop.gcnArchName, cus, cus * 4);
-    for (int mix = 0; mix < 3; ++mix) {
-        printf("%s\"%s\": [", mix ? ", " : "", mix == 1 ? "tron" : mix == 2 ? "valu_half_exec" : "valu");
+    for (int mix = 0; mix < 5; ++mix) {
+        static const char *const names[5] = {"valu", "tron", "valu_half_exec", "mul_lo_hi_pairs", "mad_u64_u32"};
+        printf("%s\"%s\": [", mix ? ", " : "", names[mix]);
         for (int wps = 1; wps <= 8; wps *= 2) {
             const int blocks = cus * wps;                          // wps blocks of 4 waves per CU = wps waves per SIMD
             hipEvent_t e0, e1;
             CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; ++rep) {                    // rep 0 warms up (clock ramp), rep 1 is timed
                 CHECK(hipEventRecord(e0));
-                if (mix != 1) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 2);
+                if (mix >= 3) hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 4, mix == 4);
+                else if (mix != 1) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 2);
                 else hipLaunchKernelGGL(tron_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
@@ -111,8 +151,10 @@ int main()
             uint64_t h[2];
             CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
             const double ghz = (double)h[0] / (double)h[1] * 0.1;
-            const double valu_per_wave = (double)iters * (mix == 1 ? kBlocksPerIter * 11 : kValuPerIter);
-            const double all_per_wave = (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
+            // (mul mixes: iters / 4 iterations of 64 multiplies, or of 32 v_mad_u64_u32 = the same 32 full products)
+            const double valu_per_wave = mix >= 3 ? (double)(iters / 4) * (mix == 4 ? 32 : 64)
+                                                  : (double)iters * (mix == 1 ? kBlocksPerIter * 11 : kValuPerIter);
+            const double all_per_wave = mix >= 3 ? valu_per_wave : (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
             const double waves = (double)blocks * 4;
             const double s = ms * 1e-3;
             printf("%s{\"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"valu_wave_insts_per_s\": %.4e, "
