@@ -19,6 +19,7 @@ CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
 CRL_ROLLOUT_BITS = 8
 CRL_ROLLOUT_QUAD = 16
+CRL_ROLLOUT_QBITS = 32
 
 _lib = None
 _lock = threading.Lock()

@@ -151,10 +151,11 @@ class TronBatch:
 
     # -- T fused random-agent steps with auto-reset
     def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto"):
-        """``kernel``: "auto" (library's choice), "quad" / "bits" / "bytes" (pin one of the LDS kernels) or "global";
+        """``kernel``: "auto" (library's choice), "quad" / "qbits" / "bits" / "bytes" (pin one of the LDS kernels) or "global";
         ``use_lds=False`` is the older spelling of "global".  All kernels give identical results."""
         flags = {"auto": 0, "bits": _native.CRL_ROLLOUT_BITS, "bytes": _native.CRL_ROLLOUT_BYTES,
-                 "global": _native.CRL_ROLLOUT_NO_LDS, "quad": _native.CRL_ROLLOUT_QUAD}[kernel]
+                 "global": _native.CRL_ROLLOUT_NO_LDS, "quad": _native.CRL_ROLLOUT_QUAD,
+                 "qbits": _native.CRL_ROLLOUT_QBITS}[kernel]
         if not use_lds:
             flags = _native.CRL_ROLLOUT_NO_LDS
         if self._rollout_args is None:       # the state / statistics tensors are never reallocated: bind them once

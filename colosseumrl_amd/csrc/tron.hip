@@ -1686,6 +1686,515 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
 }
 
+// ---- quad bitboard rollout: one lane per PLAYER on occupancy bitboards (boards up to 40x40, P <= 4, T >= 256) ------
+// The lane-per-game bitboard kernel above keeps a 40x40 game in 528 bytes of LDS, but 65,536 games are still only
+// 1,024 waves: one per SIMD, issuing an instruction every ~5.9 cycles.  This kernel is to it what
+// tron_rollout_quad_kernel is to the byte kernel: a lane plays ONE player (probe a bit, die or move, set a bit), the
+// quad shares what is per game (alive count by two DPP adds, the random stream, the reset), the reference's sequential
+// order (CyTronGrid.pyx:15-62) is resolved -- redundantly in the four lanes, on DPP-gathered copies -- only on the
+// 1.3 % of wave-steps where a target meets another player's head or target.  64 games per workgroup (34 KB of LDS), four
+// workgroups per CU: 4 waves per SIMD.
+//   * Two bit slabs per game as above: a reset swaps them; the retired one is rewritten with the start layout by the
+//     quad, 16 bytes per lane and step (group t & 3 of the slab, an immediate offset: no address arithmetic), so it is
+//     fresh again four steps later; an episode shorter than that rewrites it at once.
+//   * Owners are not tracked: as above the state handed back is rebuilt by REPLAYING the unfinished episode on byte
+//     slabs.  The bit slabs are dead by then, and their LDS takes the byte slabs of 16 games at a time: four turns, each
+//     laid out and copied out by the whole workgroup and replayed by one wave with a lane per game (the same
+//     tron_resolve_lds as everywhere).
+template <int P, bool LARGE>
+__global__ void __launch_bounds__(256, 4)
+tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const TronBits bits, const int64_t B,
+                          const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                          int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                          int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    static_assert(P <= 4, "one lane per player, four lanes per game");
+    constexpr int kGames = 64, kWaveGames = 16;
+    constexpr int kMaxN = LARGE ? kLdsMaxNLarge : kLdsMaxNSmall;
+    constexpr int kMaxW = (((kMaxN + 2) * (kMaxN + 1) + 31) / 32 + 3) & ~3;     // pattern words, a multiple of 4
+    constexpr int kSlab = (kMaxW * 4 + 127) & ~127;                             // 256 / 128 bytes
+    constexpr int kGroups = kSlab / 64;                                         // 64 bytes per quad and step: 4 / 2 groups
+    constexpr int RS = LARGE ? kRowBytesLarge : kRowBytesSmall;                 // byte slabs of the replay
+    static_assert(kGroups <= 4, "a slab is rewritten within four steps");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    __shared__ uint32_t wall_words[kSlab / 4];
+    __shared__ uint32_t r_tc[kGames];                           // hand-over to the replay: step counter at the end,
+    __shared__ int r_steps[kGames];                             // steps to replay (-1: T steps from the incoming state)
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN, S = N + 1;
+    const uint32_t bstep4 = (uint32_t)((-S) & 0xff) | (1u << 8) | ((uint32_t)S << 16) | (0xffu << 24);
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int p = lane & 3;                                     // my player
+    const int slot = threadIdx.x >> 2;                          // my game's slabs in this workgroup
+    const int64_t b = (int64_t)blockIdx.x * kGames + slot;
+    const bool gvalid = b < B;
+    const bool pvalid = gvalid && p < P;
+    const int64_t bb = gvalid ? b : 0;
+    const int64_t env0 = (int64_t)blockIdx.x * kGames + wave * kWaveGames;   // first game of this wave
+    const int n_env = (int)((B - env0) < kWaveGames ? (B - env0 > 0 ? B - env0 : 0) : kWaveGames);
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const int mine = lds0 + slot * bits.stride;                 // my game: slab A, slab B, four junk words
+    const bool wide = (N & 3) == 0 && N >= 8;
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+
+    // the empty board (walls only), one word per thread, shared through LDS
+    if (threadIdx.x < kSlab / 4) {
+        uint32_t w = 0;
+        if (threadIdx.x < kMaxW)
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t bit = threadIdx.x * 32 + k;
+                const uint32_t row = __umulhi(bit, bits.inv_s), col = bit - row * S;
+                w |= (uint32_t)((row == 0) | (row > (uint32_t)N) | (col == (uint32_t)N)) << k;
+            }
+        wall_words[threadIdx.x] = w;
+    }
+    // my player's state and the running totals: loads in flight while the slabs are laid out
+    const int h_in = pvalid ? heads[p * B + bb] : 0;
+    const int d_in = pvalid ? dirs[p * B + bb] : 0;
+    const int k_in = pvalid ? deaths[p * B + bb] : 1;
+    const int old_ret = pvalid ? st.ret_sum[p * B + bb] : 0;
+    const uint32_t old_wins = pvalid ? st.win_count[p * B + bb] : 0u;
+    const uint32_t tc_in = gvalid ? st.tcount[bb] : 0u, ts_at_entry = gvalid ? st.tstep[bb] : 0u;
+    const uint32_t old_n_ep = gvalid ? st.n_episodes[bb] : 0u, old_len_sum = gvalid ? st.len_sum[bb] : 0u;
+    const uint32_t old_last_w = gvalid ? st.last_winners[bb] : 0u;
+    __syncthreads();
+    // my quarter of every 64-byte group of a slab: words 16 g + 4 p .. + 3.  `fresh` is the start layout (walls + start
+    // heads), kept in registers for the rewrites.
+    int fh = cfg.start_heads[0], fd = cfg.start_dirs[0];
+    fh = (p == 1) ? cfg.start_heads[1] : fh; fd = (p == 1) ? cfg.start_dirs[1] : fd;
+    fh = (p == 2) ? cfg.start_heads[2] : fh; fd = (p == 2) ? cfg.start_dirs[2] : fd;
+    fh = (p == 3) ? cfg.start_heads[3] : fh; fd = (p == 3) ? cfg.start_dirs[3] : fd;
+    u32x4 fresh[kGroups];
+#pragma unroll
+    for (int grp = 0; grp < kGroups; ++grp) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = 16 * grp + 4 * p + i;
+            const uint32_t wall = wall_words[j];
+            uint32_t v = wall;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int sh = cfg.start_heads[q];
+                const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
+                const int fb = (sy + 1) * S + (sh - sy * N);
+                v |= ((fb >> 5) == j) ? 1u << (fb & 31) : 0u;
+            }
+            w[i] = v;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(mine + 4 * j) = wall;             // slab A: the empty board
+            *(lds_u32 *)(uintptr_t)(uint32_t)(mine + kSlab + 4 * j) = v;        // slab B, the spare: the start layout
+        }
+        fresh[grp] = (u32x4){w[0], w[1], w[2], w[3]};
+        asm volatile("" : "+v"(fresh[grp]));
+    }
+    *(lds_u32 *)(uintptr_t)(uint32_t)(mine + 2 * kSlab + 4 * p) = 0u;           // my junk word
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- copy in: the wave ORs the occupied cells of its 16 boards into their slabs A
+    {
+        const int8_t *gslab = board + env0 * NN;
+        const int slab0 = lds0 + wave * kWaveGames * bits.stride;
+        if (wide) {
+            const int bytes = n_env * NN;
+#pragma unroll 5
+            for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {      // unrolled: several loads in flight
+                const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                const int cq = (off - e * NN) >> 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // one bit per non-zero byte of the dword, gathered to a nibble (see tron_rollout_bits_kernel)
+                    const uint32_t nz = (((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u;
+                    const uint64_t nib = ((nz >> 7) * 0x10204080u) >> 28;
+                    const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                    const int bit = (y + 1) * S + 4 * (cq + q - y * (N >> 2));   // 4 cells of one row: contiguous bits,
+                    const uint64_t two = nib << (bit & 31);                       // possibly across a word boundary
+                    unsigned int *wp = (unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2));
+                    atomicOr(wp, (unsigned int)two);
+                    atomicOr(wp + 1, (unsigned int)(two >> 32));
+                }
+            }
+        } else {
+            for (int e = 0; e < n_env; ++e)
+                for (int c = lane; c < NN; c += CRL_WAVE) {
+                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                    const int bit = (y + 1) * S + (c - y * N);
+                    if (gslab[(int64_t)e * NN + c] != 0)
+                        atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2)), 1u << (bit & 31));
+                }
+        }
+    }
+    // ---- my player: the head as a BIT address (8 * slab address + bit index; a step is +-1 or +-S)
+    const int jaddr = mine + 2 * kSlab + 4 * p;                 // my junk word: dead players probe and "move" there
+    const int jpos = 8 * jaddr;
+    const int fy = (int)__umulhi((uint32_t)(fh < 0 ? 0 : fh), g.inv_n);
+    // my start cell as a bit index inside a slab; a seat without a player sits on a padding bit behind the pattern
+    // words (no target ever equals it, and it never moves)
+    static_assert(kSlab * 8 - 8 >= kMaxW * 32 || kSlab * 8 - 8 >= (kMaxN + 2) * (kMaxN + 1), "padding bits behind the board");
+    const int fresh_off = (p < P) ? (fy + 1) * S + (fh - fy * N) : kSlab * 8 - 8 + p;
+    const int fresh_d8 = fd << 3;
+    const bool fresh_run = p < P;
+    int cur8 = 8 * mine;                                        // 8 * (slab in play)
+    const int flip8 = (8 * mine) ^ (8 * (mine + kSlab));
+    int spare_p = mine + kSlab + 16 * p;                        // my 16 bytes of group 0 of the spare slab
+    const int both_p = (mine + 16 * p) + (mine + kSlab + 16 * p);   // a swap is both_p - spare_p (slabs are not aligned
+                                                                    // to their size: no xor)
+    int pos, d8 = (d_in & 3) << 3;
+    {
+        const int hc = min(max(h_in, 0), NN - 1);
+        const int y = (int)__umulhi((uint32_t)hc, g.inv_n);
+        pos = cur8 + (pvalid ? (y + 1) * S + (hc - y * N) : fresh_off);
+    }
+    uint32_t alive_steps = 0, wn = 0, marks = 0, ok_at2 = 0;    // as in tron_rollout_quad_kernel; ok_at2: the spare is
+                                                                // completely fresh once 2 * (steps done) reaches it
+    __syncthreads();                                            // action table
+    uint32_t a_lo = 0, a_hi = 0;
+    auto transpose2 = [](uint32_t x) -> uint32_t {
+        uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
+        x ^= t ^ (t << 6);
+        t = (x ^ (x >> 12)) & 0x0000F0F0u;
+        x ^= t ^ (t << 12);
+        return x;
+    };
+    auto refill = [&](const uint32_t group) {                   // see tron_rollout_quad_kernel
+        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
+        uint32_t code[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t frac, first;
+            crl_mul_wide<true>(81u, r.w[i], frac, first);
+            code[2 * i] = act_lut[first];
+            code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
+        }
+        const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);
+        const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);
+        const uint32_t r01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
+        const uint32_t r23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+        const int sh = (p & 1) * 16;
+        const int b01[4] = {tron_quad<0x00>((int)r01), tron_quad<0x55>((int)r01), tron_quad<0xAA>((int)r01), tron_quad<0xFF>((int)r01)};
+        const int b23[4] = {tron_quad<0x00>((int)r23), tron_quad<0x55>((int)r23), tron_quad<0xAA>((int)r23), tron_quad<0xFF>((int)r23)};
+        uint32_t s16[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s16[q] = ((uint32_t)(p < 2 ? b01[q] : b23[q]) >> sh) & 0xffffu;
+        a_lo = s16[0] | s16[1] << 16;
+        a_hi = s16[2] | s16[3] << 16;
+    };
+    refill(tc_in >> 5);
+    uint32_t acts = ((tc_in & 16u) ? a_hi : a_lo) >> ((tc_in & 15u) * 2u);
+    uint32_t dry2 = 32u - 2u * (tc_in & 15u);
+    int neg2 = -(int)dry2;
+    bool run = pvalid && k_in == 0;
+    auto store_group = [&](const int grp) {                     // my 16 bytes of group grp of the spare slab
+        *(lds_u128 *)(uintptr_t)(uint32_t)(spare_p + 64 * grp) = fresh[grp];
+    };
+    auto one_step = [&](auto grp_tag) {
+        constexpr int GRP = decltype(grp_tag)::value;
+        const int dir8 = (int)((acts << 3) + (uint32_t)d8);
+        const int tgt = pos + __builtin_amdgcn_sbfe((int)bstep4, dir8, 8);
+        const int tq = run ? tgt : jpos;                        // a dead player probes its own junk word
+        const int wa = (tq >> 3) & ~3;                          // the word holding the cell; its bit is tq & 31
+        uint32_t word;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(word) : "v"(wa) : "memory");
+        // right behind the probe: the LDS serves a wave's requests in order, so the store runs while the wave waits
+        if constexpr (GRP < kGroups) store_group(GRP);
+        const uint32_t bit = 1u << (tq & 31);
+        acts >>= 2;
+        neg2 += 2;
+        if (neg2 == 0) {
+            const uint32_t c = tc_in + (dry2 >> 1);
+            if ((c & 16u) == 0u) refill(c >> 5);
+            acts = (c & 16u) ? a_hi : a_lo;
+            dry2 += 32u;
+            neg2 = -32;
+        }
+        const int x1 = tq ^ tron_quad<0x39>(pos), x2 = tq ^ tron_quad<0x4E>(pos), x3 = tq ^ tron_quad<0x93>(pos);
+        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
+        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(word) : : "memory");
+        int dirE, to, wsel;
+        bool ran, moved, alive_now;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
+            // rare: the quad's four players in the reference's order, redundantly in its four lanes
+            const int d = (d8 >> 3) & 3, dir = (dir8 >> 3) & 3, al = run ? 1 : 0, oc = (word & bit) ? 1 : 0;
+            int ps[4] = {tron_quad<0x00>(pos), tron_quad<0x55>(pos), tron_quad<0xAA>(pos), tron_quad<0xFF>(pos)};
+            int ds[4] = {tron_quad<0x00>(d), tron_quad<0x55>(d), tron_quad<0xAA>(d), tron_quad<0xFF>(d)};
+            int al4[4] = {tron_quad<0x00>(al), tron_quad<0x55>(al), tron_quad<0xAA>(al), tron_quad<0xFF>(al)};
+            const int tg[4] = {tron_quad<0x00>(tgt), tron_quad<0x55>(tgt), tron_quad<0xAA>(tgt), tron_quad<0xFF>(tgt)};
+            const int oq[4] = {tron_quad<0x00>(oc), tron_quad<0x55>(oc), tron_quad<0xAA>(oc), tron_quad<0xFF>(oc)};
+            const int nd[4] = {tron_quad<0x00>(dir), tron_quad<0x55>(dir), tron_quad<0xAA>(dir), tron_quad<0xFF>(dir)};
+            const int jbase = mine + 2 * kSlab;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                       // CyTronGrid.pyx:15-62
+                const bool runi = al4[i] != 0;                   // :16 (may have been killed head-on by j < i)
+                bool on_head[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) on_head[q] = (q != i) && (tg[i] == ps[q]);   // ps[q] already moved for q < i
+                bool occ = oq[i] != 0;                          // trail or wall
+#pragma unroll
+                for (int j = 0; j < i; ++j) occ |= on_head[j];  // j moved there earlier in this very step
+                const bool mv = runi & !occ;
+                al4[i] = (runi & occ) ? 0 : al4[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q != i) al4[q] = (runi & on_head[q]) ? 0 : al4[q];                // :56-57 head-on: the owner dies too
+                ds[i] = runi ? nd[i] : ds[i];                   // :44
+                ps[i] = mv ? tg[i] : ps[i];
+                atomicOr((unsigned int *)(lds + ((mv ? ((tg[i] >> 3) & ~3) : jbase) - lds0)), 1u << (tg[i] & 31));
+            }
+            int pS = ps[0], dS = ds[0], aS = al4[0];
+            pS = (p == 1) ? ps[1] : pS; dS = (p == 1) ? ds[1] : dS; aS = (p == 1) ? al4[1] : aS;
+            pS = (p == 2) ? ps[2] : pS; dS = (p == 2) ? ds[2] : dS; aS = (p == 2) ? al4[2] : aS;
+            pS = (p == 3) ? ps[3] : pS; dS = (p == 3) ? ds[3] : dS; aS = (p == 3) ? al4[3] : aS;
+            to = pS;
+            dirE = dS << 3;
+            wsel = jaddr;
+            int one = 1;
+            asm volatile("" : "+v"(one));                       // an opaque `true`: keeps the selects below the join
+            ran = moved = one != 0;
+            alive_now = (p < P) && aS != 0;
+        } else {
+            const bool dead = run & ((word & bit) != 0u);       // :47-57 trail or wall
+            dirE = dir8;
+            to = tgt;
+            wsel = wa;
+            ran = run;                                          // :44 the direction is committed even if the move dies
+            moved = run ^ dead;                                 // :60-62
+            alive_now = moved;
+        }
+        d8 = ran ? dirE : d8;
+        pos = moved ? to : pos;
+        atomicOr((unsigned int *)(lds + ((moved ? wsel : jaddr) - lds0)), bit);
+        run = alive_now;
+        // TronGridEnvironment.py:309-321 for the game: alive players over the quad
+        int a = run ? 1 : 0;
+        asm volatile("" : "+v"(a));
+        int alive = a + tron_quad<0xB1>(a);
+        alive += tron_quad<0x4E>(alive);
+        alive_steps += (uint32_t)a;
+        if (alive <= 1) {                                       // new_state: swap the slabs
+            const uint32_t done2 = dry2 + (uint32_t)neg2;       // 2 * (launch steps done)
+            // the spare is completely fresh four steps after it was retired -- or at once, for a shorter episode (rare)
+            if (__builtin_amdgcn_ballot_w64(done2 < ok_at2)) {
+                if (done2 < ok_at2) {
+#pragma unroll
+                    for (int grp = 0; grp < kGroups; ++grp) store_group(grp);
+                }
+            }
+            ok_at2 = done2 + 8u;
+            cur8 ^= flip8;
+            spare_p = both_p - spare_p;
+            wn += 0x10000u + (uint32_t)a;
+            marks = ((marks << 16) + done2) + (uint32_t)a;
+            pos = cur8 + fresh_off;
+            d8 = fresh_d8;
+            run = fresh_run;
+        }
+    };
+    for (int t = 0;;) {                                         // four steps per trip, one per group of the spare slab
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 0>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 1>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 2>{}); ++t;
+        if (t >= T) break;
+        one_step(std::integral_constant<int, 3>{}); ++t;
+    }
+    // ---- statistics (my player's columns; the game's by lane 0 of the quad) and the hand-over to the replay
+    const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
+    const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
+    const uint32_t tc = tc_in + (uint32_t)T;
+    const uint32_t ts = n_ep ? (uint32_t)(T - done_last) : ts_at_entry + (uint32_t)T;
+    const int last_len = (n_ep > 1u) ? done_last - done_prev : (int)ts_at_entry + done_last;
+    int lw = (last_alive & 1) << p;
+    lw |= tron_quad<0xB1>(lw);
+    lw |= tron_quad<0x4E>(lw);
+    const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;
+    int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    if (pvalid) {
+        const int rs = old_ret + ret;
+        const uint32_t wc = old_wins + wins;
+        st.ret_sum[p * B + b] = rs;
+        st.win_count[p * B + b] = wc;
+        if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+    }
+    if (p == 0) {
+        r_tc[slot] = tc;
+        r_steps[slot] = gvalid ? (n_ep ? (int)ts : -1) : 0;
+    }
+    if (gvalid && p == 0) {
+        const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + (ts_at_entry + (uint32_t)T - ts);
+        st.tcount[b] = tc;
+        st.tstep[b] = ts;
+        st.n_episodes[b] = ne;
+        st.len_sum[b] = ls;
+        if (n_ep > 0) {
+            st.last_winners[b] = (uint8_t)lw;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+        if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+    }
+    __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
+
+    // ---- replay of the unfinished episodes on byte slabs: rebuilds board / heads / dirs / deaths.  Four turns of 16
+    // games: the workgroup lays out fresh boards, wave `turn` replays with a lane per game, the workgroup copies out.
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    constexpr int kRowDwords = RS / 4;
+    const int sd = pad.stride >> 2;                             // dwords per byte slab
+    for (int turn = 0; turn < kGames / kWaveGames; ++turn) {
+        {   // (1) fresh boards in the 16 slabs (16 threads each): walls, empty cells; then the start heads
+            const int base = lds0 + (int)(threadIdx.x >> 4) * pad.stride;
+            for (int d = (int)(threadIdx.x & 15); d < sd; d += 16) {
+                const int byte = d * 4;
+                const int rw = byte / RS, col = byte - rw * RS;
+                const int left = N - col;                       // cells from this dword to the row's end
+                uint32_t v = 0xffffffffu;
+                if (rw >= 1 && rw <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
+                *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kWaveGames) {
+            const int base = lds0 + (int)threadIdx.x * pad.stride;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int sh = cfg.start_heads[q];
+                const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(base + (sy + 1) * RS + (sh - sy * N)) = (uint8_t)(q + 1);
+            }
+        }
+        __syncthreads();
+        const int64_t gbase = (int64_t)blockIdx.x * kGames + turn * kWaveGames;     // first game of this turn
+        const int n_turn = (int)((B - gbase) < kWaveGames ? (B - gbase > 0 ? B - gbase : 0) : kWaveGames);
+        if (wave == turn) {                                     // (2) a lane per game; lanes 16.. idle along
+            const int gl = lane & (kWaveGames - 1);
+            const bool lvalid = lane < n_turn;                  // (n_turn <= 16)
+            const int64_t bg = gbase + gl, bbg = lvalid ? bg : 0;
+            const int rsteps = lvalid ? r_steps[turn * kWaveGames + gl] : 0;
+            const bool from_start = rsteps >= 0;                // else: from the state the launch came in with
+            const int steps_r = lvalid ? (from_start ? rsteps : T) : 0;
+            const uint32_t tc_end = r_tc[turn * kWaveGames + gl];
+            const uint32_t gidr = (uint32_t)(first_env_id + (uint64_t)bbg);
+            // every lane replays the LAST steps_r of the wave's `replay_len` iterations (see tron_rollout_bits_kernel)
+            int replay_len = steps_r;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) replay_len = max(replay_len, __shfl_xor(replay_len, off, CRL_WAVE));
+            const int first_r = replay_len - steps_r;
+            uint32_t c_r = tc_end - (uint32_t)replay_len;
+            const int bmine = lds0 + gl * pad.stride;
+            if (__builtin_amdgcn_ballot_w64(lvalid && !from_start)) {            // somebody resumes from the incoming board
+                const int8_t *gslab = board + gbase * NN;
+                if (wide) {
+                    const int bytes = n_turn * NN;
+                    for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                        const int cq = (off - e * NN) >> 2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                            *(lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
+                        }
+                    }
+                } else {
+                    for (int e = 0; e < n_turn; ++e)
+                        for (int c = lane; c < NN; c += CRL_WAVE) {
+                            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                            *(lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lvalid && from_start) {                     // this lane's slab was overwritten too: fresh again
+                    for (int y = 0; y < N; ++y)
+#pragma unroll
+                        for (int j = 0; j < kRowDwords; ++j) {
+                            uint32_t w = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
+                            *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
+                        }
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        const int sh = cfg.start_heads[q];
+                        const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
+                        *(lds_u8 *)(uintptr_t)(uint32_t)(bmine + (sy + 1) * RS + (sh - sy * N)) = (uint8_t)(q + 1);
+                    }
+                }
+            }
+            TronRegs<P> s;
+            uint32_t stamp[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                int h = cfg.start_heads[q];
+                s.d[q] = cfg.start_dirs[q];
+                s.k[q] = lvalid ? 0 : 1;
+                if (!from_start) {
+                    h = lvalid ? min(max((int)heads[q * B + bbg], 0), NN - 1) : 0;
+                    s.d[q] = lvalid ? dirs[q * B + bbg] & 3 : 0;
+                    s.k[q] = lvalid ? deaths[q * B + bbg] : 1;
+                }
+                const int y = (int)__umulhi((uint32_t)h, g.inv_n);
+                s.h[q] = bmine + (y + 1) * RS + (h - y * N);
+                stamp[q] = (uint32_t)(q + 1);
+            }
+            // (lanes 16.. share the slabs of lanes 0..15 but never run: their stores go to that slab's junk byte)
+            const int junk = bmine + pad.junk;
+            LdsBoard<3> bd{0u};                                 // single episode: tag 0, cells hold the plain owner
+            TronRng<P> rr;
+            int act[P];
+            rr.start(gidr, c_r, seed_lo, seed_hi);
+            rr.next_lut(gidr, c_r, seed_lo, seed_hi, act_lut, act);
+            for (int t = 0; t < replay_len; ++t) {
+                TronProbe<P> pr;
+                tron_probe_padded<P>(step4, bd, s, act, pr);
+                c_r += 1;
+                rr.next_lut(gidr, c_r, seed_lo, seed_hi, act_lut, act);
+                tron_resolve_lds<P>(bd, s, pr, stamp, junk, lvalid && t >= first_r);
+            }
+            if (lvalid) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const int rel = s.h[q] - bmine;
+                    const int rw = rel / RS;
+                    heads[q * B + bg] = (int16_t)((rw - 1) * N + (rel - rw * RS));
+                    dirs[q * B + bg] = (int8_t)s.d[q];
+                    deaths[q * B + bg] = (int8_t)s.k[q];
+                }
+            }
+        }
+        __syncthreads();
+        {   // (3) copy out: cells are plain owners (walls are never copied)
+            int8_t *gslab = board + gbase * NN;
+            if (wide) {
+                const int bytes = n_turn * NN;
+                for (int off = (int)threadIdx.x * 16; off < bytes; off += 256 * 16) {
+                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                    int o[4];
+                    tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+                    uint32_t w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + o[q]);
+                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            } else {
+                const int cells = n_turn * NN;
+                for (int i = (int)threadIdx.x; i < cells; i += 256) {
+                    const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
+                    const int c = i - e * NN;
+                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                    gslab[i] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // state sanity for hand-made states: heads inside the board and on their owner's cell
 __global__ void __launch_bounds__(256)
 tron_check_state_kernel(const int P, const int NN, const int64_t B, const int8_t *__restrict__ board,
@@ -2199,6 +2708,15 @@ constexpr int kLdsDynamic = 160 * 1024 - 1024;  // dynamic part; the kernels als
         default: crl_set_error("tron: P=%d out of range 1..8", P_); return CRL_EINVAL; \
     }
 
+#define TRON_DISPATCH_P4(P_, CALL)         \
+    switch (P_) {                          \
+        case 1: { constexpr int PP = 1; CALL; } break; \
+        case 2: { constexpr int PP = 2; CALL; } break; \
+        case 3: { constexpr int PP = 3; CALL; } break; \
+        case 4: { constexpr int PP = 4; CALL; } break; \
+        default: crl_set_error("tron: P=%d out of range 1..4", P_); return CRL_EINVAL; \
+    }
+
 extern "C" {
 
 int crl_tron_create(int N, int P, const int16_t *start_heads, const int8_t *start_dirs, crl_ctx **out)
@@ -2279,7 +2797,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
-    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
@@ -2306,7 +2824,28 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     // one lane per player, four per game: boards up to 20x20 with at most 4 players (see tron_rollout_quad_kernel)
     const bool quad_ok = lds_ok && small && cfg.P <= 4 && pad.sweep_rows == 1;
     // the default wherever it applies: 1.42e11 vs 1.24e11 env-steps/s for the lane-per-game byte kernel at 20x20, P = 4
-    const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS));
+    const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QBITS));
+    // the same on bitboards (+ replay): boards above 20x20, where byte slabs would leave a CU with one wave per SIMD
+    const bool qbits_ok = lds_ok && cfg.P <= 4;
+    const bool use_qbits = qbits_ok && !use_quad &&
+                           ((flags & CRL_ROLLOUT_QBITS) || (!small && T >= 256 && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS))));
+    if (use_qbits) {
+        const size_t lds_q = std::max((size_t)64 * bits.stride, (size_t)16 * pad.stride);
+        constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, see below)
+        for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
+            const int tt = std::min(kQuadMaxT, T - t0);
+            TRON_DISPATCH_P4(cfg.P, {
+                if (small)
+                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, false>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, bits, B,
+                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                else
+                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, true>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, bits, B,
+                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+            });
+            CRL_LAUNCH_CHECK();
+        }
+        return CRL_OK;
+    }
     if (use_quad) {
         // (the kernel keeps a launch's episode, win and step counts in 14..16 bits: longer rollouts go out as several launches,
         //  which is the same rollout -- the state and the step counters carry over)

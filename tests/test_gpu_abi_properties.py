@@ -137,7 +137,7 @@ def test_tron_check_state():
     assert tb.check_state() == 2
 
 
-@pytest.mark.parametrize("kernel", ["bytes", "bits", "quad"])
+@pytest.mark.parametrize("kernel", ["bytes", "bits", "quad", "qbits"])
 def test_hand_made_states_with_wild_heads_stay_inside_the_slab(kernel):
     """Heads outside the board (a hand-uploaded or corrupted state) are clamped onto it by the LDS rollout kernels: the
     results of such games are unspecified, but the launch completes, reports no error, and every OTHER game of the batch

@@ -14,7 +14,9 @@ from oracle import oracle as O
                                             (30, 3, 1024, 800, "bytes"), (6, 2, 512, 3000, "bits"), (6, 2, 512, 3000, "bytes"),
                                             (12, 8, 512, 1500, "bits"), (12, 8, 512, 1500, "bytes"), (23, 4, 512, 1200, "auto"),
                                             (16, 5, 700, 1200, "bytes"), (40, 4, 1000, 900, "bits"), (40, 4, 1000, 900, "bytes"),
-                                            (36, 8, 300, 700, "bits"), (36, 8, 300, 700, "bytes"), (40, 4, 512, 600, "global")])
+                                            (36, 8, 300, 700, "bits"), (36, 8, 300, 700, "bytes"), (40, 4, 512, 600, "global"),
+                                            (40, 4, 1000, 900, "qbits"), (30, 3, 1024 + 7, 800, "qbits"), (20, 4, 4096, 1500, "qbits"),
+                                            (6, 2, 512, 3000, "qbits"), (13, 3, 1024 + 9, 1200, "qbits"), (33, 2, 130, 20000, "qbits")])
 def test_tron_long_rollout(N, P, B, T, kernel):
     from colosseumrl_amd.batched import TronBatch
     seed, first = 0x5EED + N, 10 ** 6

@@ -86,23 +86,24 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
     return ost
 
 
-@pytest.mark.parametrize("kernel", ["quad", "bits", "bytes", "global", "auto"])
+@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global", "auto"])
 @pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (20, 3, 1000 + 3, (40, 9)), (12, 2, 321, (60,)), (16, 4, 64 * 5 + 1, (25, 25)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
                                            (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,)),
                                            (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,)),
                                            (20, 4, 1000, (300, 2, 260)), (40, 4, 700, (1, 1, 290)), (37, 7, 130, (280,)),
                                            (4, 2, 200, (50,)), (4, 4, 70, (20,)), (4, 3, 130, (30,)), (5, 4, 100, (40,))])
 def test_rollout_vs_oracle(N, P, B, chunks, kernel):
-    """Fused random-agent rollout == oracle rollout, bit for bit, for the four kernels behind crl_tron_rollout (lane per
-    player "quad" -- where it does not apply, P > 4 or boards above 20x20, the flag falls through to the library's choice --
-    LDS bitboard with replay epilogue, LDS byte slabs, global memory) and the library's own choice: ragged batches, odd
+    """Fused random-agent rollout == oracle rollout, bit for bit, for the five kernels behind crl_tron_rollout (lane per
+    player on byte slabs "quad" / on bitboards with replay "qbits" -- where they do not apply, P > 4 or for quad boards
+    above 20x20, the flag falls through to the library's choice -- lane-per-game LDS bitboard with replay epilogue, LDS
+    byte slabs, global memory) and the library's own choice: ragged batches, odd
     boards (byte copy path), split launches (state and RNG position carry over; a 1-step launch makes the bitboard
     kernel replay from the incoming state), and launches long enough to wrap the byte kernel's episode tags."""
     ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, kernel=kernel)
     assert ost.n_episodes.sum() > B
 
 
-@pytest.mark.parametrize("kernel", ["quad", "bits", "bytes", "global"])
+@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global"])
 def test_rollout_after_scripted_steps(kernel):
     """A rollout continues from whatever state the step API left (mid-episode, some players dead, histories that no
     RNG stream produced): the bitboard kernel must resume from the incoming board, not from the episode start."""
@@ -153,11 +154,12 @@ def test_rollout_full_size_properties(N, T):
     assert torch.equal(half.n_episodes, tb.n_episodes[B // 2:])
 
 
-@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (40, (32,), "auto"), (40, (300,), "auto")])
+@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (20, (20, 12), "qbits"), (40, (32,), "auto"), (40, (300,), "auto"), (40, (300,), "bits")])
 def test_rollout_full_size_vs_oracle(N, chunks, kernel):
     """BASELINE config 2 / the config-5 shard at FULL size (B = 65,536, P = 4) against the oracle itself, not only through
     invariants: every state array and every statistic, bit for bit (the oracle needs ~10-100 ms per launch on 8 threads).
-    T = 300 on 40x40 is the bitboard kernel with its replay epilogue; 20x20 'bits' pins the bitboard kernel there."""
+    T = 300 on 40x40 is the lane-per-player bitboard kernel with its replay epilogue ('bits': the lane-per-game one); 20x20
+    'bits' / 'qbits' pin the bitboard kernels there."""
     ost = _rollout_pair(N, 4, 65536, chunks, seed=20261004, first=3 * 65536, kernel=kernel)
     assert ost.n_episodes.sum() > 65536
 

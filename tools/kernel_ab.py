@@ -12,7 +12,7 @@ from colosseumrl_amd.batched import TronBatch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 B = 65536
-tbs = {k: TronBatch(N, 4, B) for k in (("quad", "bytes", "bits") if N <= 20 else ("bytes", "bits"))}
+tbs = {k: TronBatch(N, 4, B) for k in (("quad", "bytes", "bits", "qbits") if N <= 20 else ("bytes", "bits", "qbits"))}
 for k, tb in tbs.items():
     tb.rollout(T, 0, kernel=k)
 torch.cuda.synchronize()
