@@ -50,7 +50,7 @@ CALIBRATION = os.path.join(ROOT, "profiles", "r2_valu_issue_calibration.json")
 WORKLOADS = {
     # name: (game, kwargs, per-GPU batch, env-steps fused into one launch by default, resident waves per SIMD)
     "tron_p4_n20_b65536": ("tron", dict(board_size=20, num_players=4), 65536, 8192, 4),   # one lane per player: 4 waves/SIMD
-    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192, 1),
+    "tron_p4_n40_b65536": ("tron", dict(board_size=40, num_players=4), 65536, 8192, 4),   # one lane per player, bitboards
     "ttt_p3_5x5_k4_b262144": ("ttt", dict(dims=(5, 5), k=4, num_players=3), 262144, 2048, 4),
     "ttt_p3_3x5_k3_b262144": ("ttt", dict(dims=(3, 5), k=3, num_players=3), 262144, 2048, 4),
     "ttt_p4_3x3x3_b262144": ("ttt", dict(dims=(3, 3, 3), k=3, num_players=4), 262144, 2048, 4),
@@ -102,7 +102,9 @@ def kernel_name(game, kw, steps_per_launch):
         n = kw["board_size"]                                     # csrc/tron.hip, crl_tron_rollout's choice
         if n <= 20:
             return "tron_rollout_quad_kernel" if kw["num_players"] <= 4 else "tron_rollout_lds_kernel"
-        return ("tron_rollout_bits_kernel" if steps_per_launch >= 256 else "tron_rollout_lds_kernel") if n <= 40 else "tron_rollout_kernel"
+        if n <= 40 and steps_per_launch >= 256:
+            return "tron_rollout_qbits_kernel" if kw["num_players"] <= 4 else "tron_rollout_bits_kernel"
+        return "tron_rollout_lds_kernel" if n <= 40 else "tron_rollout_kernel"
     return "%s_rollout_kernel" % game
 
 

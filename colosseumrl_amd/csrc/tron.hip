@@ -1049,7 +1049,11 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         return x;
     };
     auto refill = [&](const uint32_t group) {                   // group = c >> 5
-        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
+        // (the seed through an opaque copy: the ten rounds' keys are then derived here, every 32 steps, instead of living
+        //  in 20 scalar registers across the step loop -- which had pushed the loop's lane masks out of SGPRs)
+        uint32_t k0 = seed_lo, k1 = seed_hi;
+        asm volatile("" : "+s"(k0), "+s"(k1));
+        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
         uint32_t code[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1836,7 +1840,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     static_assert(kSlab * 8 - 8 >= kMaxW * 32 || kSlab * 8 - 8 >= (kMaxN + 2) * (kMaxN + 1), "padding bits behind the board");
     const int fresh_off = (p < P) ? (fy + 1) * S + (fh - fy * N) : kSlab * 8 - 8 + p;
     const int fresh_d8 = fd << 3;
-    const bool fresh_run = p < P;
+    const int fresh_a = (p < P) ? 1 : 0;
     int cur8 = 8 * mine;                                        // 8 * (slab in play)
     const int flip8 = (8 * mine) ^ (8 * (mine + kSlab));
     int spare_p = mine + kSlab + 16 * p;                        // my 16 bytes of group 0 of the spare slab
@@ -1860,7 +1864,11 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         return x;
     };
     auto refill = [&](const uint32_t group) {                   // see tron_rollout_quad_kernel
-        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, seed_lo, seed_hi);
+        // (the seed through an opaque copy: the ten rounds' keys are then derived here, every 32 steps, instead of living
+        //  in 20 scalar registers across the step loop -- which had pushed the loop's lane masks out of SGPRs)
+        uint32_t k0 = seed_lo, k1 = seed_hi;
+        asm volatile("" : "+s"(k0), "+s"(k1));
+        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
         uint32_t code[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1886,12 +1894,15 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     uint32_t acts = ((tc_in & 16u) ? a_hi : a_lo) >> ((tc_in & 15u) * 2u);
     uint32_t dry2 = 32u - 2u * (tc_in & 15u);
     int neg2 = -(int)dry2;
-    bool run = pvalid && k_in == 0;
+    // my player is alive: carried as a 0 / 1 vector register (the compiler would not keep a lane mask across the unrolled
+    // loop and its reset branches; one compare per step turns it into one)
+    int a = (pvalid && k_in == 0) ? 1 : 0;
     auto store_group = [&](const int grp) {                     // my 16 bytes of group grp of the spare slab
         *(lds_u128 *)(uintptr_t)(uint32_t)(spare_p + 64 * grp) = fresh[grp];
     };
     auto one_step = [&](auto grp_tag) {
         constexpr int GRP = decltype(grp_tag)::value;
+        const bool run = a != 0;
         const int dir8 = (int)((acts << 3) + (uint32_t)d8);
         const int tgt = pos + __builtin_amdgcn_sbfe((int)bstep4, dir8, 8);
         const int tq = run ? tgt : jpos;                        // a dead player probes its own junk word
@@ -1900,7 +1911,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         asm volatile("ds_read_b32 %0, %1" : "=v"(word) : "v"(wa) : "memory");
         // right behind the probe: the LDS serves a wave's requests in order, so the store runs while the wave waits
         if constexpr (GRP < kGroups) store_group(GRP);
-        const uint32_t bit = 1u << (tq & 31);
+        uint32_t bit;                                           // 1 << (tq & 31): the shift reads five bits by itself
+        asm("v_lshlrev_b32 %0, %1, 1" : "=v"(bit) : "v"(tq));
         acts >>= 2;
         neg2 += 2;
         if (neg2 == 0) {
@@ -1967,9 +1979,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         d8 = ran ? dirE : d8;
         pos = moved ? to : pos;
         atomicOr((unsigned int *)(lds + ((moved ? wsel : jaddr) - lds0)), bit);
-        run = alive_now;
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
-        int a = run ? 1 : 0;
+        a = alive_now ? 1 : 0;
         asm volatile("" : "+v"(a));
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
@@ -1977,11 +1988,9 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         if (alive <= 1) {                                       // new_state: swap the slabs
             const uint32_t done2 = dry2 + (uint32_t)neg2;       // 2 * (launch steps done)
             // the spare is completely fresh four steps after it was retired -- or at once, for a shorter episode (rare)
-            if (__builtin_amdgcn_ballot_w64(done2 < ok_at2)) {
-                if (done2 < ok_at2) {
+            if (done2 < ok_at2) {
 #pragma unroll
-                    for (int grp = 0; grp < kGroups; ++grp) store_group(grp);
-                }
+                for (int grp = 0; grp < kGroups; ++grp) store_group(grp);
             }
             ok_at2 = done2 + 8u;
             cur8 ^= flip8;
@@ -1990,19 +1999,19 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             marks = ((marks << 16) + done2) + (uint32_t)a;
             pos = cur8 + fresh_off;
             d8 = fresh_d8;
-            run = fresh_run;
+            a = fresh_a;
         }
     };
-    for (int t = 0;;) {                                         // four steps per trip, one per group of the spare slab
-        if (t >= T) break;
-        one_step(std::integral_constant<int, 0>{}); ++t;
-        if (t >= T) break;
-        one_step(std::integral_constant<int, 1>{}); ++t;
-        if (t >= T) break;
-        one_step(std::integral_constant<int, 2>{}); ++t;
-        if (t >= T) break;
-        one_step(std::integral_constant<int, 3>{}); ++t;
+    // four steps per trip, one per group of the spare slab; the odd steps afterwards
+    for (int trip = T >> 2; trip > 0; --trip) {
+        one_step(std::integral_constant<int, 0>{});
+        one_step(std::integral_constant<int, 1>{});
+        one_step(std::integral_constant<int, 2>{});
+        one_step(std::integral_constant<int, 3>{});
     }
+    if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{});
+    if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{});
+    if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{});
     // ---- statistics (my player's columns; the game's by lane 0 of the quad) and the hand-over to the replay
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
