@@ -1900,7 +1900,10 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     auto store_group = [&](const int grp) {                     // my 16 bytes of group grp of the spare slab
         *(lds_u128 *)(uintptr_t)(uint32_t)(spare_p + 64 * grp) = fresh[grp];
     };
-    auto one_step = [&](auto grp_tag) {
+    // When every game of the wave enters with its step counter a multiple of four (launches of 4 k steps keep it so),
+    // `acts` can only run dry at the end of a four-step trip: the countdown is then kept per trip, not per step.
+    const bool by_trip = __builtin_amdgcn_ballot_w64((tc_in & 3u) != 0u) == 0ull;
+    auto one_step = [&](auto grp_tag, const bool trips) {      // trips: wave-uniform, this step is part of such a trip
         constexpr int GRP = decltype(grp_tag)::value;
         const bool run = a != 0;
         const int dir8 = (int)((acts << 3) + (uint32_t)d8);
@@ -1914,8 +1917,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         uint32_t bit;                                           // 1 << (tq & 31): the shift reads five bits by itself
         asm("v_lshlrev_b32 %0, %1, 1" : "=v"(bit) : "v"(tq));
         acts >>= 2;
-        neg2 += 2;
-        if (neg2 == 0) {
+        if (!trips || GRP == 3) neg2 += trips ? 8 : 2;
+        if ((!trips || GRP == 3) && neg2 == 0) {
             const uint32_t c = tc_in + (dry2 >> 1);
             if ((c & 16u) == 0u) refill(c >> 5);
             acts = (c & 16u) ? a_hi : a_lo;
@@ -1986,7 +1989,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         alive += tron_quad<0x4E>(alive);
         alive_steps += (uint32_t)a;
         if (alive <= 1) {                                       // new_state: swap the slabs
-            const uint32_t done2 = dry2 + (uint32_t)neg2;       // 2 * (launch steps done)
+            // 2 * (launch steps done); inside a trip the countdown is as of the trip's start
+            const uint32_t done2 = dry2 + (uint32_t)neg2 + (uint32_t)((trips && GRP < 3) ? 2 * (GRP + 1) : 0);
             // the spare is completely fresh four steps after it was retired -- or at once, for a shorter episode (rare)
             if (done2 < ok_at2) {
 #pragma unroll
@@ -2004,14 +2008,14 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     };
     // four steps per trip, one per group of the spare slab; the odd steps afterwards
     for (int trip = T >> 2; trip > 0; --trip) {
-        one_step(std::integral_constant<int, 0>{});
-        one_step(std::integral_constant<int, 1>{});
-        one_step(std::integral_constant<int, 2>{});
-        one_step(std::integral_constant<int, 3>{});
+        one_step(std::integral_constant<int, 0>{}, by_trip);
+        one_step(std::integral_constant<int, 1>{}, by_trip);
+        one_step(std::integral_constant<int, 2>{}, by_trip);
+        one_step(std::integral_constant<int, 3>{}, by_trip);
     }
-    if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{});
-    if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{});
-    if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{});
+    if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{}, false);
+    if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{}, false);
+    if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{}, false);
     // ---- statistics (my player's columns; the game's by lane 0 of the quad) and the hand-over to the replay
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
