@@ -102,9 +102,11 @@ def kernel_name(game, kw, steps_per_launch):
         n = kw["board_size"]                                     # csrc/tron.hip, crl_tron_rollout's choice
         if n <= 20:
             return "tron_rollout_quad_kernel" if kw["num_players"] <= 4 else "tron_rollout_lds_kernel"
-        if n <= 40 and steps_per_launch >= 256:
-            return "tron_rollout_qbits_kernel" if kw["num_players"] <= 4 else "tron_rollout_bits_kernel"
-        return "tron_rollout_lds_kernel" if n <= 40 else "tron_rollout_kernel"
+        if n <= 40 and kw["num_players"] <= 4:
+            return "tron_rollout_qbits_kernel"
+        if n <= 40:
+            return "tron_rollout_bits_kernel" if steps_per_launch >= 256 else "tron_rollout_lds_kernel"
+        return "tron_rollout_kernel"
     return "%s_rollout_kernel" % game
 
 

@@ -13,12 +13,18 @@
 // heads) and patches same-step interactions in registers, so it costs one round of loads and one
 // round of stores instead of P dependent round trips.
 //
-// Three interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
-//   * LDS byte slabs (boards up to 20x20: 256 games per workgroup; up to 40x40: 64): every wave copies its boards
-//     into LDS once, plays all T steps there (wall-bordered slabs, heads as LDS addresses, episode-tagged cells with
-//     a rolling one-row rewrite instead of board clears), and writes the boards back once.
-//   * LDS bitboards + replay (default above 20x20, T >= 256): occupancy only while playing, deaths as lane masks;
-//     the unfinished episode is replayed on byte slabs at the end to recover owners.
+// Five interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
+//   * lane per PLAYER, four lanes per game (at most 4 players; the defaults where they apply): the quad shares what is
+//     per game by DPP (alive count, random stream, reset), the reference's sequential order is resolved only on the
+//     ~1 % of wave-steps where players interact.  64 games per workgroup, 4 waves per SIMD:
+//       - tron_rollout_quad_kernel, LDS byte slabs, boards up to 20x20;
+//       - tron_rollout_qbits_kernel, LDS bitboards + replay epilogue, boards up to 40x40 (default for 21..40).
+//   * lane per GAME (more than 4 players; or pinned):
+//       - LDS byte slabs (boards up to 20x20: 256 games per workgroup; up to 40x40: 64): every wave copies its boards
+//         into LDS once, plays all T steps there (wall-bordered slabs, heads as LDS addresses, episode-tagged cells
+//         with a rolling one-row rewrite instead of board clears), and writes the boards back once;
+//       - LDS bitboards + replay (above 20x20, T >= 256): occupancy only while playing, deaths as lane masks; the
+//         unfinished episode is replayed on byte slabs at the end to recover owners.
 //   * global-memory (boards above 40x40): boards stay in HBM / Infinity Cache, same tagged cells, tags stripped
 //     in place at the end.
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
@@ -1690,7 +1696,7 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
 }
 
-// ---- quad bitboard rollout: one lane per PLAYER on occupancy bitboards (boards up to 40x40, P <= 4, T >= 256) ------
+// ---- quad bitboard rollout: one lane per PLAYER on occupancy bitboards (boards up to 40x40, P <= 4) ------------------
 // The lane-per-game bitboard kernel above keeps a 40x40 game in 528 bytes of LDS, but 65,536 games are still only
 // 1,024 waves: one per SIMD, issuing an instruction every ~5.9 cycles.  This kernel is to it what
 // tron_rollout_quad_kernel is to the byte kernel: a lane plays ONE player (probe a bit, die or move, set a bit), the
@@ -2838,10 +2844,12 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     const bool quad_ok = lds_ok && small && cfg.P <= 4 && pad.sweep_rows == 1;
     // the default wherever it applies: 1.42e11 vs 1.24e11 env-steps/s for the lane-per-game byte kernel at 20x20, P = 4
     const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QBITS));
-    // the same on bitboards (+ replay): boards above 20x20, where byte slabs would leave a CU with one wave per SIMD
+    // the same on bitboards (+ replay): boards above 20x20, where byte slabs would leave a CU with one wave per SIMD.
+    // Launches of any length: at 40x40 even a 16-step launch takes 0.15 ms against 0.25 ms on byte slabs (the replay is
+    // cheaper than moving 1,852-byte slabs through a lone wave per SIMD); tools/sessions/gpu_session_z.sh
     const bool qbits_ok = lds_ok && cfg.P <= 4;
     const bool use_qbits = qbits_ok && !use_quad &&
-                           ((flags & CRL_ROLLOUT_QBITS) || (!small && T >= 256 && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS))));
+                           ((flags & CRL_ROLLOUT_QBITS) || (!small && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS))));
     if (use_qbits) {
         const size_t lds_q = std::max((size_t)64 * bits.stride, (size_t)16 * pad.stride);
         constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, see below)

@@ -50,11 +50,11 @@ extern "C" {
 /* flags for crl_tron_rollout */
 #define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
 #define CRL_ROLLOUT_BYTES   4u  /* force the lane-per-game byte-per-cell LDS kernel */
-#define CRL_ROLLOUT_BITS    8u  /* force the lane-per-game bitboard LDS kernel with replay epilogue (default for boards 21..40 wide, T >= 256, P > 4) */
+#define CRL_ROLLOUT_BITS    8u  /* force the lane-per-game bitboard LDS kernel with replay epilogue (default for boards 21..40 wide with P > 4 and T >= 256) */
 #define CRL_ROLLOUT_QUAD   16u  /* the lane-per-player kernel (four lanes per game): boards up to 20x20 with at most 4 players.
                                  * It is the default there; elsewhere the flag is ignored */
 #define CRL_ROLLOUT_QBITS  32u  /* the lane-per-player bitboard kernel with replay epilogue (at most 4 players, boards up to
-                                 * 40x40): the default for boards 21..40 wide and T >= 256; elsewhere the flag is ignored */
+                                 * 40x40): the default for boards 21..40 wide; with more than 4 players the flag is ignored */
 
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 
@@ -119,8 +119,8 @@ typedef struct {
  *   j = c & 7;  v = W[j >> 1] * 3^((j & 1) * 4 + (p & 3))  (mod 2^32)
  *   a = mulhi32(v, 3): 0 -> forward, 1 -> right, 2 -> left        (base-3 digits of the fraction W/2^32)
  * Boards up to 40x40 are played out of LDS (one copy in / one copy out per launch): boards up to 20x20 on a
- * byte-per-cell slab (one lane per player when P <= 4, else one lane per game), larger ones (T >= 256) on an occupancy
- * bitboard whose unfinished episode is replayed with
+ * byte-per-cell slab (one lane per player when P <= 4, else one lane per game), larger ones on an occupancy bitboard
+ * (one lane per player when P <= 4; else one lane per game and T >= 256) whose unfinished episode is replayed with
  * owners at the end of the launch; boards above 40x40, or flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / _BITS /
  * _QUAD / _QBITS pin one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
  * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player; callers

@@ -130,8 +130,8 @@ def test_rollout_after_scripted_steps(kernel):
 
 @pytest.mark.parametrize("N,T", [(20, 128), (40, 128), (40, 300)])
 def test_rollout_full_size_properties(N, T):
-    """BASELINE config 2 (N=20, LDS byte slabs) and config 5 per-GPU shard (N=40: byte slabs at T=128, bitboards +
-    replay at T=300), B=65536, P=4: size-independent properties of the fused rollout.
+    """BASELINE config 2 (N=20, LDS byte slabs, a lane per player) and config 5 per-GPU shard (N=40: bitboards + replay,
+    a lane per player), B=65536, P=4: size-independent properties of the fused rollout.
     sum(len_sum)+sum(tstep) == B*T; wins <= episodes; board consistent with heads; shard invariance."""
     import torch
     from colosseumrl_amd.batched import TronBatch
@@ -154,7 +154,7 @@ def test_rollout_full_size_properties(N, T):
     assert torch.equal(half.n_episodes, tb.n_episodes[B // 2:])
 
 
-@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (20, (20, 12), "qbits"), (40, (32,), "auto"), (40, (300,), "auto"), (40, (300,), "bits")])
+@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (20, (20, 12), "qbits"), (40, (32,), "auto"), (40, (32,), "bytes"), (40, (300,), "auto"), (40, (300,), "bits")])
 def test_rollout_full_size_vs_oracle(N, chunks, kernel):
     """BASELINE config 2 / the config-5 shard at FULL size (B = 65,536, P = 4) against the oracle itself, not only through
     invariants: every state array and every statistic, bit for bit (the oracle needs ~10-100 ms per launch on 8 threads).
