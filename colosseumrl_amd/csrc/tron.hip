@@ -145,6 +145,7 @@ __device__ __forceinline__ void tron_outcome(const TronRegs<P> &s, int (&rew)[P]
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes of global memory at a dword boundary
 
 // phases 2+3: the reference's sequential resolution on registers (CyTronGrid.pyx:15-62), trail writes, and the
 // reward / terminal / winners tail (TronGridEnvironment.py:309-321).  Straight-line code: every decision is a
@@ -962,27 +963,71 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     constexpr int kCopyBatch = 7;                               // 16 boards of <= 400 bytes = <= 6.25 KiB per wave
     const int8_t *gslab_in = board + env0 * NN;
     const int bytes_in = n_env * NN;
+    // 20x20 boards (the headline shape) move by ROWS: a row is 20 bytes = five dwords in HBM and six in the slab (its four
+    // wall bytes included), so a lane takes rows lane, lane + 64, ... of the wave's 320: a 16-byte + a 4-byte load each
+    // (consecutive lanes read consecutive rows: whole cache lines), three two-dword LDS stores, one division for the
+    // game -- no per-dword slab offsets, no wall fill to overwrite.  Other sizes move by 16-byte pieces as before.
+    constexpr int kRowsPerLane = (kWaveGames * 20) / CRL_WAVE;  // 5
+    const bool rows20 = N == 20;
+    const int rows_in = n_env * 20;
     uint4 cin[kCopyBatch];
-    if (wide) {
+    u32x4_a4 rin4[kRowsPerLane];
+    uint32_t rin1[kRowsPerLane];
+    if (rows20) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+            const int R = lane + k * CRL_WAVE;
+            const int8_t *src = gslab_in + (R < rows_in ? R * 20 : 0);
+            rin4[k] = *reinterpret_cast<const u32x4_a4 *>(src);
+            rin1[k] = *reinterpret_cast<const uint32_t *>(src + 16);
+        }
+    } else if (wide) {
 #pragma unroll
         for (int k = 0; k < kCopyBatch; ++k) {
             const int off = lane * 16 + k * (CRL_WAVE * 16);
             cin[k] = *reinterpret_cast<const uint4 *>(gslab_in + (off < bytes_in ? off : 0));
         }
     }
-    const int h_in = pvalid ? heads[p * B + bb] : 0;
-    const int d_in = pvalid ? dirs[p * B + bb] : 0;
-    int k = pvalid ? deaths[p * B + bb] : 1;                    // a seat without a player counts as dead for good
-    const int old_ret = pvalid ? st.ret_sum[p * B + bb] : 0;
-    const uint32_t old_wins = pvalid ? st.win_count[p * B + bb] : 0u;
-    uint32_t tc = gvalid ? st.tcount[bb] : 0u, ts = gvalid ? st.tstep[bb] : 0u;
-    const uint32_t old_n_ep = gvalid ? st.n_episodes[bb] : 0u, old_len_sum = gvalid ? st.len_sum[bb] : 0u;
-    const uint32_t old_last_w = gvalid ? st.last_winners[bb] : 0u;
-    // walls everywhere (each lane a quarter of its game's slab), then the cells
-    for (int off = 4 * p; off < pad.stride; off += 16) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (wide) {
+    // (unconditional, from a clamped index: under `pvalid ? load : 0` every load sits in its own branch with its own wait)
+    const int64_t pb = (int64_t)(p < P ? p : 0) * B + bb;
+    const int h_in = heads[pb];
+    const int d_in = dirs[pb];
+    int k = deaths[pb];
+    const int old_ret = st.ret_sum[pb];
+    const uint32_t old_wins = st.win_count[pb];
+    uint32_t tc = st.tcount[bb], ts = st.tstep[bb];
+    const uint32_t old_n_ep = st.n_episodes[bb], old_len_sum = st.len_sum[bb];
+    const uint32_t old_last_w = st.last_winners[bb];
+    k = pvalid ? k : 1;                                         // a seat without a player counts as dead for good
+    if (rows20) {
+        // the two wall rows and the junk dword of my game (three dwords per lane), then my rows of the wave's boards
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int dw = 3 * p + i;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(mine + (dw < 6 ? 4 * dw : 21 * RS + 4 * (dw - 6))) = 0xffffffffu;
+        }
+        if (p == 0) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + pad.junk) = 0xffffffffu;
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
+            const int R = lane + k2 * CRL_WAVE;
+            const bool have = R < rows_in;                      // rows of games beyond the batch: empty
+            const int e = (int)__umulhi((uint32_t)R, g.inv_n);  // R = 20 e + r
+            const int a = slab0 + e * pad.stride + (R - 20 * e + 1) * RS;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a) = have ? rin4[k2].x : 0u;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a + 4) = have ? rin4[k2].y : 0u;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a + 8) = have ? rin4[k2].z : 0u;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a + 12) = have ? rin4[k2].w : 0u;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a + 16) = have ? rin1[k2] : 0u;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(a + 20) = 0xffffffffu;
+        }
+    } else {
+        // walls everywhere (each lane a quarter of its game's slab), then the cells
+        for (int off = 4 * p; off < pad.stride; off += 16) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (rows20) {
+    } else if (wide) {
 #pragma unroll
         for (int k2 = 0; k2 < kCopyBatch; ++k2) {
             const int off = lane * 16 + k2 * (CRL_WAVE * 16);
@@ -1208,7 +1253,35 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);
     constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);
     int8_t *gslab = board + env0 * NN;
-    if (wide) {
+    if (rows20) {
+        uint32_t c[kRowsPerLane][5], trep[kRowsPerLane];
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {             // all LDS reads in flight, then the arithmetic
+            const int R = lane + k2 * CRL_WAVE;
+            const int e = (int)__umulhi((uint32_t)R, g.inv_n);
+            const int sb = slab0 + e * pad.stride;
+            const int a = sb + (R - 20 * e + 1) * RS;
+            trep[k2] = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) c[k2][q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(a + 4 * q);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
+            const int R = lane + k2 * CRL_WAVE;
+            const uint32_t tr = trep[k2] * 0x01010101u;
+            uint32_t w[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const uint32_t diff = ((c[k2][q] >> OB) & TM) ^ tr;
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                w[q] = c[k2][q] & OM & ~(stale * 0xffu);
+            }
+            if (R < rows_in) {
+                *reinterpret_cast<u32x4_a4 *>(gslab + R * 20) = (u32x4_a4){w[0], w[1], w[2], w[3]};
+                *reinterpret_cast<uint32_t *>(gslab + R * 20 + 16) = w[4];
+            }
+        }
+    } else if (wide) {
         const int bytes = n_env * NN;
 #pragma unroll 7
         for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
@@ -1761,14 +1834,16 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         wall_words[threadIdx.x] = w;
     }
     // my player's state and the running totals: loads in flight while the slabs are laid out
-    const int h_in = pvalid ? heads[p * B + bb] : 0;
-    const int d_in = pvalid ? dirs[p * B + bb] : 0;
-    const int k_in = pvalid ? deaths[p * B + bb] : 1;
-    const int old_ret = pvalid ? st.ret_sum[p * B + bb] : 0;
-    const uint32_t old_wins = pvalid ? st.win_count[p * B + bb] : 0u;
-    const uint32_t tc_in = gvalid ? st.tcount[bb] : 0u, ts_at_entry = gvalid ? st.tstep[bb] : 0u;
-    const uint32_t old_n_ep = gvalid ? st.n_episodes[bb] : 0u, old_len_sum = gvalid ? st.len_sum[bb] : 0u;
-    const uint32_t old_last_w = gvalid ? st.last_winners[bb] : 0u;
+    // (unconditional, from a clamped index: under `pvalid ? load : 0` every load sits in its own branch with its own wait)
+    const int64_t pb = (int64_t)(p < P ? p : 0) * B + bb;
+    const int h_in = heads[pb];
+    const int d_in = dirs[pb];
+    const int k_in = pvalid ? (int)deaths[pb] : 1;
+    const int old_ret = st.ret_sum[pb];
+    const uint32_t old_wins = st.win_count[pb];
+    const uint32_t tc_in = st.tcount[bb], ts_at_entry = st.tstep[bb];
+    const uint32_t old_n_ep = st.n_episodes[bb], old_len_sum = st.len_sum[bb];
+    const uint32_t old_last_w = st.last_winners[bb];
     __syncthreads();
     // my quarter of every 64-byte group of a slab: words 16 g + 4 p .. + 3.  `fresh` is the start layout (walls + start
     // heads), kept in registers for the rewrites.
