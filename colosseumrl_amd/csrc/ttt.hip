@@ -24,25 +24,49 @@ struct ttt_dirs {
     uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
 };
 
-// ND = 4 (boards with at most 4 line directions: everything 1-D / 2-D) or 13 (3-D).  The K-1 shift-and rounds are
-// the outer, wave-uniform loop and the directions the unrolled inner one: strides and start masks are plain SGPR
-// operands, a round is 2 VALU per direction, and no direction needs its own branch (unused slots have start == 0).
+// ND = 4 (boards with at most 4 line directions: everything 1-D / 2-D) or 13 (3-D).  Strides and start masks are plain
+// SGPR operands and no direction needs its own branch (unused slots have start == 0).  A K-window along stride s is
+// built by doubling: t = m & (m >> s) is "two in a row", t & (t >> 2s) four, ... -- for the pinned K = 3 / 4 / 5 that is
+// two or three shift-and pairs per direction (K is wave-uniform: one scalar branch) where the plain K-1 rounds of the
+// generic loop take K-1 pairs plus the copies that seed them.
 template <int ND>
 __device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t m)
 {
-    uint32_t t[ND], run[ND];
-#pragma unroll
-    for (int d = 0; d < ND; ++d) t[d] = run[d] = m;
-    for (int s = 1; s < dd.K; ++s) {
+    uint32_t hit = 0;
+    if (dd.K == 3) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            t[d] >>= dd.stride[d];                  // cell c + s * stride of direction d, seen from c
-            run[d] &= t[d];
+            const int s = dd.stride[d];
+            hit |= m & (m >> s) & (m >> (2 * s)) & dd.start[d];
         }
-    }
-    uint32_t hit = 0;
+    } else if (dd.K == 4) {
 #pragma unroll
-    for (int d = 0; d < ND; ++d) hit |= run[d] & dd.start[d];
+        for (int d = 0; d < ND; ++d) {
+            const int s = dd.stride[d];
+            const uint32_t two = m & (m >> s);
+            hit |= two & (two >> (2 * s)) & dd.start[d];
+        }
+    } else if (dd.K == 5) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int s = dd.stride[d];
+            const uint32_t two = m & (m >> s);
+            hit |= two & (two >> (2 * s)) & (m >> (4 * s)) & dd.start[d];
+        }
+    } else {
+        uint32_t t[ND], run[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) t[d] = run[d] = m;
+        for (int s = 1; s < dd.K; ++s) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                t[d] >>= dd.stride[d];              // cell c + s * stride of direction d, seen from c
+                run[d] &= t[d];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) hit |= run[d] & dd.start[d];
+    }
     return hit != 0;
 }
 
@@ -129,20 +153,14 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
     philox_out rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
-    for (int t = 0; t < T; ++t) {
+    // one ply with random word `word`
+    auto ply = [&](const uint32_t word) {
         uint32_t all = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) all |= o[p];
         const uint32_t empty = dd.full & ~all;
         const int n_empty = __popc(empty);
-        const uint32_t sel = tc & 3u;                  // one Philox call serves 4 steps
-        uint32_t word = rnd.w[0];
-        word = (sel == 1) ? rnd.w[1] : word;
-        word = (sel == 2) ? rnd.w[2] : word;
-        word = (sel == 3) ? rnd.w[3] : word;
         const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
-        tc += 1;
-        if ((tc & 3u) == 0) rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
         int r, term, ws;
         ttt_step_core<P, ND>(dd, o, w, tm, action, r, term, ws);
         ts += 1;
@@ -154,6 +172,30 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             for (int p = 0; p < P; ++p) { wins[p] += (ws == p); o[p] = 0; }
             w = -1; tm = 0; ts = 0;
         }
+    };
+    int t = 0;
+    // One Philox call serves 4 plies.  When every game of the wave enters with its step counter a multiple of four
+    // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
+    // per-ply select chain, one refill test per trip.
+    if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
+        for (; t + 4 <= T; t += 4) {
+            ply(rnd.w[0]);
+            ply(rnd.w[1]);
+            ply(rnd.w[2]);
+            ply(rnd.w[3]);
+            tc += 4;
+            rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        }
+    }
+    for (; t < T; ++t) {
+        const uint32_t sel = tc & 3u;
+        uint32_t word = rnd.w[0];
+        word = (sel == 1) ? rnd.w[1] : word;
+        word = (sel == 2) ? rnd.w[2] : word;
+        word = (sel == 3) ? rnd.w[3] : word;
+        tc += 1;
+        if ((tc & 3u) == 0) rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        ply(word);
     }
     int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
