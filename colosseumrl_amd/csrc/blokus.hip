@@ -236,8 +236,10 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const int 
             F &= ac.x >> s.sh(j);                       // bit x+4: cell j of the shape at origin (x, y) is allowed
             ct[j] = ac.y >> s.shc(j);                   // bit x+4: cell j of the shape at origin (x, y) is an anchor
         }
+        // (v_bcnt_u32_b32 adds its second operand: accumulate in the instruction itself; left to the compiler the five
+        //  counts of a row go through a tree of v_add3)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) cnt += __popc(F & ct[j]);
+        for (int j = 0; j < 5; ++j) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & ct[j]));
         if (ANY_ONLY && __ballot(active && cnt > 0)) break;
     }
     return active ? cnt : 0u;

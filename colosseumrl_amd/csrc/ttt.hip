@@ -99,16 +99,18 @@ __device__ __forceinline__ void ttt_step_core(const ttt_dirs &dd, uint32_t (&o)[
     to_move = (pl + 1 == P) ? 0 : pl + 1;              // :313
 }
 
-// index of the r-th (0-based) set bit of m (row-major np.where order, tictactoe_2p_env.py:345)
-__device__ __forceinline__ int nth_set_bit(uint32_t m, int r)
+// index of the r-th (0-based) set bit of m (row-major np.where order, tictactoe_2p_env.py:345): binary search over
+// bit fields.  Per level: the count below the midpoint (bit-field extract + popcount), the rank moves on by an UNSIGNED
+// min (r - c wraps to a huge value exactly when r < c), the position by a compare.
+__device__ __forceinline__ int nth_set_bit(const uint32_t m, int r)
 {
-    int pos = 0, c;
-    c = __popc(m & 0xffffu); if (r >= c) { r -= c; m >>= 16; pos += 16; }
-    c = __popc(m & 0xffu);   if (r >= c) { r -= c; m >>= 8;  pos += 8; }
-    c = __popc(m & 0xfu);    if (r >= c) { r -= c; m >>= 4;  pos += 4; }
-    c = __popc(m & 0x3u);    if (r >= c) { r -= c; m >>= 2;  pos += 2; }
-    c = (int)(m & 1u);       if (r >= c) { pos += 1; }
-    return pos;
+    uint32_t rr = (uint32_t)r, pos = 0, c;
+    c = (uint32_t)__popc(m & 0xffffu);                              pos = (rr >= c) ? 16u : 0u;          rr = min(rr, rr - c);
+    c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 8u));        pos = (rr >= c) ? pos + 8u : pos;    rr = min(rr, rr - c);
+    c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 4u));        pos = (rr >= c) ? pos + 4u : pos;    rr = min(rr, rr - c);
+    c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 2u));        pos = (rr >= c) ? pos + 2u : pos;    rr = min(rr, rr - c);
+    c = __builtin_amdgcn_ubfe(m, pos, 1u);                          pos = (rr >= c) ? pos + 1u : pos;
+    return (int)pos;
 }
 
 template <int P, int ND>
