@@ -131,10 +131,16 @@ void build_tables(BlkTables &t)
 struct WaveLds {
     uint32_t occ[4][BN];     // board rows per colour, bit x = column x
     uint2 ac[4][32];         // per player, index y+4: {allowed << 8, corner << 8}; rows outside the board are 0
-    uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
+    union {                  // the count / existence passes and the select pass never overlap in time
+        struct {
+            uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
+            uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
+        } sel;
+        uint2 sh[9][28];     // the player being counted: sh[s][r] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell
+    } u;
+    uint2 pad9[28];          // {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh`
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
     uint8_t items[NSHAPE];   // work list of a count / existence pass: piece << 3 | k  (k-th distinct orientation)
-    uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -221,25 +227,41 @@ __device__ __forceinline__ ShapeRegs blk_load_shape(const BlkTables &T, const in
     return s;
 }
 
-// actions contributed by one oriented shape when its origin lies in rows [y0, y1]; any_only: stop at the first hit
+// Rows of player q's allowed / corner masks pre-shifted by every column offset a shape cell can have (dx + 4 = 0..8).
+// A count pass tests ~90 oriented shapes x up to 20 origin rows x 5 cells; with the shifts done here, once per row and
+// offset, a cell test is one 8-byte LDS read and two ANDs instead of a read, two variable shifts and two ANDs.
+__device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const int lane)
+{
+    for (int i = lane; i < 9 * 28; i += 64) {
+        const int sft = i / 28, r = i - sft * 28;
+        const uint2 v = L.ac[q][r];
+        L.u.sh[sft][r] = make_uint2(v.x >> sft, v.y >> sft);
+    }
+    wave_sync();
+}
+
+// actions contributed by one oriented shape when its origin lies in rows [y0, y1]; any_only: stop at the first hit.
+// blk_build_shifted(q) must have run.
 template <bool ANY_ONLY>
-__device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const int q, const ShapeRegs &s, const bool active,
+__device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const ShapeRegs &s, const bool active,
                                                     const int y0, const int y1)
 {
+    // per cell: the table row of origin row 0 (cell j at column offset sh(j), row offset ro(j)); slots beyond the shape's
+    // cells read {all ones, 0}: no constraint on the fit, no anchor
+    const uint2 *cellrow[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) cellrow[j] = (j < s.n) ? &L.u.sh[s.sh(j)][s.ro(j)] : &L.pad9[s.ro(j)];
     uint32_t cnt = 0;
 #pragma nounroll
     for (int y = y0; y <= y1; ++y) {
-        uint32_t F = 0xffffffffu, ct[5];
+        uint2 v[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint2 ac = L.ac[q][y + s.ro(j)];
-            F &= ac.x >> s.sh(j);                       // bit x+4: cell j of the shape at origin (x, y) is allowed
-            ct[j] = ac.y >> s.shc(j);                   // bit x+4: cell j of the shape at origin (x, y) is an anchor
-        }
-        // (v_bcnt_u32_b32 adds its second operand: accumulate in the instruction itself; left to the compiler the five
-        //  counts of a row go through a tree of v_add3)
+        for (int j = 0; j < 5; ++j) v[j] = cellrow[j][y];
+        const uint32_t F = v[0].x & v[1].x & v[2].x & v[3].x & v[4].x;   // bit x+4: the shape fits at origin (x, y)
+        // bit x+4 of v[j].y: cell j of the shape at origin (x, y) is an anchor.  (v_bcnt_u32_b32 adds its second operand:
+        // accumulate in the instruction itself; left to the compiler the five counts go through a tree of v_add3)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & ct[j]));
+        for (int j = 0; j < 5; ++j) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & v[j].y));
         if (ANY_ONLY && __ballot(active && cnt > 0)) break;
     }
     return active ? cnt : 0u;
@@ -279,13 +301,14 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
     if (y1 < y0 || inv == 0) return false;
     if (inv & 1u) return true;                          // the monomino fits on any anchor (anchors are allowed cells)
     const int items = blk_build_items(T, L, inv, lane);
+    blk_build_shifted(L, q, lane);
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
         const bool active = i < items;
         const int it = active ? L.items[i] : 0;
         const int piece = it >> 3;
         const ShapeRegs s = blk_load_shape(T, piece, T.uniq[piece][it & 7] & 7);
-        const uint32_t c = blk_shape_count<true>(L, q, s, active, y0, y1);
+        const uint32_t c = blk_shape_count<true>(L, s, active, y0, y1);
         if (__ballot(c > 0)) return true;
     }
     return false;
@@ -299,6 +322,7 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     if (lane < 32) L.pcnt[lane] = 0;
     if (y1 < y0) { wave_sync(); return 0; }
     const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
+    blk_build_shifted(L, q, lane);
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
         const bool active = i < items;
@@ -306,7 +330,7 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
         const int piece = it >> 3;
         const int om = T.uniq[piece][it & 7];
         const ShapeRegs s = blk_load_shape(T, piece, om & 7);
-        const uint32_t c = blk_shape_count<false>(L, q, s, active, y0, y1) * (uint32_t)(om >> 4);
+        const uint32_t c = blk_shape_count<false>(L, s, active, y0, y1) * (uint32_t)(om >> 4);
         if (c) atomicAdd(&L.pcnt[piece], c);
     }
     wave_sync();
@@ -327,14 +351,19 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const int piece = __builtin_ctzll(hit);
     r -= (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), piece);
     const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
-    // fit masks of the 8 orientations of that piece, all 20 origin rows (rows outside the board stay 0)
+    // fit masks of the 8 orientations of that piece, all 20 origin rows; the rows outside the board are 0 (the table
+    // shares its LDS with the count pass's shifted rows, so they are rewritten every time)
+    for (int i = lane; i < 8 * 12; i += 64) {
+        const int o = i / 12, k = i - o * 12;
+        L.u.sel.fit[o][k < 4 ? k : k + BN] = 0u;         // index 0..3 and 24..31
+    }
     for (int i = lane; i < 8 * BN; i += 64) {
         const int o = i / BN, y = i - o * BN;
         const ShapeRegs s = blk_load_shape(T, piece, o);
         uint32_t F = 0xffffffffu;
 #pragma unroll
         for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
-        L.fit[o][y + 4] = F;                             // bit x+4
+        L.u.sel.fit[o][y + 4] = F;                       // bit x+4
     }
     // level 2: the anchors in row-major order.  Row lanes scatter their set bits into a list ...
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
@@ -346,7 +375,7 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         while (m) {
             const int x = __builtin_ctz(m);
             m &= m - 1;
-            L.alist[pos++] = (uint16_t)((lane << 8) | x);
+            L.u.sel.alist[pos++] = (uint16_t)((lane << 8) | x);
         }
     }
     wave_sync();
@@ -358,11 +387,11 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const int po = pair ? lane / n : 0, pj = pair ? lane - po * n : 0;
     const uint32_t cb = T.cells[piece * 8 + po][pj];
     const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
-    const uint32_t *frow = &L.fit[po][8 - dy4];                  // frow[ay] = fit[po][ay - dy + 4]
+    const uint32_t *frow = &L.u.sel.fit[po][8 - dy4];            // frow[ay] = fit[po][ay - dy + 4]
     const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
     BlkMove mv = {piece, 0, 0, 0, 0};
     for (int a = 0; a < n_anchor; ++a) {
-        const int packed = __builtin_amdgcn_readfirstlane((int)L.alist[a]);
+        const int packed = __builtin_amdgcn_readfirstlane((int)L.u.sel.alist[a]);
         const int ay = packed >> 8, ax = packed & 0xff;
         const unsigned long long legal = __ballot(pair && ((frow[ay] >> (ax + shbase)) & 1u));
         const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
@@ -485,9 +514,9 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
     const int lane = threadIdx.x & 63;                                                            \
     const int wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* wave-uniform: SGPR addressing */ \
     WaveLds &L = Lw[wave_];                                                                       \
-    /* rows -4..-1 and 20..27 of the padded row tables are zero for the whole launch (only 0..19 are rewritten) */ \
+    /* rows -4..-1 and 20..27 of the padded ac[] rows are zero for the whole launch (only 0..19 are rewritten) */     \
     for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);            \
-    for (int i = lane; i < 8 * 32; i += 64) L.fit[i >> 5][i & 31] = 0u;                           \
+    for (int i = lane; i < 28; i += 64) L.pad9[i] = make_uint2(0xffffffffu, 0u);                  \
     const int64_t b = (int64_t)blockIdx.x * 4 + wave_;                                            \
     if (b >= B) return;
 
