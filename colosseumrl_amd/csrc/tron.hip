@@ -1148,34 +1148,49 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         //  correct, LDS operations retire in order and an extra one in flight only makes them conservative)
         uint32_t raw;
         asm volatile("ds_read_u8 %0, %1" : "=v"(raw) : "v"(tq) : "memory");
-        acts >>= 2;
-        neg2 += 2;
-        if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
-            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
-            if ((c & 16u) == 0u) refill(c >> 5);
-            acts = (c & 16u) ? a_hi : a_lo;
-            dry2 += 32u;
-            neg2 = -32;
-        }
         // does anything in this wave need the reference's sequential order?  my target against the other players'
         // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell; every pair is seen from
         // one of its two lanes by the rotations by one and two)
         const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
         const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
-        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw) : : "memory");
-        // both paths end in the same three selects: k = dead ? why : k; d = ran ? dir : d; h = moved ? to : h
-        uint32_t why;
-        int dirE, to;
-        bool dead, ran, moved, alive_now;
+        uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw), "+v"(near) : : "memory");   // (near: the test runs while the probe is out)
+        // The common path, for every lane and without a branch: each player on its own (correct unless players interact).
+        const uint32_t m = min(raw ^ tagbits, raw ^ 0xf8u);
+        const bool dead = run & ((m - 1u) < 7u);                // :47-57
+        const bool moved = run ^ dead;                          // :60-62
+        const int h_was = h;
+        k = dead ? (int)m : k;
+        d8 = run ? dir8 : d8;                                   // :44 the direction is committed even if the move dies
+        h = moved ? tgt : h;
+        // the trail: a head cell already holds its player's stamp (new_state / every earlier move put it there), so a
+        // player that stays where it is restamps its own head and the store needs no condition
+        *(lds_u8 *)(uintptr_t)(uint32_t)h = (uint8_t)stamp;
+        bool alive_now = moved;
+#if defined(CRL_DIAG_NO_SLOW)      /* diagnostic builds only (WRONG results): what the interaction path costs the common one */
+        if (false && near == 0u) {
+#elif defined(CRL_DIAG_DETECT_ONLY) /* ... and with the detection kept but nothing behind it */
+        if (__builtin_amdgcn_ballot_w64(near == 0u) != 0ull) asm volatile("s_nop 0");
+        if (false) {
+#else
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
-            // rare: gather the quad and resolve in the reference's order, redundantly in its four lanes
+#endif
+            // Rare (1.3 % of wave-steps): some quad of the wave needs the reference's order.  A fix-up AFTER the common
+            // path rather than an alternative to it -- as an if / else the join cost every step a dozen scalar
+            // instructions merging lane masks and a copy of the selects (13 % of the kernel's time).  The pre-step state
+            // is rebuilt from what is still in registers: a player that ran stood at tgt - step and had direction
+            // dir - action (acts is shifted only at the end of the step); one that did not run is unchanged.
+            // Cells the common path stamped go back to "empty" first (0 reads as empty under every tag; they were empty:
+            // the player moved there), then the wave gathers every quad's four players and resolves them in order,
+            // redundantly in the quad's four lanes: that rewrites the stamp of every player that really moved.
+            if (moved) *(lds_u8 *)(uintptr_t)(uint32_t)tgt = (uint8_t)0;
             TronRegs<4> s;
             TronProbe<4> pr;
             uint32_t stamp4[4];
-            const int d = (d8 >> 3) & 3, dir = (dir8 >> 3) & 3, kk = run ? 0 : k;
-            s.h[0] = tron_quad<0x00>(h); s.h[1] = tron_quad<0x55>(h); s.h[2] = tron_quad<0xAA>(h); s.h[3] = tron_quad<0xFF>(h);
-            s.d[0] = tron_quad<0x00>(d); s.d[1] = tron_quad<0x55>(d); s.d[2] = tron_quad<0xAA>(d); s.d[3] = tron_quad<0xFF>(d);
+            const int h0 = h_was;
+            const int d0 = (run ? (dir8 - (int)(acts << 3)) >> 3 : d8 >> 3) & 3, dir = (dir8 >> 3) & 3, kk = run ? 0 : k;
+            s.h[0] = tron_quad<0x00>(h0); s.h[1] = tron_quad<0x55>(h0); s.h[2] = tron_quad<0xAA>(h0); s.h[3] = tron_quad<0xFF>(h0);
+            s.d[0] = tron_quad<0x00>(d0); s.d[1] = tron_quad<0x55>(d0); s.d[2] = tron_quad<0xAA>(d0); s.d[3] = tron_quad<0xFF>(d0);
             s.k[0] = tron_quad<0x00>(kk); s.k[1] = tron_quad<0x55>(kk); s.k[2] = tron_quad<0xAA>(kk); s.k[3] = tron_quad<0xFF>(kk);
             pr.tgt[0] = tron_quad<0x00>(tgt); pr.tgt[1] = tron_quad<0x55>(tgt); pr.tgt[2] = tron_quad<0xAA>(tgt); pr.tgt[3] = tron_quad<0xFF>(tgt);
             pr.raw[0] = tron_quad<0x00>((int)raw); pr.raw[1] = tron_quad<0x55>((int)raw); pr.raw[2] = tron_quad<0xAA>((int)raw); pr.raw[3] = tron_quad<0xFF>((int)raw);
@@ -1188,29 +1203,11 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             hS = (p == 1) ? s.h[1] : hS; dS = (p == 1) ? s.d[1] : dS; kS = (p == 1) ? s.k[1] : kS;
             hS = (p == 2) ? s.h[2] : hS; dS = (p == 2) ? s.d[2] : dS; kS = (p == 2) ? s.k[2] : kS;
             hS = (p == 3) ? s.h[3] : hS; dS = (p == 3) ? s.d[3] : dS; kS = (p == 3) ? s.k[3] : kS;
-            to = (p < P) ? hS : junk;
-            dirE = dS << 3;
-            why = (uint32_t)kS;
-            int one = 1;
-            asm volatile("" : "+v"(one));                       // (an opaque `true`: keeps the three selects below the join
-            dead = ran = moved = one != 0;                      //  instead of a copy of them per path and register moves)
+            h = (p < P) ? hS : junk;
+            d8 = dS << 3;
+            k = kS;
             alive_now = kS == 0;
-        } else {
-            const uint32_t m = min(raw ^ tagbits, raw ^ 0xf8u);
-            why = m;
-            dirE = dir8;
-            to = tgt;
-            ran = run;                                          // :44 the direction is committed even if the move dies
-            dead = run & ((m - 1u) < 7u);                       // :47-57
-            moved = run ^ dead;                                 // :60-62
-            alive_now = moved;
         }
-        k = dead ? (int)why : k;
-        d8 = ran ? dirE : d8;
-        h = moved ? to : h;
-        // the trail: a head cell already holds its player's stamp (new_state / every earlier move put it there), so a
-        // player that stays where it is restamps its own head and the store needs no condition
-        *(lds_u8 *)(uintptr_t)(uint32_t)h = (uint8_t)stamp;
         run = alive_now;
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
         int a = run ? 1 : 0;
@@ -1230,10 +1227,20 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             sweep = (sweep == sweep_end) ? sweep_first : sweep;
             *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
             wn += 0x10000u + (uint32_t)a;                       // the winners are whoever is alive at the terminal step
-            // (launch steps done = (dry2 + neg2) / 2: no use of the scalar t, which would turn it into a vector register)
-            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a);
+            // (launch steps done = (dry2 + neg2) / 2 + 1, the countdown moves on below: no use of the scalar t, which
+            //  would turn it into a vector register)
+            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a + 2u);
             h = fresh_h; d8 = fresh_d8;
             run = fresh_run;
+        }
+        acts >>= 2;
+        neg2 += 2;
+        if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
+            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
+            if ((c & 16u) == 0u) refill(c >> 5);
+            acts = (c & 16u) ? a_hi : a_lo;
+            dry2 += 32u;
+            neg2 = -32;
         }
     }
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
@@ -2012,7 +2019,14 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(word) : : "memory");
         int dirE, to, wsel;
         bool ran, moved, alive_now;
+#if defined(CRL_DIAG_NO_SLOW)      /* diagnostic builds only (WRONG results): what the interaction path costs the common one */
+        if (false && near == 0u) {
+#elif defined(CRL_DIAG_DETECT_ONLY) /* ... and with the detection kept but nothing behind it */
+        if (__builtin_amdgcn_ballot_w64(near == 0u) != 0ull) asm volatile("s_nop 0");
+        if (false) {
+#else
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
+#endif
             // rare: the quad's four players in the reference's order, redundantly in its four lanes
             const int d = (d8 >> 3) & 3, dir = (dir8 >> 3) & 3, al = run ? 1 : 0, oc = (word & bit) ? 1 : 0;
             int ps[4] = {tron_quad<0x00>(pos), tron_quad<0x55>(pos), tron_quad<0xAA>(pos), tron_quad<0xFF>(pos)};
