@@ -2004,21 +2004,18 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         if constexpr (GRP < kGroups) store_group(GRP);
         uint32_t bit;                                           // 1 << (tq & 31): the shift reads five bits by itself
         asm("v_lshlrev_b32 %0, %1, 1" : "=v"(bit) : "v"(tq));
-        acts >>= 2;
-        if (!trips || GRP == 3) neg2 += trips ? 8 : 2;
-        if ((!trips || GRP == 3) && neg2 == 0) {
-            const uint32_t c = tc_in + (dry2 >> 1);
-            if ((c & 16u) == 0u) refill(c >> 5);
-            acts = (c & 16u) ? a_hi : a_lo;
-            dry2 += 32u;
-            neg2 = -32;
-        }
         const int x1 = tq ^ tron_quad<0x39>(pos), x2 = tq ^ tron_quad<0x4E>(pos), x3 = tq ^ tron_quad<0x93>(pos);
         const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
-        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(word) : : "memory");
-        int dirE, to, wsel;
-        bool ran, moved, alive_now;
+        uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(word), "+v"(near) : : "memory");
+        // the common path, for every lane and without a branch: each player on its own (see tron_rollout_quad_kernel)
+        const bool dead = run & ((word & bit) != 0u);           // :47-57 trail or wall
+        const bool moved = run ^ dead;                          // :60-62
+        const int pos_was = pos;
+        d8 = run ? dir8 : d8;                                   // :44 the direction is committed even if the move dies
+        pos = moved ? tgt : pos;
+        atomicOr((unsigned int *)(lds + ((moved ? wa : jaddr) - lds0)), bit);
+        bool alive_now = moved;
 #if defined(CRL_DIAG_NO_SLOW)      /* diagnostic builds only (WRONG results): what the interaction path costs the common one */
         if (false && near == 0u) {
 #elif defined(CRL_DIAG_DETECT_ONLY) /* ... and with the detection kept but nothing behind it */
@@ -2027,9 +2024,12 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
 #else
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
 #endif
-            // rare: the quad's four players in the reference's order, redundantly in its four lanes
-            const int d = (d8 >> 3) & 3, dir = (dir8 >> 3) & 3, al = run ? 1 : 0, oc = (word & bit) ? 1 : 0;
-            int ps[4] = {tron_quad<0x00>(pos), tron_quad<0x55>(pos), tron_quad<0xAA>(pos), tron_quad<0xFF>(pos)};
+            // rare fix-up: take back the bits the common path set (those cells were empty), then the quad's four players
+            // in the reference's order from the pre-step state, redundantly in its four lanes
+            if (moved) atomicAnd((unsigned int *)(lds + (wa - lds0)), ~bit);
+            const int d = (run ? (dir8 - (int)(acts << 3)) >> 3 : d8 >> 3) & 3, dir = (dir8 >> 3) & 3;
+            const int al = run ? 1 : 0, oc = (word & bit) ? 1 : 0;
+            int ps[4] = {tron_quad<0x00>(pos_was), tron_quad<0x55>(pos_was), tron_quad<0xAA>(pos_was), tron_quad<0xFF>(pos_was)};
             int ds[4] = {tron_quad<0x00>(d), tron_quad<0x55>(d), tron_quad<0xAA>(d), tron_quad<0xFF>(d)};
             int al4[4] = {tron_quad<0x00>(al), tron_quad<0x55>(al), tron_quad<0xAA>(al), tron_quad<0xFF>(al)};
             const int tg[4] = {tron_quad<0x00>(tgt), tron_quad<0x55>(tgt), tron_quad<0xAA>(tgt), tron_quad<0xFF>(tgt)};
@@ -2058,25 +2058,10 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             pS = (p == 1) ? ps[1] : pS; dS = (p == 1) ? ds[1] : dS; aS = (p == 1) ? al4[1] : aS;
             pS = (p == 2) ? ps[2] : pS; dS = (p == 2) ? ds[2] : dS; aS = (p == 2) ? al4[2] : aS;
             pS = (p == 3) ? ps[3] : pS; dS = (p == 3) ? ds[3] : dS; aS = (p == 3) ? al4[3] : aS;
-            to = pS;
-            dirE = dS << 3;
-            wsel = jaddr;
-            int one = 1;
-            asm volatile("" : "+v"(one));                       // an opaque `true`: keeps the selects below the join
-            ran = moved = one != 0;
+            pos = pS;
+            d8 = dS << 3;
             alive_now = (p < P) && aS != 0;
-        } else {
-            const bool dead = run & ((word & bit) != 0u);       // :47-57 trail or wall
-            dirE = dir8;
-            to = tgt;
-            wsel = wa;
-            ran = run;                                          // :44 the direction is committed even if the move dies
-            moved = run ^ dead;                                 // :60-62
-            alive_now = moved;
         }
-        d8 = ran ? dirE : d8;
-        pos = moved ? to : pos;
-        atomicOr((unsigned int *)(lds + ((moved ? wsel : jaddr) - lds0)), bit);
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
         a = alive_now ? 1 : 0;
         asm volatile("" : "+v"(a));
@@ -2084,8 +2069,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         alive += tron_quad<0x4E>(alive);
         alive_steps += (uint32_t)a;
         if (alive <= 1) {                                       // new_state: swap the slabs
-            // 2 * (launch steps done); inside a trip the countdown is as of the trip's start
-            const uint32_t done2 = dry2 + (uint32_t)neg2 + (uint32_t)((trips && GRP < 3) ? 2 * (GRP + 1) : 0);
+            // 2 * (launch steps done): the countdown moves on below; inside a trip it is as of the trip's start
+            const uint32_t done2 = dry2 + (uint32_t)neg2 + (uint32_t)(trips ? 2 * (GRP + 1) : 2);
             // the spare is completely fresh four steps after it was retired -- or at once, for a shorter episode (rare)
             if (done2 < ok_at2) {
 #pragma unroll
@@ -2099,6 +2084,15 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             pos = cur8 + fresh_off;
             d8 = fresh_d8;
             a = fresh_a;
+        }
+        acts >>= 2;                                             // (after the fix-up, which reads this step's action)
+        if (!trips || GRP == 3) neg2 += trips ? 8 : 2;
+        if ((!trips || GRP == 3) && neg2 == 0) {
+            const uint32_t c = tc_in + (dry2 >> 1);
+            if ((c & 16u) == 0u) refill(c >> 5);
+            acts = (c & 16u) ? a_hi : a_lo;
+            dry2 += 32u;
+            neg2 = -32;
         }
     };
     // four steps per trip, one per group of the spare slab; the odd steps afterwards
