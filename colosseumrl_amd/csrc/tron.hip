@@ -2934,16 +2934,21 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     const bool use_qbits = qbits_ok && !use_quad &&
                            ((flags & CRL_ROLLOUT_QBITS) || (!small && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS))));
     if (use_qbits) {
-        const size_t lds_q = std::max((size_t)64 * bits.stride, (size_t)16 * pad.stride);
+        // four lanes of a game store 64 contiguous bytes per 16-byte rewrite store, which the LDS serves eight lanes (two
+        // games) at a time: a game stride of 16 dwords mod 32 banks keeps the two games on different banks (the
+        // lane-per-game kernel's 4 mod 32 would overlap them)
+        TronBits qb = bits;
+        qb.stride = bits.stride - 16 + 64;
+        const size_t lds_q = std::max((size_t)64 * qb.stride, (size_t)16 * pad.stride);
         constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, see below)
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
             const int tt = std::min(kQuadMaxT, T - t0);
             TRON_DISPATCH_P4(cfg.P, {
                 if (small)
-                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, false>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, bits, B,
+                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, false>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, qb, B,
                                        (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
                 else
-                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, true>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, bits, B,
+                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, true>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, qb, B,
                                        (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
             });
             CRL_LAUNCH_CHECK();
