@@ -1057,7 +1057,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const int fy = (int)__umulhi((uint32_t)(fh < 0 ? 0 : fh), g.inv_n);
     const int fresh_h = (p < P) ? mine + (fy + 1) * RS + (fh - fy * N) : junk;
     const int fresh_d8 = fd << 3;
-    const bool fresh_run = p < P;
+    const int fresh_a = (p < P) ? 1 : 0;
     int h, d8 = (d_in & 3) << 3;                                // directions live pre-scaled (the bit offset into step4),
     {                                                           // bits above 4:3 are garbage
         const int hc = min(max(h_in, 0), NN - 1);
@@ -1134,13 +1134,16 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     uint32_t dry2 = 32u - 2u * (tc & 15u);
     int neg2 = -(int)dry2;
     const uint32_t tc_in = tc;
-    bool run = k == 0;                                          // my player is alive; k only says why it is not
+    // my player is alive (k only says why it is not): carried as a 0 / 1 vector register -- one compare per step makes
+    // the lane mask; carried AS a lane mask it costs ~8 scalar instructions per step to merge around the reset branch
+    int a = (k == 0) ? 1 : 0;
     // Cell decode.  A cell is tag << 3 | owner; walls are 0xff and the tag 31 is never used, so with x = cell ^ tag << 3
     // and w = cell ^ 0xf8 the cell is occupied for THIS episode iff 1 <= min(x, w) <= 7: x is the owner under the
     // current tag (>= 8 under a stale one), w is 7 for a wall (>= 8 for every other cell).  That minimum also is what
     // deaths[] records, except that a wall reads 7 where the reference stores the mover's own id (CyTronGrid.pyx:47-48):
     // translated once, at the end.
     for (int t = 0; t < T; ++t) {
+        const bool run = a != 0;
         const int dir8 = (int)((acts << 3) + (uint32_t)d8);     // bits 4:3: (d + action) & 3 (a bit-field offset reads 5 bits)
         const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir8, 8);
         const int tq = run ? tgt : junk;                        // a dead player probes its own junk byte
@@ -1208,13 +1211,12 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             k = kS;
             alive_now = kS == 0;
         }
-        run = alive_now;
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
-        int a = run ? 1 : 0;
-        asm volatile("" : "+v"(a));                             // a plain 0 / 1 register (not a carry chain): DPP adds below
+        a = alive_now ? 1 : 0;
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
         alive_steps += (uint32_t)a;
+        neg2 += 2;                                              // the action countdown (its refill: end of the step)
         if (alive <= 1) {                                       // (a game beyond the batch is "over" at every step)
             // new_state: bump the tag, rewrite the next row of the rolling clear (boards up to 20x20 with 5 tag bits:
             // crl_tron_rollout checks sweep_rows == 1), stamp the heads
@@ -1227,14 +1229,12 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             sweep = (sweep == sweep_end) ? sweep_first : sweep;
             *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
             wn += 0x10000u + (uint32_t)a;                       // the winners are whoever is alive at the terminal step
-            // (launch steps done = (dry2 + neg2) / 2 + 1, the countdown moves on below: no use of the scalar t, which
-            //  would turn it into a vector register)
-            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a + 2u);
+            // (launch steps done = (dry2 + neg2) / 2: no use of the scalar t, which would turn it into a vector register)
+            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a);
             h = fresh_h; d8 = fresh_d8;
-            run = fresh_run;
+            a = fresh_a;
         }
         acts >>= 2;
-        neg2 += 2;
         if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
             const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
             if ((c & 16u) == 0u) refill(c >> 5);
@@ -1249,7 +1249,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const uint32_t ts_at_entry = ts;
     ts = n_ep ? (uint32_t)(T - done_last) : ts_at_entry + (uint32_t)T;
     const int last_len = (n_ep > 1u) ? done_last - done_prev : (int)ts_at_entry + done_last;
-    k = run ? 0 : (k == 7 ? p + 1 : k);
+    k = a ? 0 : (k == 7 ? p + 1 : k);
     const int d = (d8 >> 3) & 3;
     // ---- epilogue: the junk dword hands this board's tag to its copier, boards LDS -> HBM without tags
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2064,7 +2064,6 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         }
         // TronGridEnvironment.py:309-321 for the game: alive players over the quad
         a = alive_now ? 1 : 0;
-        asm volatile("" : "+v"(a));
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
         alive_steps += (uint32_t)a;
