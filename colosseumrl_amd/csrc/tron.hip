@@ -929,6 +929,53 @@ __device__ __forceinline__ int tron_quad(const int v)          // v of the lane 
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
+// The game's random stream, shared out over a quad of lanes (one lane per player; both lane-per-player kernels).  The
+// contract (include/colosseum_hip.h) gives every step c a code byte -- four 2-bit actions -- from word (c & 7) >> 1 of
+// Philox block c >> 3.  Computed per lane that is a Philox call every 8 steps in each of the four lanes.  Instead lane q
+// computes block 4 (c >> 5) + q once per 32 steps, turns its four words into the block's 8 code bytes (two registers:
+// steps 0-3, 4-7), transposes each register as a 4x4 matrix of 2-bit fields (steps x players -> players x steps: two delta
+// swaps), so that byte p' holds player p''s four actions, and the quad exchanges them with DPP broadcasts: lane p ends up
+// with its player's 32 actions of group `group` = c >> 5 in two registers (steps 0-15 / 16-31 of the group).
+// Every lane of the quad must call this together (the broadcasts read all four lanes).
+__device__ __forceinline__ void tron_quad_actions(const uint32_t gid, const uint32_t group, const int p, const uint32_t seed_lo,
+                                                  const uint32_t seed_hi, const uint8_t *act_lut, uint32_t &a_lo, uint32_t &a_hi)
+{
+    auto transpose2 = [](uint32_t x) -> uint32_t {              // 4x4 transpose of the 2-bit fields of x (bit 8r + 2c)
+        uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
+        x ^= t ^ (t << 6);
+        t = (x ^ (x >> 12)) & 0x0000F0F0u;
+        x ^= t ^ (t << 12);
+        return x;
+    };
+    // (the seed through an opaque copy: the ten rounds' keys are then derived here, every 32 steps, instead of living in
+    //  20 scalar registers across the caller's step loop)
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
+    uint32_t code[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t frac, first;                                   // w * 81 = first : frac (one v_mad_u64_u32)
+        crl_mul_wide<true>(81u, r.w[i], frac, first);
+        code[2 * i] = act_lut[first];
+        code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
+    }
+    const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);   // byte p' = player p', steps 0-3
+    const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);   //                 steps 4-7
+    const uint32_t r01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);   // {lo.b0, hi.b0, lo.b1, hi.b1}: players 0, 1 (16 bits each)
+    const uint32_t r23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);   // {lo.b2, hi.b2, lo.b3, hi.b3}: players 2, 3
+    // (every broadcast runs in all four lanes, THEN the lane picks: a DPP read of a lane that sits out a divergent branch
+    //  returns 0)
+    const int sh = (p & 1) * 16;
+    const int b01[4] = {tron_quad<0x00>((int)r01), tron_quad<0x55>((int)r01), tron_quad<0xAA>((int)r01), tron_quad<0xFF>((int)r01)};
+    const int b23[4] = {tron_quad<0x00>((int)r23), tron_quad<0x55>((int)r23), tron_quad<0xAA>((int)r23), tron_quad<0xFF>((int)r23)};
+    uint32_t s16[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s16[q] = ((uint32_t)(p < 2 ? b01[q] : b23[q]) >> sh) & 0xffffu;
+    a_lo = s16[0] | s16[1] << 16;
+    a_hi = s16[2] | s16[3] << 16;
+}
+
 template <int RS>
 __global__ void __launch_bounds__(256, 4)
 tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
@@ -1084,50 +1131,8 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     if (!gvalid) k = 1;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
-    // The game's random stream, shared out over the quad.  The contract (include/colosseum_hip.h) gives every step c a
-    // code byte -- four 2-bit actions -- from word (c & 7) >> 1 of Philox block c >> 3.  Computed per lane that is a
-    // Philox call (40 quarter-rate multiplies) every 8 steps in each of the four lanes.  Instead lane q computes block
-    // 4 (c >> 5) + q once per 32 steps, turns its four words into the block's 8 code bytes (two registers: steps 0-3,
-    // 4-7), transposes each register as a 4x4 matrix of 2-bit fields (steps x players -> players x steps: two delta
-    // swaps), so that byte p' holds player p''s four actions, and the quad exchanges them with DPP broadcasts: lane p
-    // ends up with its player's 32 actions in two registers; a step takes the low two bits of `acts` and shifts.
     uint32_t a_lo = 0, a_hi = 0;                                // my player's actions of steps 0-15 / 16-31 of the group
-    auto transpose2 = [](uint32_t x) -> uint32_t {              // 4x4 transpose of the 2-bit fields of x (bit 8r + 2c)
-        uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
-        x ^= t ^ (t << 6);
-        t = (x ^ (x >> 12)) & 0x0000F0F0u;
-        x ^= t ^ (t << 12);
-        return x;
-    };
-    auto refill = [&](const uint32_t group) {                   // group = c >> 5
-        // (the seed through an opaque copy: the ten rounds' keys are then derived here, every 32 steps, instead of living
-        //  in 20 scalar registers across the step loop -- which had pushed the loop's lane masks out of SGPRs)
-        uint32_t k0 = seed_lo, k1 = seed_hi;
-        asm volatile("" : "+s"(k0), "+s"(k1));
-        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
-        uint32_t code[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t frac, first;                               // w * 81 = first : frac (one v_mad_u64_u32)
-            crl_mul_wide<true>(81u, r.w[i], frac, first);
-            code[2 * i] = act_lut[first];
-            code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
-        }
-        const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);   // byte p' = player p', steps 0-3
-        const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);   //                 steps 4-7
-        const uint32_t r01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);   // {lo.b0, hi.b0, lo.b1, hi.b1}: players 0, 1 (16 bits each)
-        const uint32_t r23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);   // {lo.b2, hi.b2, lo.b3, hi.b3}: players 2, 3
-        // (every broadcast runs in all four lanes, THEN the lane picks: a DPP read of a lane that sits out a divergent
-        //  branch returns 0)
-        const int sh = (p & 1) * 16;
-        const int b01[4] = {tron_quad<0x00>((int)r01), tron_quad<0x55>((int)r01), tron_quad<0xAA>((int)r01), tron_quad<0xFF>((int)r01)};
-        const int b23[4] = {tron_quad<0x00>((int)r23), tron_quad<0x55>((int)r23), tron_quad<0xAA>((int)r23), tron_quad<0xFF>((int)r23)};
-        uint32_t s16[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s16[q] = ((uint32_t)(p < 2 ? b01[q] : b23[q]) >> sh) & 0xffffu;
-        a_lo = s16[0] | s16[1] << 16;
-        a_hi = s16[2] | s16[3] << 16;
-    };
+    auto refill = [&](const uint32_t group) { tron_quad_actions(gid, group, p, seed_lo, seed_hi, act_lut, a_lo, a_hi); };
     refill(tc >> 5);
     uint32_t acts = ((tc & 16u) ? a_hi : a_lo) >> ((tc & 15u) * 2u);   // bits 1:0 = this step's action code (0, 1, 3)
     // `acts` runs dry after dry2 / 2 steps of this launch; neg2 = 2 (launch steps done) - dry2 counts up to zero
@@ -1944,40 +1949,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
                                                                 // completely fresh once 2 * (steps done) reaches it
     __syncthreads();                                            // action table
     uint32_t a_lo = 0, a_hi = 0;
-    auto transpose2 = [](uint32_t x) -> uint32_t {
-        uint32_t t = (x ^ (x >> 6)) & 0x00CC00CCu;
-        x ^= t ^ (t << 6);
-        t = (x ^ (x >> 12)) & 0x0000F0F0u;
-        x ^= t ^ (t << 12);
-        return x;
-    };
-    auto refill = [&](const uint32_t group) {                   // see tron_rollout_quad_kernel
-        // (the seed through an opaque copy: the ten rounds' keys are then derived here, every 32 steps, instead of living
-        //  in 20 scalar registers across the step loop -- which had pushed the loop's lane masks out of SGPRs)
-        uint32_t k0 = seed_lo, k1 = seed_hi;
-        asm volatile("" : "+s"(k0), "+s"(k1));
-        const philox_out r = philox4x32_10<true>(gid, 4u * group + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
-        uint32_t code[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t frac, first;
-            crl_mul_wide<true>(81u, r.w[i], frac, first);
-            code[2 * i] = act_lut[first];
-            code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
-        }
-        const uint32_t lo = transpose2(code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24);
-        const uint32_t hi = transpose2(code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24);
-        const uint32_t r01 = __builtin_amdgcn_perm(hi, lo, 0x05010400u);
-        const uint32_t r23 = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
-        const int sh = (p & 1) * 16;
-        const int b01[4] = {tron_quad<0x00>((int)r01), tron_quad<0x55>((int)r01), tron_quad<0xAA>((int)r01), tron_quad<0xFF>((int)r01)};
-        const int b23[4] = {tron_quad<0x00>((int)r23), tron_quad<0x55>((int)r23), tron_quad<0xAA>((int)r23), tron_quad<0xFF>((int)r23)};
-        uint32_t s16[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s16[q] = ((uint32_t)(p < 2 ? b01[q] : b23[q]) >> sh) & 0xffffu;
-        a_lo = s16[0] | s16[1] << 16;
-        a_hi = s16[2] | s16[3] << 16;
-    };
+    auto refill = [&](const uint32_t group) { tron_quad_actions(gid, group, p, seed_lo, seed_hi, act_lut, a_lo, a_hi); };
     refill(tc_in >> 5);
     uint32_t acts = ((tc_in & 16u) ? a_hi : a_lo) >> ((tc_in & 15u) * 2u);
     uint32_t dry2 = 32u - 2u * (tc_in & 15u);
