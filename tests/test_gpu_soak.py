@@ -16,7 +16,8 @@ from oracle import oracle as O
                                             (16, 5, 700, 1200, "bytes"), (40, 4, 1000, 900, "bits"), (40, 4, 1000, 900, "bytes"),
                                             (36, 8, 300, 700, "bits"), (36, 8, 300, 700, "bytes"), (40, 4, 512, 600, "global"),
                                             (40, 4, 1000, 900, "qbits"), (30, 3, 1024 + 7, 800, "qbits"), (20, 4, 4096, 1500, "qbits"),
-                                            (6, 2, 512, 3000, "qbits"), (13, 3, 1024 + 9, 1200, "qbits"), (33, 2, 130, 20000, "qbits")])
+                                            (6, 2, 512, 3000, "qbits"), (13, 3, 1024 + 9, 1200, "qbits"), (33, 2, 130, 20000, "qbits"),
+                                            (9, 3, 130, 40001, "quad")])      # (> 16,383 steps: the lane-per-player kernels split the launch)
 def test_tron_long_rollout(N, P, B, T, kernel):
     from colosseumrl_amd.batched import TronBatch
     seed, first = 0x5EED + N, 10 ** 6
