@@ -794,6 +794,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     // the condition is permanent (round 0 is excluded: its single-corner anchor rule is not).  Purely a cache of
     // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
     uint32_t dead = 0;
+    philox_out rnd = {{0u, 0u, 0u, 0u}};
 #ifdef BLK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -807,8 +808,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane);   // len(valid_actions) of the mover
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
-        const philox_out rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
+        // one Philox call serves 4 plies (everything here is wave-uniform: the ten rounds run on the scalar unit, ~100
+        // instructions -- worth keeping the four words across plies)
         const uint32_t sel = tc & 3u;
+        if (sel == 0u || t == 0) rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
         uint32_t word = rnd.w[0];
         word = (sel == 1) ? rnd.w[1] : word;
         word = (sel == 2) ? rnd.w[2] : word;
