@@ -358,6 +358,24 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     wall, gpu = rate(eager, 1000)
     out["tron_n20_step_auto_reset"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
                                        "algorithmic_GBs": (12 * P + 2) * B / gpu / 1e9, "games": B}
+    # the same 16 calls recorded once into a HIP graph and replayed: what a caller that steps in a loop should do about the
+    # launch boundary (the call is launch- / latency-bound: 3.3 MB of traffic)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for k in range(16):
+                    tb.step(acts[k], auto_reset=True)
+        torch.cuda.current_stream().wait_stream(side)
+        wall, gpu = rate(graph.replay, 60)
+        out["tron_n20_step_auto_reset_graph16"] = {"env_steps_per_s": 16 * B / wall, "us_per_call": wall * 1e6 / 16,
+                                                   "gpu_us_per_call": gpu * 1e6 / 16, "games": B,
+                                                   "what": "16 step calls captured in one HIP graph, per call"}
+        del graph
+    except Exception as exc:                                    # never fatal for the bench line
+        out["tron_n20_step_auto_reset_graph16"] = {"error": repr(exc)[:200]}
     buf = tb.observe_all()
     wall, gpu = rate(lambda: tb.observe_all(buf), 500)
     nbytes = (1 + P) * N * N * B
