@@ -1354,6 +1354,174 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     }
 }
 
+// ---- replay of unfinished episodes on byte slabs (epilogue of both bitboard kernels) --------------------------------
+// The bitboard kernels do not know who owns a cell; the state they hand back is rebuilt by replaying each game's unfinished
+// episode with the byte-slab stepper (same tron_resolve_lds, same random stream), from the start layout or -- for a game
+// that was not reset during the launch -- from the state the launch came in with.  The pieces below work on `n_slabs` byte
+// slabs laid out from LDS address lds0 (pad.stride apart), which hold the games [gbase, gbase + n_games).
+
+// (1) fresh boards in every slab: walls, empty cells.  Called by `nthreads` threads (tid = 0 .. nthreads - 1), a multiple of
+// n_slabs; the caller synchronises the workgroup afterwards.
+template <int RS>
+__device__ __forceinline__ void tron_replay_fresh_slabs(const int lds0, const TronPad &pad, const int N, const int n_slabs,
+                                                        const int tid, const int nthreads)
+{
+    const int parts = nthreads / n_slabs, slab = tid % n_slabs;
+    const int base = lds0 + slab * pad.stride, sd = pad.stride >> 2;
+    for (int d = tid / n_slabs; d < sd; d += parts) {
+        const int byte = d * 4;
+        const int row = byte / RS, col = byte - row * RS;
+        const int left = N - col;                               // cells from this dword to the row's end
+        uint32_t v = 0xffffffffu;
+        if (row >= 1 && row <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
+        *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
+    }
+}
+
+// the P start heads of new_state stamped into the slab at `base`
+template <int P, int RS>
+__device__ __forceinline__ void tron_replay_stamp_heads(const crl_tron_cfg &cfg, const TronGeom &g, const int base)
+{
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int sh = cfg.start_heads[q];
+        const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
+        *(lds_u8 *)(uintptr_t)(uint32_t)(base + (sy + 1) * RS + (sh - sy * g.N)) = (uint8_t)(q + 1);
+    }
+}
+
+// (2a) one wave copies the n_games incoming boards at `gslab` into the slabs (for the games that resume from them)
+template <int RS>
+__device__ __forceinline__ void tron_replay_copy_in(const int8_t *__restrict__ gslab, const int n_games, const int lds0,
+                                                    const TronPad &pad, const TronGeom &g, const int lane)
+{
+    const int N = g.N, NN = g.NN;
+    if ((N & 3) == 0 && N >= 8) {
+        const int bytes = n_games * NN;
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            const int cq = (off - e * NN) >> 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
+                *(lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
+            }
+        }
+    } else {
+        for (int e = 0; e < n_games; ++e)
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a lane's own slab back to the start layout (after tron_replay_copy_in overwrote it with an incoming board)
+template <int P, int RS>
+__device__ __forceinline__ void tron_replay_refresh_slab(const crl_tron_cfg &cfg, const TronGeom &g, const int bmine)
+{
+    constexpr int kRowDwords = RS / 4;
+    for (int y = 0; y < g.N; ++y)
+#pragma unroll
+        for (int j = 0; j < kRowDwords; ++j) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w |= (4 * j + k < g.N) ? 0u : (0xffu << (8 * k));
+            *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
+        }
+    tron_replay_stamp_heads<P, RS>(cfg, g, bmine);
+}
+
+// (2b) this lane replays game `bg` (global id gid) on the slab at bmine and writes its heads / dirs / deaths.  Every lane
+// of the wave runs `replay_len` iterations and takes part in the LAST steps_r of them (the games of a wave normally
+// share their step counter, so counting backwards from the end, tc_end, keeps the Philox refills wave-uniform).  A lane
+// without a game (lvalid false) idles along: its stores go to the slab's junk byte.
+template <int P, int RS>
+__device__ __forceinline__ void tron_replay_lane(const crl_tron_cfg &cfg, const TronGeom &g, const TronPad &pad, const int bmine,
+                                                 const uint8_t *act_lut, const bool lvalid, const bool from_start,
+                                                 const int steps_r, const int replay_len, const uint32_t tc_end,
+                                                 const uint32_t gid, const uint32_t seed_lo, const uint32_t seed_hi,
+                                                 const int64_t bg, const int64_t B, int16_t *__restrict__ heads,
+                                                 int8_t *__restrict__ dirs, int8_t *__restrict__ deaths)
+{
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    const int N = g.N, NN = g.NN;
+    const int first_r = replay_len - steps_r;                   // this lane joins at iteration first_r
+    uint32_t c_r = tc_end - (uint32_t)replay_len;
+    const int64_t bbg = lvalid ? bg : 0;
+    TronRegs<P> s;
+    uint32_t stamp[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        int h = cfg.start_heads[q];
+        s.d[q] = cfg.start_dirs[q];
+        s.k[q] = lvalid ? 0 : 1;
+        if (!from_start) {
+            h = lvalid ? min(max((int)heads[q * B + bbg], 0), NN - 1) : 0;
+            s.d[q] = lvalid ? dirs[q * B + bbg] & 3 : 0;
+            s.k[q] = lvalid ? deaths[q * B + bbg] : 1;
+        }
+        const int y = (int)__umulhi((uint32_t)h, g.inv_n);
+        s.h[q] = bmine + (y + 1) * RS + (h - y * N);
+        stamp[q] = (uint32_t)(q + 1);
+    }
+    const int junk = bmine + pad.junk;
+    LdsBoard<(P <= 7) ? 3 : 4> bd{0u};                          // single episode: tag 0, cells hold the plain owner
+    TronRng<P> rr;
+    int act[P];
+    rr.start(gid, c_r, seed_lo, seed_hi);
+    rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
+    for (int t = 0; t < replay_len; ++t) {
+        TronProbe<P> pr;
+        tron_probe_padded<P>(step4, bd, s, act, pr);
+        c_r += 1;
+        rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
+        tron_resolve_lds<P>(bd, s, pr, stamp, junk, lvalid && t >= first_r);
+    }
+    if (lvalid) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int rel = s.h[q] - bmine;
+            const int row = rel / RS;
+            heads[q * B + bg] = (int16_t)((row - 1) * N + (rel - row * RS));
+            dirs[q * B + bg] = (int8_t)s.d[q];
+            deaths[q * B + bg] = (int8_t)s.k[q];
+        }
+    }
+}
+
+// (3) the slabs' boards to HBM (cells are plain owners; walls are never copied), by `nthreads` threads
+template <int RS>
+__device__ __forceinline__ void tron_replay_copy_out(int8_t *__restrict__ gslab, const int n_games, const int lds0,
+                                                     const TronPad &pad, const TronGeom &g, const int tid, const int nthreads)
+{
+    const int N = g.N, NN = g.NN;
+    if ((N & 3) == 0 && N >= 8) {
+        const int bytes = n_games * NN;
+        for (int off = tid * 16; off < bytes; off += nthreads * 16) {
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + o[q]);
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        const int cells = n_games * NN;
+        for (int i = tid; i < cells; i += nthreads) {
+            const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
+            const int c = i - e * NN;
+            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+            gslab[i] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N));
+        }
+    }
+}
+
 // ---- bitboard rollout ---------------------------------------------------------------------------------------
 // For long launches the rollout does not need to know WHO owns a cell while it plays: the owner only decides the
 // value stored in deaths[], and deaths[] / the board bytes of all but the LAST episode of a launch are never
@@ -1621,161 +1789,38 @@ tron_rollout_bits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     for (int p = 0; p < P; ++p) acc.ret[p] = 2 * (int)alive_steps[p] - T + 9 * (int)acc.wins[p];
     if (valid) acc.store(st, B, b);
 
-    // ---- replay of the unfinished episode on byte slabs: rebuilds board / heads / dirs / deaths
+    // ---- replay of the unfinished episode on byte slabs: rebuilds board / heads / dirs / deaths (helpers above)
     const bool from_start = acc.n_ep > 0;                       // else: from the state the launch came in with
     const int steps_r = valid ? (from_start ? (int)acc.ts : T) : 0;
-    // every lane replays the LAST steps_r of the wave's `replay_len` iterations: the games of a wave normally share
-    // their step counter, so counting backwards from the end keeps the RNG position (Philox refills) wave-uniform
     int replay_len = steps_r;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) replay_len = max(replay_len, __shfl_xor(replay_len, off, CRL_WAVE));
-    const int first_r = replay_len - steps_r;                   // this lane joins at iteration first_r
-    uint32_t c_r = acc.tc - (uint32_t)replay_len;
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
     // The LDS holds the byte slabs of all 4 waves (boards up to 20x20) or of one wave at a time (LARGE).  Per turn:
     // the whole workgroup lays out fresh boards, the owning wave(s) replay, the whole workgroup copies the boards out.
     constexpr int kTurns = LARGE ? 4 : 1;
     constexpr int kSlabs = LARGE ? CRL_WAVE : 256;
-    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
     const int slot = LARGE ? lane : (int)threadIdx.x;
     const int bmine = lds0 + slot * pad.stride;
-    const int slab0 = bmine - lane * pad.stride;                // first slab of this wave
-    const int sd = pad.stride >> 2;                             // dwords per slab
     for (int turn = 0; turn < kTurns; ++turn) {
-        // (1) fresh boards in every slab: walls, empty cells, the start heads
-        {
-            const int part = LARGE ? wave : 0, parts = LARGE ? 4 : 1;            // threads per slab
-            const int base = lds0 + (LARGE ? lane : (int)threadIdx.x) * pad.stride;
-            for (int d = part; d < sd; d += parts) {
-                const int byte = d * 4;
-                const int row = byte / RS, col = byte - row * RS;
-                const int left = N - col;                                        // cells from this dword to the row's end
-                uint32_t v = 0xffffffffu;
-                if (row >= 1 && row <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
-                *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
-            }
-        }
+        tron_replay_fresh_slabs<RS>(lds0, pad, N, kSlabs, (int)threadIdx.x, 256);
         __syncthreads();
-        if (LARGE ? wave == 0 : true) {
-            const int base = lds0 + (LARGE ? lane : (int)threadIdx.x) * pad.stride;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const int fh = cfg.start_heads[p];
-                const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
-                *(lds_u8 *)(uintptr_t)(uint32_t)(base + (fy + 1) * RS + (fh - fy * N)) = (uint8_t)(p + 1);
-            }
-        }
+        if ((int)threadIdx.x < kSlabs) tron_replay_stamp_heads<P, RS>(cfg, g, lds0 + (int)threadIdx.x * pad.stride);
         __syncthreads();
-        // (2) the owning wave replays
         if (!LARGE || wave == turn) {
-            constexpr int kRowDwords = RS / 4;
-            if (__builtin_amdgcn_ballot_w64(valid && !from_start)) {        // somebody resumes from the incoming board
-                const int8_t *gslab = board + env0 * NN;
-                if (wide) {
-                    const int bytes = n_env * NN;
-                    for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                        const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                        const int cq = (off - e * NN) >> 2;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                            *(lds_u32 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
-                        }
-                    }
-                } else {
-                    for (int e = 0; e < n_env; ++e)
-                        for (int c = lane; c < NN; c += CRL_WAVE) {
-                            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                            *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
-                        }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (from_start) {                               // this lane's slab was overwritten too: fresh again
-                    for (int y = 0; y < N; ++y)
-#pragma unroll
-                        for (int j = 0; j < kRowDwords; ++j) {
-                            uint32_t w = 0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
-                            *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
-                        }
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const int fh = cfg.start_heads[p];
-                        const int fy = (int)__umulhi((uint32_t)fh, g.inv_n);
-                        *(lds_u8 *)(uintptr_t)(uint32_t)(bmine + (fy + 1) * RS + (fh - fy * N)) = (uint8_t)(p + 1);
-                    }
-                }
+            if (__builtin_amdgcn_ballot_w64(valid && !from_start)) {            // somebody resumes from the incoming board
+                tron_replay_copy_in<RS>(board + env0 * NN, n_env, bmine - lane * pad.stride, pad, g, lane);
+                if (from_start) tron_replay_refresh_slab<P, RS>(cfg, g, bmine);  // this lane's slab was overwritten too
             }
-            TronRegs<P> s;
-            uint32_t stamp[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                int h = cfg.start_heads[p];
-                s.d[p] = cfg.start_dirs[p];
-                s.k[p] = 0;
-                if (!from_start) {
-                    h = valid ? min(max((int)heads[p * B + bb], 0), NN - 1) : 0;
-                    s.d[p] = valid ? dirs[p * B + bb] & 3 : 0;
-                    s.k[p] = valid ? deaths[p * B + bb] : 1;
-                }
-                const int y = (int)__umulhi((uint32_t)h, g.inv_n);
-                s.h[p] = bmine + (y + 1) * RS + (h - y * N);
-                stamp[p] = (uint32_t)(p + 1);
-            }
-            const int junk = bmine + pad.junk;
-            LdsBoard<(P <= 7) ? 3 : 4> bd{0u};                  // single episode: tag 0, cells hold the plain owner
-            TronRng<P> rr;
-            rr.start(gid, c_r, seed_lo, seed_hi);
-            rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
-            for (int t = 0; t < replay_len; ++t) {
-                TronProbe<P> pr;
-                tron_probe_padded<P>(step4, bd, s, act, pr);
-                c_r += 1;
-                rr.next_lut(gid, c_r, seed_lo, seed_hi, act_lut, act);
-                tron_resolve_lds<P>(bd, s, pr, stamp, junk, t >= first_r);
-            }
-            if (valid) {
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int rel = s.h[p] - bmine;
-                    const int row = rel / RS;
-                    heads[p * B + b] = (int16_t)((row - 1) * N + (rel - row * RS));
-                    dirs[p * B + b] = (int8_t)s.d[p];
-                    deaths[p * B + b] = (int8_t)s.k[p];
-                }
-            }
+            tron_replay_lane<P, RS>(cfg, g, pad, bmine, act_lut, valid, from_start, steps_r, replay_len, acc.tc, gid,
+                                    seed_lo, seed_hi, b, B, heads, dirs, deaths);
         }
         __syncthreads();
-        // (3) copy out: cells are plain owners (walls are never copied)
         {
             const int64_t gbase = (int64_t)blockIdx.x * blockDim.x + (LARGE ? turn * CRL_WAVE : 0);
             const int64_t rem = B - gbase;
             const int n_out = (int)(rem < 0 ? 0 : (rem > kSlabs ? kSlabs : rem));
-            int8_t *gslab = board + gbase * NN;
-            if (wide) {
-                const int bytes = n_out * NN;
-                for (int off = (int)threadIdx.x * 16; off < bytes; off += 256 * 16) {
-                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                    int o[4];
-                    tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
-                    uint32_t w[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + o[q]);
-                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            } else {
-                const int cells = n_out * NN;
-                for (int i = (int)threadIdx.x; i < cells; i += 256) {
-                    const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
-                    const int c = i - e * NN;
-                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                    gslab[i] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N));
-                }
-            }
+            tron_replay_copy_out<RS>(board + gbase * NN, n_out, lds0, pad, g, (int)threadIdx.x, 256);
         }
         if (LARGE) __syncthreads();
     }
@@ -2112,158 +2157,36 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     }
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
 
-    // ---- replay of the unfinished episodes on byte slabs: rebuilds board / heads / dirs / deaths.  Four turns of 16
-    // games: the workgroup lays out fresh boards, wave `turn` replays with a lane per game, the workgroup copies out.
-    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
-    constexpr int kRowDwords = RS / 4;
-    const int sd = pad.stride >> 2;                             // dwords per byte slab
+    // ---- replay of the unfinished episodes on byte slabs: rebuilds board / heads / dirs / deaths (helpers above).  Four
+    // turns of 16 games: the workgroup lays out fresh boards, wave `turn` replays with a lane per game, the workgroup
+    // copies out.
     for (int turn = 0; turn < kGames / kWaveGames; ++turn) {
-        {   // (1) fresh boards in the 16 slabs (16 threads each): walls, empty cells; then the start heads
-            const int base = lds0 + (int)(threadIdx.x >> 4) * pad.stride;
-            for (int d = (int)(threadIdx.x & 15); d < sd; d += 16) {
-                const int byte = d * 4;
-                const int rw = byte / RS, col = byte - rw * RS;
-                const int left = N - col;                       // cells from this dword to the row's end
-                uint32_t v = 0xffffffffu;
-                if (rw >= 1 && rw <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
-                *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
-            }
-        }
+        tron_replay_fresh_slabs<RS>(lds0, pad, N, kWaveGames, (int)threadIdx.x, 256);
         __syncthreads();
-        if (threadIdx.x < kWaveGames) {
-            const int base = lds0 + (int)threadIdx.x * pad.stride;
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const int sh = cfg.start_heads[q];
-                const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
-                *(lds_u8 *)(uintptr_t)(uint32_t)(base + (sy + 1) * RS + (sh - sy * N)) = (uint8_t)(q + 1);
-            }
-        }
+        if ((int)threadIdx.x < kWaveGames) tron_replay_stamp_heads<P, RS>(cfg, g, lds0 + (int)threadIdx.x * pad.stride);
         __syncthreads();
         const int64_t gbase = (int64_t)blockIdx.x * kGames + turn * kWaveGames;     // first game of this turn
         const int n_turn = (int)((B - gbase) < kWaveGames ? (B - gbase > 0 ? B - gbase : 0) : kWaveGames);
-        if (wave == turn) {                                     // (2) a lane per game; lanes 16.. idle along
+        if (wave == turn) {                                     // a lane per game; lanes 16.. idle along on slabs 0..15
             const int gl = lane & (kWaveGames - 1);
             const bool lvalid = lane < n_turn;                  // (n_turn <= 16)
-            const int64_t bg = gbase + gl, bbg = lvalid ? bg : 0;
             const int rsteps = lvalid ? r_steps[turn * kWaveGames + gl] : 0;
             const bool from_start = rsteps >= 0;                // else: from the state the launch came in with
             const int steps_r = lvalid ? (from_start ? rsteps : T) : 0;
-            const uint32_t tc_end = r_tc[turn * kWaveGames + gl];
-            const uint32_t gidr = (uint32_t)(first_env_id + (uint64_t)bbg);
-            // every lane replays the LAST steps_r of the wave's `replay_len` iterations (see tron_rollout_bits_kernel)
             int replay_len = steps_r;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) replay_len = max(replay_len, __shfl_xor(replay_len, off, CRL_WAVE));
-            const int first_r = replay_len - steps_r;
-            uint32_t c_r = tc_end - (uint32_t)replay_len;
             const int bmine = lds0 + gl * pad.stride;
             if (__builtin_amdgcn_ballot_w64(lvalid && !from_start)) {            // somebody resumes from the incoming board
-                const int8_t *gslab = board + gbase * NN;
-                if (wide) {
-                    const int bytes = n_turn * NN;
-                    for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
-                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                        const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                        const int cq = (off - e * NN) >> 2;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int y = (int)__umulhi((uint32_t)(cq + q), pad.inv_nq);
-                            *(lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + 4 * (cq + q - y * (N >> 2))) = w[q];
-                        }
-                    }
-                } else {
-                    for (int e = 0; e < n_turn; ++e)
-                        for (int c = lane; c < NN; c += CRL_WAVE) {
-                            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                            *(lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
-                        }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lvalid && from_start) {                     // this lane's slab was overwritten too: fresh again
-                    for (int y = 0; y < N; ++y)
-#pragma unroll
-                        for (int j = 0; j < kRowDwords; ++j) {
-                            uint32_t w = 0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) w |= (4 * j + k < N) ? 0u : (0xffu << (8 * k));
-                            *(lds_u32 *)(uintptr_t)(uint32_t)(bmine + (y + 1) * RS + 4 * j) = w;
-                        }
-#pragma unroll
-                    for (int q = 0; q < P; ++q) {
-                        const int sh = cfg.start_heads[q];
-                        const int sy = (int)__umulhi((uint32_t)sh, g.inv_n);
-                        *(lds_u8 *)(uintptr_t)(uint32_t)(bmine + (sy + 1) * RS + (sh - sy * N)) = (uint8_t)(q + 1);
-                    }
-                }
+                tron_replay_copy_in<RS>(board + gbase * NN, n_turn, lds0, pad, g, lane);
+                if (lvalid && from_start) tron_replay_refresh_slab<P, RS>(cfg, g, bmine);
             }
-            TronRegs<P> s;
-            uint32_t stamp[P];
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                int h = cfg.start_heads[q];
-                s.d[q] = cfg.start_dirs[q];
-                s.k[q] = lvalid ? 0 : 1;
-                if (!from_start) {
-                    h = lvalid ? min(max((int)heads[q * B + bbg], 0), NN - 1) : 0;
-                    s.d[q] = lvalid ? dirs[q * B + bbg] & 3 : 0;
-                    s.k[q] = lvalid ? deaths[q * B + bbg] : 1;
-                }
-                const int y = (int)__umulhi((uint32_t)h, g.inv_n);
-                s.h[q] = bmine + (y + 1) * RS + (h - y * N);
-                stamp[q] = (uint32_t)(q + 1);
-            }
-            // (lanes 16.. share the slabs of lanes 0..15 but never run: their stores go to that slab's junk byte)
-            const int junk = bmine + pad.junk;
-            LdsBoard<3> bd{0u};                                 // single episode: tag 0, cells hold the plain owner
-            TronRng<P> rr;
-            int act[P];
-            rr.start(gidr, c_r, seed_lo, seed_hi);
-            rr.next_lut(gidr, c_r, seed_lo, seed_hi, act_lut, act);
-            for (int t = 0; t < replay_len; ++t) {
-                TronProbe<P> pr;
-                tron_probe_padded<P>(step4, bd, s, act, pr);
-                c_r += 1;
-                rr.next_lut(gidr, c_r, seed_lo, seed_hi, act_lut, act);
-                tron_resolve_lds<P>(bd, s, pr, stamp, junk, lvalid && t >= first_r);
-            }
-            if (lvalid) {
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    const int rel = s.h[q] - bmine;
-                    const int rw = rel / RS;
-                    heads[q * B + bg] = (int16_t)((rw - 1) * N + (rel - rw * RS));
-                    dirs[q * B + bg] = (int8_t)s.d[q];
-                    deaths[q * B + bg] = (int8_t)s.k[q];
-                }
-            }
+            tron_replay_lane<P, RS>(cfg, g, pad, bmine, act_lut, lvalid, from_start, steps_r, replay_len,
+                                    r_tc[turn * kWaveGames + gl], (uint32_t)(first_env_id + (uint64_t)(lvalid ? gbase + gl : 0)),
+                                    seed_lo, seed_hi, gbase + gl, B, heads, dirs, deaths);
         }
         __syncthreads();
-        {   // (3) copy out: cells are plain owners (walls are never copied)
-            int8_t *gslab = board + gbase * NN;
-            if (wide) {
-                const int bytes = n_turn * NN;
-                for (int off = (int)threadIdx.x * 16; off < bytes; off += 256 * 16) {
-                    const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-                    int o[4];
-                    tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
-                    uint32_t w[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + o[q]);
-                    *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            } else {
-                const int cells = n_turn * NN;
-                for (int i = (int)threadIdx.x; i < cells; i += 256) {
-                    const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
-                    const int c = i - e * NN;
-                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                    gslab[i] = (int8_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N));
-                }
-            }
-        }
+        tron_replay_copy_out<RS>(board + gbase * NN, n_turn, lds0, pad, g, (int)threadIdx.x, 256);
         __syncthreads();
     }
 }
