@@ -727,7 +727,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     // wave per SIMD hides HBM latency only through its own loads in flight, so the first kCopyBatch loads (all 25 of a
     // 20x20 launch) are issued BEFORE the wall fill and scattered after it; short launches are dominated by this copy.
     constexpr int kCopyBatch = 26;
-    const int8_t *gslab_in = board + env0 * NN;
+    const int8_t *gslab_in = board + (n_env > 0 ? env0 : 0) * NN;   // (a wave wholly beyond the batch still issues its loads: from game 0)
     const int slab0_in = mine - lane * pad.stride;
     const int bytes_in = n_env * NN;
     uint4 cin[kCopyBatch];
@@ -1008,7 +1008,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const bool wide = (N & 3) == 0 && N >= 8;
     // ---- prologue: every global load in flight together (the wave's boards, my player's state, the running totals)
     constexpr int kCopyBatch = 7;                               // 16 boards of <= 400 bytes = <= 6.25 KiB per wave
-    const int8_t *gslab_in = board + env0 * NN;
+    const int8_t *gslab_in = board + (n_env > 0 ? env0 : 0) * NN;   // (a wave wholly beyond the batch still issues its loads: from game 0)
     const int bytes_in = n_env * NN;
     // 20x20 boards (the headline shape) move by ROWS: a row is 20 bytes = five dwords in HBM and six in the slab (its four
     // wall bytes included), so a lane takes rows lane, lane + 64, ... of the wave's 320: a 16-byte + a 4-byte load each

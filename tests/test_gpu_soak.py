@@ -34,6 +34,36 @@ def test_tron_long_rollout(N, P, B, T, kernel):
     assert int(ost.n_episodes.min()) > 32          # every game wrapped its 5-bit episode tag at least once
 
 
+def test_tron_random_configurations_all_kernels():
+    """Randomised differential run (tools/debug/tron_fuzz.py with a fixed seed, 150 configurations): board sizes 4..40,
+    2..8 players, ragged batches whose last workgroup has waves wholly beyond the batch (a 3,000-configuration run of this
+    found an out-of-bounds read there), split launches, launches longer than the lane-per-player kernels' step limit --
+    every rollout kernel against the oracle, bit for bit."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    rng = np.random.default_rng(424242)
+    for case in range(150):
+        N, P, B = int(rng.integers(4, 41)), int(rng.integers(2, 9)), int(rng.integers(1, 3000))
+        P = min(P, 4) if N == 4 else P                  # (a 4x4 board's start ring holds at most 4 players)
+        chunks = [int(rng.integers(1, 700)) for _ in range(int(rng.integers(1, 4)))]
+        if rng.random() < 0.1:
+            chunks.append(int(rng.integers(16384, 18000)))
+            B = min(B, 200)
+        seed, first = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+        sh, sd = O.tron_start_positions(N, P)
+        ost = O.TronState(N, P, B)
+        O.tron_reset(ost, sh, sd)
+        for T in chunks:
+            O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=16)
+        for kernel in ("auto", "quad", "qbits", "bytes", "bits", "global"):
+            tb = TronBatch(N, P, B, first_env_id=first)
+            for T in chunks:
+                tb.rollout(T, seed, kernel=kernel)
+            for k in ("board", "heads", "dirs", "deaths", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len"):
+                want = getattr(ost, k)
+                assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), (case, N, P, B, chunks, kernel, k)
+
+
 def test_blokus_long_rollout():
     from colosseumrl_amd.batched import BlokusBatch
     B, T, seed, first = 768, 160, 20240, 5000
