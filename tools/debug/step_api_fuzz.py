@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised twin run of the per-step API (soak aid): the fused step_observe calls against their unfused equivalents and,
+through the rollout equivalence (sample + step T times == rollout(T)), against the rollout kernels, on random shapes and
+ragged batches.  usage: step_api_fuzz.py [n_cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from colosseumrl_amd.batched import TronBatch, TTTBatch
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad, t0 = 0, time.time()
+for case in range(n_cases):
+    N, P, B = int(rng.integers(4, 41)), int(rng.integers(2, 9)), int(rng.integers(1, 2500))
+    P = min(P, 4) if N == 4 else P
+    T, seed, first = int(rng.integers(1, 40)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+    a, b, c = (TronBatch(N, P, B, first_env_id=first) for _ in range(3))
+    for t in range(T):
+        fusable = (N * N) % 16 == 0 and P < 8            # else the library takes three launches and wants explicit actions
+        oa = a.step_observe(None if fusable else a.sample(seed), seed=seed)
+        b.step(b.sample(seed), auto_reset=True)
+        ob = b.observe_all()
+        for k in ("board", "heads", "directions", "deaths"):
+            if not torch.equal(oa[k], ob[k]):
+                bad += 1
+                print("TRON step_observe MISMATCH case %d N=%d P=%d B=%d t=%d field=%s" % (case, N, P, B, t, k), flush=True)
+                break
+    c.rollout(T, seed)
+    for k in ("board", "heads", "dirs", "deaths", "tcount"):
+        if not (torch.equal(getattr(a, k), getattr(c, k)) and torch.equal(getattr(b, k), getattr(c, k))):
+            bad += 1
+            print("TRON step-vs-rollout MISMATCH case %d N=%d P=%d B=%d T=%d field=%s" % (case, N, P, B, T, k), flush=True)
+            break
+    # TicTacToe
+    nd = int(rng.integers(1, 4))
+    while True:
+        dims = tuple(int(rng.integers(1, 9)) for _ in range(nd))
+        if 1 <= int(np.prod(dims)) <= 32:
+            break
+    K, Pt, Bt = int(rng.integers(1, 7)), int(rng.integers(2, 9)), int(rng.integers(1, 4000))
+    try:
+        x, y, z = (TTTBatch(dims, K, Pt, Bt, first_env_id=first) for _ in range(3))
+    except Exception:
+        continue
+    for t in range(T):
+        ox = x.step_observe(None, seed=seed)
+        y.step(y.sample(seed), auto_reset=True)
+        vb, bb = y.valid_mask(), y.board(y.to_move, Pt)
+        if not (torch.equal(ox["valid"], vb) and torch.equal(ox["board"], bb)):
+            bad += 1
+            print("TTT step_observe MISMATCH case %d dims=%s K=%d P=%d B=%d t=%d" % (case, dims, K, Pt, Bt, t), flush=True)
+            break
+    z.rollout(T, seed)
+    for k in ("occ", "winner", "to_move", "tcount"):
+        if not (torch.equal(getattr(x, k), getattr(z, k)) and torch.equal(getattr(y, k), getattr(z, k))):
+            bad += 1
+            print("TTT step-vs-rollout MISMATCH case %d dims=%s K=%d P=%d B=%d T=%d field=%s" % (case, dims, K, Pt, Bt, T, k), flush=True)
+            break
+    if case % 20 == 19:
+        print("case %d done, %.0f s, mismatches %d" % (case + 1, time.time() - t0, bad), flush=True)
+print("fuzz: %d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
