@@ -323,15 +323,26 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     if (y1 < y0) { wave_sync(); return 0; }
     const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
     blk_build_shifted(L, q, lane);
-    for (int base = 0; base < items; base += 64) {
-        const int i = base + lane;
+    // 64 lanes per batch of shapes.  A batch with at most 32 (16) shapes left gives each shape two (four) lanes, each with
+    // its share of the origin rows -- the counts meet in pcnt[] anyway: the second batch of an early-game inventory (91
+    // shapes: 64 + 27) and the only batch of a late one then take half or a quarter of the row loop.
+    const int n_rows = y1 - y0 + 1;
+    for (int base = 0; base < items; ) {
+        const int left = items - base;
+        const int split_log = left <= 16 ? 2 : (left <= 32 ? 1 : 0);         // wave-uniform
+        const int i = base + (lane >> split_log), part = lane & ((1 << split_log) - 1);
+        const int share = (n_rows + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up
+        const int ya = y0 + part * share, yb = min(ya + share - 1, y1);
         const bool active = i < items;
         const int it = active ? L.items[i] : 0;
         const int piece = it >> 3;
         const int om = T.uniq[piece][it & 7];
         const ShapeRegs s = blk_load_shape(T, piece, om & 7);
-        const uint32_t c = blk_shape_count<false>(L, s, active, y0, y1) * (uint32_t)(om >> 4);
+        // (a full batch keeps the wave-uniform row range: scalar loop control, rows read in pairs)
+        const uint32_t c = (split_log == 0 ? blk_shape_count<false>(L, s, active, y0, y1)
+                                           : blk_shape_count<false>(L, s, active, ya, yb)) * (uint32_t)(om >> 4);
         if (c) atomicAdd(&L.pcnt[piece], c);
+        base += 64 >> split_log;
     }
     wave_sync();
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
