@@ -401,6 +401,17 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const uint32_t *frow = &L.u.sel.fit[po][8 - dy4];            // frow[ay] = fit[po][ay - dy + 4]
     const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
     BlkMove mv = {piece, 0, 0, 0, 0};
+#ifdef BLK_DIAG_FULLWALK     /* diagnostic builds only: one extra walk over ALL anchors, to price the walk (tools/sessions) */
+    {
+        uint32_t dummy = 0;
+        for (int a = 0; a < n_anchor; ++a) {
+            const int packed = __builtin_amdgcn_readfirstlane((int)L.u.sel.alist[a]);
+            const int ay = packed >> 8, ax = packed & 0xff;
+            dummy += (uint32_t)__builtin_popcountll(__ballot(pair && ((frow[ay] >> (ax + shbase)) & 1u)));
+        }
+        if (dummy == 0xffffffffu) mv.x = 1;
+    }
+#endif
     for (int a = 0; a < n_anchor; ++a) {
         const int packed = __builtin_amdgcn_readfirstlane((int)L.u.sel.alist[a]);
         const int ay = packed >> 8, ax = packed & 0xff;
