@@ -516,6 +516,16 @@ def main():
     # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
+    # Device warm-up, before W and K and on a SCRATCH stepper (other memory, other games): ~30 ms of the same kind of
+    # launches, so that a 45-us timed region on a box that has just been handed over is not measured at idle clocks
+    # (first run on a fresh box: 62 us, every later one 41-45 us).  Not part of the W warm-up steps or the K timed steps.
+    t_dev = time.perf_counter()
+    scratch = make_stepper(game, kw, min(batch, 65536), device, 0)
+    while time.perf_counter() - t_dev < 0.03:
+        scratch.rollout(min(default_chunk, 2048), args.seed)
+        torch.cuda.synchronize()
+    del scratch
+    device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
     if args.warmup > 0:
         timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events, dst)
     else:
@@ -544,6 +554,7 @@ def main():
                        "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
                        "gather": "rccl gather to rank 0 (torch.distributed.gather)" if use_dist else "none (single process, no process group)"},
             "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
+            "device_warmup_ms": round(device_warmup_ms, 1),
             "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),
         }
         if not equal:

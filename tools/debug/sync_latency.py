@@ -32,3 +32,20 @@ for _ in range(200):
     ts.append(time.perf_counter() - t0)
 ts.sort()
 print("flag %d: with two event records: median %.1f us, min %.1f us; events say %.1f us" % (flag, ts[100] * 1e6, ts[0] * 1e6, e0.elapsed_time(e1) * 1e3))
+# the same launch replayed from a one-node HIP graph
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+g = torch.cuda.CUDAGraph()
+with torch.cuda.stream(side):
+    with torch.cuda.graph(g, stream=side):
+        tb.rollout(20, 0)
+torch.cuda.current_stream().wait_stream(side)
+ts = []
+for _ in range(200):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+ts.sort()
+print("flag %d: graph replay + sync median %.1f us, min %.1f us" % (flag, ts[100] * 1e6, ts[0] * 1e6))
