@@ -1233,9 +1233,12 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             sweep += RS;
             sweep = (sweep == sweep_end) ? sweep_first : sweep;
             *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;    // seats without a player: their junk byte
-            wn += 0x10000u + (uint32_t)a;                       // the winners are whoever is alive at the terminal step
-            // (launch steps done = (dry2 + neg2) / 2: no use of the scalar t, which would turn it into a vector register)
-            marks = ((marks << 16) + dry2) + ((uint32_t)neg2 + (uint32_t)a);
+            // episodes + 1, my wins + a (the winners are whoever is alive at the terminal step), and the reset's step count
+            // pushed into `marks` (launch steps done = (dry2 + neg2) / 2: no use of the scalar t, which would turn it into a
+            // vector register).  As inline asm: the compiler folds `0x10000 + a` into a select of two constants plus an
+            // add, and the shift-add pair into three instructions.
+            asm("v_add3_u32 %0, %0, %1, %2" : "+v"(wn) : "v"(a), "s"(0x10000u));
+            asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add3_u32 %0, %0, %2, %3" : "+v"(marks) : "v"(dry2), "v"(neg2), "v"(a));
             h = fresh_h; d8 = fresh_d8;
             a = fresh_a;
         }
@@ -2095,8 +2098,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             ok_at2 = done2 + 8u;
             cur8 ^= flip8;
             spare_p = both_p - spare_p;
-            wn += 0x10000u + (uint32_t)a;
-            marks = ((marks << 16) + done2) + (uint32_t)a;
+            asm("v_add3_u32 %0, %0, %1, %2" : "+v"(wn) : "v"(a), "s"(0x10000u));       // (see tron_rollout_quad_kernel)
+            asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add_u32 %0, %0, %2" : "+v"(marks) : "v"(done2), "v"(a));
             pos = cur8 + fresh_off;
             d8 = fresh_d8;
             a = fresh_a;
