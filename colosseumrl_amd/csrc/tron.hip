@@ -1147,7 +1147,14 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     // current tag (>= 8 under a stale one), w is 7 for a wall (>= 8 for every other cell).  That minimum also is what
     // deaths[] records, except that a wall reads 7 where the reference stores the mover's own id (CyTronGrid.pyx:47-48):
     // translated once, at the end.
-    for (int t = 0; t < T; ++t) {
+    // The action countdown: per lane in general (games may enter with different step counters); when the whole wave
+    // shares one (the usual case: the games of a batch are rolled out together) it is a scalar -- add, compare and branch
+    // on the scalar unit instead of two vector instructions and an exec-masked branch per step.
+    const bool uni_wave = __builtin_amdgcn_ballot_w64(tc != (uint32_t)__builtin_amdgcn_readfirstlane((int)tc)) == 0ull;
+    int sneg2 = __builtin_amdgcn_readfirstlane(neg2);
+    uint32_t sdry2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dry2);
+    auto one_step = [&](auto uni_tag) {
+        constexpr bool UNI = decltype(uni_tag)::value;
         const bool run = a != 0;
         const int dir8 = (int)((acts << 3) + (uint32_t)d8);     // bits 4:3: (d + action) & 3 (a bit-field offset reads 5 bits)
         const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir8, 8);
@@ -1221,7 +1228,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         int alive = a + tron_quad<0xB1>(a);
         alive += tron_quad<0x4E>(alive);
         alive_steps += (uint32_t)a;
-        neg2 += 2;                                              // the action countdown (its refill: end of the step)
+        if constexpr (UNI) sneg2 += 2; else neg2 += 2;          // the action countdown (its refill: end of the step)
         if (alive <= 1) {                                       // (a game beyond the batch is "over" at every step)
             // new_state: bump the tag, rewrite the next row of the rolling clear (boards up to 20x20 with 5 tag bits:
             // crl_tron_rollout checks sweep_rows == 1), stamp the heads
@@ -1238,18 +1245,38 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             // vector register).  As inline asm: the compiler folds `0x10000 + a` into a select of two constants plus an
             // add, and the shift-add pair into three instructions.
             asm("v_add3_u32 %0, %0, %1, %2" : "+v"(wn) : "v"(a), "s"(0x10000u));
-            asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add3_u32 %0, %0, %2, %3" : "+v"(marks) : "v"(dry2), "v"(neg2), "v"(a));
+            if constexpr (UNI) {
+                const uint32_t sdone2 = sdry2 + (uint32_t)sneg2;
+                asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add_u32 %0, %0, %2" : "+v"(marks) : "s"(sdone2), "v"(a));
+            } else {
+                asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add3_u32 %0, %0, %2, %3" : "+v"(marks) : "v"(dry2), "v"(neg2), "v"(a));
+            }
             h = fresh_h; d8 = fresh_d8;
             a = fresh_a;
         }
         acts >>= 2;
-        if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
-            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
-            if ((c & 16u) == 0u) refill(c >> 5);
-            acts = (c & 16u) ? a_hi : a_lo;
-            dry2 += 32u;
-            neg2 = -32;
+        if constexpr (UNI) {
+            if (sneg2 == 0) {                                   // the whole wave at once
+                const uint32_t c = tc_in + (sdry2 >> 1);        // the step the new actions are for
+                if ((c & 16u) == 0u) refill(c >> 5);
+                acts = (c & 16u) ? a_hi : a_lo;
+                sdry2 += 32u;
+                sneg2 = -32;
+            }
+        } else {
+            if (neg2 == 0) {                                    // a quad shares its step counter: whole quads take this branch
+                const uint32_t c = tc_in + (dry2 >> 1);
+                if ((c & 16u) == 0u) refill(c >> 5);
+                acts = (c & 16u) ? a_hi : a_lo;
+                dry2 += 32u;
+                neg2 = -32;
+            }
         }
+    };
+    if (uni_wave) {
+        for (int t = 0; t < T; ++t) one_step(std::true_type{});
+    } else {
+        for (int t = 0; t < T; ++t) one_step(std::false_type{});
     }
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
