@@ -2038,8 +2038,14 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     // When every game of the wave enters with its step counter a multiple of four (launches of 4 k steps keep it so),
     // `acts` can only run dry at the end of a four-step trip: the countdown is then kept per trip, not per step.
     const bool by_trip = __builtin_amdgcn_ballot_w64((tc_in & 3u) != 0u) == 0ull;
-    auto one_step = [&](auto grp_tag, const bool trips) {      // trips: wave-uniform, this step is part of such a trip
+    // ... and when the whole wave shares ONE step counter (the usual case) the countdown is a scalar: add, compare and
+    // branch on the scalar unit, every step (see tron_rollout_quad_kernel).
+    const bool uni_wave = __builtin_amdgcn_ballot_w64(tc_in != (uint32_t)__builtin_amdgcn_readfirstlane((int)tc_in)) == 0ull;
+    int sneg2 = __builtin_amdgcn_readfirstlane(neg2);
+    uint32_t sdry2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dry2);
+    auto one_step = [&](auto grp_tag, auto uni_tag, const bool trips) {   // trips: wave-uniform, this step is part of such a trip
         constexpr int GRP = decltype(grp_tag)::value;
+        constexpr bool UNI = decltype(uni_tag)::value;
         const bool run = a != 0;
         const int dir8 = (int)((acts << 3) + (uint32_t)d8);
         const int tgt = pos + __builtin_amdgcn_sbfe((int)bstep4, dir8, 8);
@@ -2116,7 +2122,9 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         alive_steps += (uint32_t)a;
         if (alive <= 1) {                                       // new_state: swap the slabs
             // 2 * (launch steps done): the countdown moves on below; inside a trip it is as of the trip's start
-            const uint32_t done2 = dry2 + (uint32_t)neg2 + (uint32_t)(trips ? 2 * (GRP + 1) : 2);
+            uint32_t done2;
+            if constexpr (UNI) done2 = sdry2 + (uint32_t)sneg2 + 2u;
+            else done2 = dry2 + (uint32_t)neg2 + (uint32_t)(trips ? 2 * (GRP + 1) : 2);
             // the spare is completely fresh four steps after it was retired -- or at once, for a shorter episode (rare)
             if (done2 < ok_at2) {
 #pragma unroll
@@ -2132,25 +2140,48 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             a = fresh_a;
         }
         acts >>= 2;                                             // (after the fix-up, which reads this step's action)
-        if (!trips || GRP == 3) neg2 += trips ? 8 : 2;
-        if ((!trips || GRP == 3) && neg2 == 0) {
-            const uint32_t c = tc_in + (dry2 >> 1);
-            if ((c & 16u) == 0u) refill(c >> 5);
-            acts = (c & 16u) ? a_hi : a_lo;
-            dry2 += 32u;
-            neg2 = -32;
+        if constexpr (UNI) {
+            sneg2 += 2;
+            if (sneg2 == 0) {
+                const uint32_t c = tc_in + (sdry2 >> 1);
+                if ((c & 16u) == 0u) refill(c >> 5);
+                acts = (c & 16u) ? a_hi : a_lo;
+                sdry2 += 32u;
+                sneg2 = -32;
+            }
+        } else {
+            if (!trips || GRP == 3) neg2 += trips ? 8 : 2;
+            if ((!trips || GRP == 3) && neg2 == 0) {
+                const uint32_t c = tc_in + (dry2 >> 1);
+                if ((c & 16u) == 0u) refill(c >> 5);
+                acts = (c & 16u) ? a_hi : a_lo;
+                dry2 += 32u;
+                neg2 = -32;
+            }
         }
     };
     // four steps per trip, one per group of the spare slab; the odd steps afterwards
-    for (int trip = T >> 2; trip > 0; --trip) {
-        one_step(std::integral_constant<int, 0>{}, by_trip);
-        one_step(std::integral_constant<int, 1>{}, by_trip);
-        one_step(std::integral_constant<int, 2>{}, by_trip);
-        one_step(std::integral_constant<int, 3>{}, by_trip);
+    if (uni_wave) {
+        for (int trip = T >> 2; trip > 0; --trip) {
+            one_step(std::integral_constant<int, 0>{}, std::true_type{}, false);
+            one_step(std::integral_constant<int, 1>{}, std::true_type{}, false);
+            one_step(std::integral_constant<int, 2>{}, std::true_type{}, false);
+            one_step(std::integral_constant<int, 3>{}, std::true_type{}, false);
+        }
+        if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{}, std::true_type{}, false);
+        if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{}, std::true_type{}, false);
+        if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{}, std::true_type{}, false);
+    } else {
+        for (int trip = T >> 2; trip > 0; --trip) {
+            one_step(std::integral_constant<int, 0>{}, std::false_type{}, by_trip);
+            one_step(std::integral_constant<int, 1>{}, std::false_type{}, by_trip);
+            one_step(std::integral_constant<int, 2>{}, std::false_type{}, by_trip);
+            one_step(std::integral_constant<int, 3>{}, std::false_type{}, by_trip);
+        }
+        if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{}, std::false_type{}, false);
+        if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{}, std::false_type{}, false);
+        if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{}, std::false_type{}, false);
     }
-    if ((T & 3) > 0) one_step(std::integral_constant<int, 0>{}, false);
-    if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{}, false);
-    if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{}, false);
     // ---- statistics (my player's columns; the game's by lane 0 of the quad) and the hand-over to the replay
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
