@@ -519,10 +519,11 @@ def main():
     # Device warm-up, before W and K and on a SCRATCH stepper (other memory, other games): ~30 ms of the same kind of
     # launches, so that a 45-us timed region on a box that has just been handed over is not measured at idle clocks
     # (first run on a fresh box: 62 us, every later one 41-45 us).  Not part of the W warm-up steps or the K timed steps.
+    # (launches of the timed region's own shape: the rocprof passes of tools/profile_bench.sh average over all dispatches)
     t_dev = time.perf_counter()
-    scratch = make_stepper(game, kw, min(batch, 65536), device, 0)
+    scratch = make_stepper(game, kw, batch, device, 0)
     while time.perf_counter() - t_dev < 0.03:
-        scratch.rollout(min(default_chunk, 2048), args.seed)
+        scratch.rollout(steps_per_launch, args.seed)
         torch.cuda.synchronize()
     del scratch
     device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
