@@ -128,6 +128,32 @@ def test_rollout_after_scripted_steps(kernel):
             assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), (k, T)
 
 
+@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global"])
+@pytest.mark.parametrize("N,P,B", [(20, 4, 1000), (33, 3, 300), (12, 7, 257)])
+def test_rollout_with_step_counters_that_differ_inside_a_wave(N, P, B, kernel):
+    """Games of one batch (and of one wave) may stand at different step counters -- states assembled from several sources.
+    The kernels then leave their wave-uniform fast paths (scalar action countdown of the lane-per-player kernels, 4-step
+    trips of the bitboard one): per-game counters from 0..1000, odd and even, against the oracle."""
+    seed, first = 77, 9
+    sh, sd = O.tron_start_positions(N, P)
+    hip = HipTron(N, P, B, sh, sd)
+    hip.tb.first_env_id = first
+    ost = O.TronState(N, P, B)
+    O.tron_reset(ost, sh, sd)
+    rng = np.random.default_rng(5)
+    tc = rng.integers(0, 1000, size=B).astype(ost.tcount.dtype)
+    tc[: B // 3] = 40                                    # (a stretch of equal counters: some waves are uniform, some are not)
+    ost.tcount[:] = tc
+    import torch
+    hip.tb.tcount.copy_(torch.from_numpy(tc.view(np.int32)))        # (oracle: uint32, device tensor: int32)
+    for T in (37, 300):
+        hip.tb.rollout(T, seed, kernel=kernel)
+        O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=8)
+    for k in ("board", "heads", "dirs", "deaths", "tcount", "tstep", "n_episodes", "win_count", "ret_sum", "len_sum", "last_winners", "last_len"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), k
+
+
 @pytest.mark.parametrize("N,T", [(20, 128), (40, 128), (40, 300)])
 def test_rollout_full_size_properties(N, T):
     """BASELINE config 2 (N=20, LDS byte slabs, a lane per player) and config 5 per-GPU shard (N=40: bitboards + replay,
