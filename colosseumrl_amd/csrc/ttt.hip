@@ -175,21 +175,36 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             w = -1; tm = 0; ts = 0;
         }
     };
-    int t = 0;
-    // One Philox call serves 4 plies.  When every game of the wave enters with its step counter a multiple of four
-    // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
-    // per-ply select chain, one refill test per trip.
-    if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
-        for (; t + 4 <= T; t += 4) {
-            ply(rnd.w[0]);
-            ply(rnd.w[1]);
-            ply(rnd.w[2]);
-            ply(rnd.w[3]);
-            tc += 4;
-            rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    // The same ply for a game that is RUNNING when the ply starts (no sticky winner, board not full) -- which every game is
+    // once it has been through a ply of this kernel, because a finished game restarts at once: the random agent's move
+    // is legal by construction, so next_state's checks (in range, cell empty, no winner yet: tictactoe_2p_env.py:293) and
+    // the empty-board-is-full corner fall away, and the winner is known the moment the line test says so.
+    auto ply_running = [&](const uint32_t word) {
+        uint32_t all = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) all |= o[p];
+        const uint32_t empty = dd.full & ~all;                  // (not 0: the game is running)
+        const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, (uint32_t)__popc(empty)));
+        const int pl = tm;
+        uint32_t mine = bit;
+#pragma unroll
+        for (int p = 0; p < P; ++p) mine |= (p == pl) ? o[p] : 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];                    // :295
+        const bool won = ttt_has_line<ND>(dd, mine);                                   // :296-300
+        const bool term = won | ((all | bit) == dd.full);                              // :302-311
+        tm = (pl + 1 == P) ? 0 : pl + 1;                                               // :313
+        ts += 1;
+        if (term) {
+            n_ep += 1;
+            len_sum += ts;
+            draws += won ? 0u : 1u;
+#pragma unroll
+            for (int p = 0; p < P; ++p) { wins[p] += (won && pl == p) ? 1u : 0u; o[p] = 0; }
+            tm = 0; ts = 0;
         }
-    }
-    for (; t < T; ++t) {
+    };
+    auto next_word = [&]() -> uint32_t {                        // the word of step counter tc, then on to tc + 1
         const uint32_t sel = tc & 3u;
         uint32_t word = rnd.w[0];
         word = (sel == 1) ? rnd.w[1] : word;
@@ -197,8 +212,32 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         word = (sel == 3) ? rnd.w[3] : word;
         tc += 1;
         if ((tc & 3u) == 0) rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
-        ply(word);
+        return word;
+    };
+    int t = 0;
+    {   // a state that came in finished but not restarted (stepped without auto-reset, or hand-made): one general ply
+        uint32_t all = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) all |= o[p];
+        if (T > 0 && __builtin_amdgcn_ballot_w64(w >= 0 || all == dd.full || (unsigned)tm >= (unsigned)P) != 0ull) {
+            ply(next_word());
+            t = 1;
+        }
     }
+    // One Philox call serves 4 plies.  When every game of the wave stands at a step counter that is a multiple of four
+    // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
+    // per-ply select chain, one refill test per trip.
+    if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
+        for (; t + 4 <= T; t += 4) {
+            ply_running(rnd.w[0]);
+            ply_running(rnd.w[1]);
+            ply_running(rnd.w[2]);
+            ply_running(rnd.w[3]);
+            tc += 4;
+            rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        }
+    }
+    for (; t < T; ++t) ply_running(next_word());
     int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
     for (int p = 0; p < P; ++p) {

@@ -61,6 +61,35 @@ def test_rollout_vs_oracle(dims, K, P, B, chunks):
     assert torch.equal(tb.results(), tb.results_from_columns())      # the row the kernel packs == the column statistics
 
 
+@pytest.mark.parametrize("dims,K,P,B", [((3, 3), 3, 2, 3000), ((3, 5), 3, 3, 1000 + 7), ((2, 2, 2), 2, 4, 300)])
+def test_rollout_from_finished_states_that_were_not_restarted(dims, K, P, B):
+    """A rollout may come in on states the step API left FINISHED (stepped without auto-reset: sticky winner, full board)
+    and at odd step counters: the kernel's first ply is then the general one (no move, terminal, restart), every later one
+    the ply of a running game.  Against the oracle, which has only the general ply."""
+    rng = np.random.default_rng(11)
+    hip, orc = HipTTT(dims, K, P, B), OracleTTT(dims, K, P, B)
+    n_cells = int(np.prod(dims))
+    for t in range(n_cells + 2):                           # random legal-or-not moves, NO auto-reset: most games end
+        act = rng.integers(-1, n_cells, size=B).astype(np.int8)
+        r1, t1, w1 = hip.step(act)
+        r2, t2, w2 = orc.step(act)
+        assert np.array_equal(t1, t2)
+    assert (orc.winner() >= 0).any() and (orc.winner() < 0).any()
+    ost = orc.st
+    seed, first = 31337, 12
+    hip.tb.first_env_id = first
+    tc = rng.integers(0, 50, size=B).astype(ost.tcount.dtype)
+    ost.tcount[:] = tc
+    import torch
+    hip.tb.tcount.copy_(torch.from_numpy(tc.view(np.int32)))
+    for T in (1, 1, 30, 64):
+        hip.tb.rollout(T, seed)
+        O.ttt_rollout(ost, seed, first, T, n_threads=8)
+        for k in ("occ", "winner", "to_move", "tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
+            want = getattr(ost, k)
+            assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), (k, T)
+
+
 @pytest.mark.parametrize("dims,K,P", [((5, 5), 4, 3), ((3, 5), 3, 3)])
 def test_rollout_full_size_vs_oracle(dims, K, P):
     """BASELINE config 3 at FULL size (B = 262,144; 5x5 K4 and the reference-pinned 3x5 K3) against the oracle itself."""
