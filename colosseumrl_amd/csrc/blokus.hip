@@ -182,10 +182,12 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane)
     return v;
 }
 
-// ---- derive allowed / corner rows of all four players from the board (lanes 0..79: player q, row y)
-__device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int round)
+// ---- derive allowed / corner rows from the board: of all four players (lanes 0..79: player q, row y), or of player
+// `only` alone (lanes 0..19)
+__device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int round, const int only = -1)
 {
-    for (int i = lane; i < 4 * BN; i += 64) {
+    const int first = only < 0 ? 0 : only * BN, last = only < 0 ? 4 * BN : (only + 1) * BN;
+    for (int i = first + lane; i < last; i += 64) {
         const int q = i / BN, y = i - q * BN;
         const uint32_t any = L.occ[0][y] | L.occ[1][y] | L.occ[2][y] | L.occ[3][y];
         const uint32_t own = L.occ[q][y];
@@ -822,7 +824,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
 #endif
     for (int t = 0; t < T_steps; ++t) {
         BLK_STAMP(0);
-        blk_prep(L, lane, round);
+        blk_prep(L, lane, round, pl);                            // the mover's rows; another player's only when the game may end
         BLK_STAMP(1);
         uint32_t ip = 0;
 #pragma unroll
@@ -840,17 +842,19 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         word = (sel == 3) ? rnd.w[3] : word;
         tc += 1;
         bool any_move = false;
+        BlkMove mv = {0, 0, 0, 0, 0};
         if (total > 0) {
             const uint32_t r = __umulhi(word, total);
-            const BlkMove mv = blk_select(T, L, pl, ip, r, lane);
+            mv = blk_select(T, L, pl, ip, r, lane);
             BLK_STAMP(3);
             // the mover keeps a move iff some OTHER piece of its inventory had one (new inventory, old board)
             any_move = total > (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[mv.piece]);
-            blk_apply(T, L, pl, mv, inv, score, lane);
-            BLK_STAMP(4);
         }
+        // Does anybody else have a move?  The reference asks that of the PRE-move board (:424), so it is asked here before
+        // the move is placed -- which lets the other players' rows be derived only now, when they are needed (late game).
         for (int q = 0; q < 4 && !any_move; ++q) {
             if (q == pl || ((dead >> q) & 1u)) continue;
+            blk_prep(L, lane, round, q);
             uint32_t iq = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
@@ -858,6 +862,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
             if (!any_move && round >= 1) dead |= 1u << q;
         }
         BLK_STAMP(5);
+        if (total > 0) {
+            blk_apply(T, L, pl, mv, inv, score, lane);
+            BLK_STAMP(4);
+        }
         const BlkOutcome out = blk_outcome(any_move, pl, score);
         round += (pl == 3) ? 1 : 0;
         pl = (pl + 1) & 3;
