@@ -433,6 +433,9 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
 }
 
 // place the piece (board.py:87-103; no legality check there) and update inventory / score (ai.py:44-54)
+// LEGAL: the move is known to be legal (the rollout plays what blk_select found), so its cells are empty and only the
+// mover's colour changes; otherwise an (illegal) overlap overwrites the other colours, like the reference.
+template <bool LEGAL = false>
 __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv,
                                           uint32_t (&inv)[4], int (&score)[4], const int lane)
 {
@@ -446,9 +449,13 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
         for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh(j) : cx; cy = (j == lane) ? s.ro(j) : cy; }
         const int x = mv.x + cx - ox, y = mv.y + cy - oy;
         if (x >= 0 && x < BN && y >= 0 && y < BN) {
-            for (int c = 0; c < 4; ++c) {
-                if (c == q) atomicOr(&L.occ[c][y], 1u << x);
-                else atomicAnd(&L.occ[c][y], ~(1u << x));    // an (illegal) overlap overwrites, like the reference
+            if (LEGAL) {
+                atomicOr(&L.occ[q][y], 1u << x);
+            } else {
+                for (int c = 0; c < 4; ++c) {
+                    if (c == q) atomicOr(&L.occ[c][y], 1u << x);
+                    else atomicAnd(&L.occ[c][y], ~(1u << x));
+                }
             }
         }
     }
@@ -863,7 +870,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         }
         BLK_STAMP(5);
         if (total > 0) {
-            blk_apply(T, L, pl, mv, inv, score, lane);
+            blk_apply<true>(T, L, pl, mv, inv, score, lane);
             BLK_STAMP(4);
         }
         const BlkOutcome out = blk_outcome(any_move, pl, score);
