@@ -179,10 +179,9 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     // once it has been through a ply of this kernel, because a finished game restarts at once: the random agent's move
     // is legal by construction, so next_state's checks (in range, cell empty, no winner yet: tictactoe_2p_env.py:293) and
     // the empty-board-is-full corner fall away, and the winner is known the moment the line test says so.
+    uint32_t all_run = 0;                                       // every player's marks (kept across running plies)
     auto ply_running = [&](const uint32_t word) {
-        uint32_t all = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) all |= o[p];
+        const uint32_t all = all_run;
         const uint32_t empty = dd.full & ~all;                  // (not 0: the game is running)
         const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, (uint32_t)__popc(empty)));
         const int pl = tm;
@@ -192,7 +191,8 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
 #pragma unroll
         for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];                    // :295
         const bool won = ttt_has_line<ND>(dd, mine);                                   // :296-300
-        const bool term = won | ((all | bit) == dd.full);                              // :302-311
+        all_run = all | bit;
+        const bool term = won | (all_run == dd.full);                                  // :302-311
         tm = (pl + 1 == P) ? 0 : pl + 1;                                               // :313
         ts += 1;
         if (term) {
@@ -201,7 +201,7 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             draws += won ? 0u : 1u;
 #pragma unroll
             for (int p = 0; p < P; ++p) { wins[p] += (won && pl == p) ? 1u : 0u; o[p] = 0; }
-            tm = 0; ts = 0;
+            tm = 0; ts = 0; all_run = 0;
         }
     };
     auto next_word = [&]() -> uint32_t {                        // the word of step counter tc, then on to tc + 1
@@ -224,6 +224,8 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             t = 1;
         }
     }
+#pragma unroll
+    for (int p = 0; p < P; ++p) all_run |= o[p];
     // One Philox call serves 4 plies.  When every game of the wave stands at a step counter that is a multiple of four
     // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
     // per-ply select chain, one refill test per trip.
