@@ -520,9 +520,18 @@ def main():
     # launches, so that a 45-us timed region on a box that has just been handed over is not measured at idle clocks
     # (first run on a fresh box: 62 us, every later one 41-45 us).  Not part of the W warm-up steps or the K timed steps.
     # (launches of the timed region's own shape: the rocprof passes of tools/profile_bench.sh average over all dispatches)
+    # First ~60 ms of large device copies (the memory clocks follow sustained HBM traffic: after a quiet spell the first
+    # 20-step launch -- 65 MB in 20 us -- ran in 31 us, the ones behind the bandwidth measurement further down in 20),
+    # then ~30 ms of launches.
     t_dev = time.perf_counter()
+    blob = torch.empty((256 << 20,), dtype=torch.uint8, device=device)
+    while time.perf_counter() - t_dev < 0.06:
+        blob[: 128 << 20].copy_(blob[128 << 20:])
+        torch.cuda.synchronize()
+    del blob
     scratch = make_stepper(game, kw, batch, device, 0)
-    while time.perf_counter() - t_dev < 0.03:
+    t_launch = time.perf_counter()
+    while time.perf_counter() - t_launch < 0.03:
         scratch.rollout(steps_per_launch, args.seed)
         torch.cuda.synchronize()
     del scratch
