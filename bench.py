@@ -609,4 +609,11 @@ def main():
 
 
 if __name__ == "__main__":
+    # stdout carries the JSON line(s) and nothing else: libraries that write to file descriptor 1 behind Python's back
+    # (RCCL prints a version banner when its communicator comes up) are sent to stderr for the duration
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(_real_stdout, "w")
     main()
+    sys.stdout.flush()
