@@ -14,6 +14,7 @@
 // start mask (windows that stay on the board).  Direction strides and start masks are
 // wave-uniform kernel arguments (SGPRs) -- no table traffic at all.
 #include "crl_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -29,24 +30,26 @@ struct ttt_dirs {
 // built by doubling: t = m & (m >> s) is "two in a row", t & (t >> 2s) four, ... -- for the pinned K = 3 / 4 / 5 that is
 // two or three shift-and pairs per direction (K is wave-uniform: one scalar branch) where the plain K-1 rounds of the
 // generic loop take K-1 pairs plus the copies that seed them.
-template <int ND>
+// KC: K when the caller has branched on it already (3, 4, 5), else 0 = ask dd.K here.
+template <int ND, int KC = 0>
 __device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t m)
 {
     uint32_t hit = 0;
-    if (dd.K == 3) {
+    const int K = KC ? KC : dd.K;
+    if (K == 3) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int s = dd.stride[d];
             hit |= m & (m >> s) & (m >> (2 * s)) & dd.start[d];
         }
-    } else if (dd.K == 4) {
+    } else if (K == 4) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int s = dd.stride[d];
             const uint32_t two = m & (m >> s);
             hit |= two & (two >> (2 * s)) & dd.start[d];
         }
-    } else if (dd.K == 5) {
+    } else if (K == 5) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const int s = dd.stride[d];
@@ -57,7 +60,7 @@ __device__ __forceinline__ bool ttt_has_line(const ttt_dirs &dd, const uint32_t 
         uint32_t t[ND], run[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) t[d] = run[d] = m;
-        for (int s = 1; s < dd.K; ++s) {
+        for (int s = 1; s < K; ++s) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 t[d] >>= dd.stride[d];              // cell c + s * stride of direction d, seen from c
@@ -180,7 +183,8 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     // is legal by construction, so next_state's checks (in range, cell empty, no winner yet: tictactoe_2p_env.py:293) and
     // the empty-board-is-full corner fall away, and the winner is known the moment the line test says so.
     uint32_t all_run = 0;                                       // every player's marks (kept across running plies)
-    auto ply_running = [&](const uint32_t word) {
+    auto ply_running = [&](auto k_tag, const uint32_t word) {   // k_tag: K as a compile-time constant (0: read it from dd)
+        constexpr int KC = decltype(k_tag)::value;
         const uint32_t all = all_run;
         const uint32_t empty = dd.full & ~all;                  // (not 0: the game is running)
         const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, (uint32_t)__popc(empty)));
@@ -190,7 +194,7 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         for (int p = 0; p < P; ++p) mine |= (p == pl) ? o[p] : 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];                    // :295
-        const bool won = ttt_has_line<ND>(dd, mine);                                   // :296-300
+        const bool won = ttt_has_line<ND, KC>(dd, mine);                               // :296-300
         all_run = all | bit;
         const bool term = won | (all_run == dd.full);                                  // :302-311
         tm = (pl + 1 == P) ? 0 : pl + 1;                                               // :313
@@ -229,17 +233,23 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     // One Philox call serves 4 plies.  When every game of the wave stands at a step counter that is a multiple of four
     // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
     // per-ply select chain, one refill test per trip.
-    if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
-        for (; t + 4 <= T; t += 4) {
-            ply_running(rnd.w[0]);
-            ply_running(rnd.w[1]);
-            ply_running(rnd.w[2]);
-            ply_running(rnd.w[3]);
-            tc += 4;
-            rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    // (K is wave-uniform: one branch here instead of one per ply)
+    auto run_plies = [&](auto k_tag) {
+        if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
+            for (; t + 4 <= T; t += 4) {
+                ply_running(k_tag, rnd.w[0]);
+                ply_running(k_tag, rnd.w[1]);
+                ply_running(k_tag, rnd.w[2]);
+                ply_running(k_tag, rnd.w[3]);
+                tc += 4;
+                rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+            }
         }
-    }
-    for (; t < T; ++t) ply_running(next_word());
+        for (; t < T; ++t) ply_running(k_tag, next_word());
+    };
+    if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
+    else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
+    else run_plies(std::integral_constant<int, 0>{});
     int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
     for (int p = 0; p < P; ++p) {
