@@ -459,6 +459,68 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     return out
 
 
+# the reference's own per-call latency (us), one core, build container: tools/time_reference_dropin.py
+REFERENCE_DROPIN_US = {
+    "tron": {"new_state": 98.8, "next_state": 11.0, "valid_actions": 0.4, "state_to_observation": 6.0},
+    "tictactoe": {"new_state": 1.3, "next_state": 33.5, "valid_actions": 8.5, "state_to_observation": 4.9},
+    "tictactoe_3p": {"new_state": 1.0, "next_state": 38.4, "valid_actions": 11.9, "state_to_observation": 5.1},
+    "tictactoe_4p": {"new_state": 1.2, "next_state": 584.1, "valid_actions": 30.4, "state_to_observation": 9.0},
+    "blokus": {"new_state": 15.2, "next_state": 171456.2, "valid_actions": 86101.3, "state_to_observation": 264.6},
+}
+
+
+def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p", "blokus")):
+    """The single-state drop-in API (what match_server.py:193,201-203,218 and ClientEnvironment.py:327-328 call): mean
+    microseconds per new_state / next_state / valid_actions / state_to_observation on ONE state, random play with
+    restarts at terminal, wall clock around each call (every call ends synchronised: it returns numpy / Python
+    objects).  Beside each figure the reference's own, timed in the build container (tools/time_reference_dropin.py)."""
+    import random
+    from colosseumrl_amd.config import get_environment
+    rng = random.Random(0)
+    out = {}
+    for name in names:
+        env = get_environment(name)() if name != "tron" else get_environment(name)("20;4")
+        n_next, n_other = (300, 300) if name == "blokus" else (3000, 1000)
+        state, players = env.new_state()
+        for _ in range(3):                                  # lazy set-up (context, staging, code objects) outside the timing
+            va = env.valid_actions(state, players[0])
+            env.state_to_observation(state, players[0])
+            acts = [rng.choice(va) for _ in players] if name != "tron" else [rng.choice(va) for _ in players]
+            state, players, _, term, _ = env.next_state(state, players, acts)
+            if term:
+                state, players = env.new_state()
+        t = {"new_state": 0.0, "next_state": 0.0, "valid_actions": 0.0, "state_to_observation": 0.0}
+        k = dict.fromkeys(t, 0)
+        for i in range(n_next):
+            t0 = time.perf_counter()
+            va = env.valid_actions(state, players[0])
+            t1 = time.perf_counter()
+            if i < n_other:
+                env.state_to_observation(state, players[0])
+                t2 = time.perf_counter()
+                t["state_to_observation"] += t2 - t1
+                k["state_to_observation"] += 1
+            t["valid_actions"] += t1 - t0
+            k["valid_actions"] += 1
+            acts = [rng.choice(va) for _ in players]
+            t0 = time.perf_counter()
+            state, players, _, term, _ = env.next_state(state, players, acts)
+            t["next_state"] += time.perf_counter() - t0
+            k["next_state"] += 1
+            if term:
+                t0 = time.perf_counter()
+                state, players = env.new_state()
+                t["new_state"] += time.perf_counter() - t0
+                k["new_state"] += 1
+        rec = {m: round(t[m] / max(k[m], 1) * 1e6, 1) for m in t}
+        rec["reference_us"] = REFERENCE_DROPIN_US.get(name)
+        rec["calls"] = k["next_state"]
+        out[name] = rec
+    out["what"] = ("us per call of the BaseEnvironment single-state API on one state (B = 1), random play; reference_us = the "
+                   "reference's own Python path, one core, build container (it cannot travel to the GPU box)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -471,6 +533,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="skip steady_state / seeds / others / step_api (profiling runs)")
     ap.add_argument("--only-step-api", action="store_true", help="run just the per-step API section (profiling runs)")
+    ap.add_argument("--only-dropin", action="store_true", help="run just the single-state drop-in latency section")
     args = ap.parse_args()
 
     import torch
@@ -488,6 +551,9 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
     use_dist = dist.is_initialized()
 
+    if args.only_dropin:
+        print(json.dumps({"dropin": dropin_latencies()}))
+        return
     if args.only_step_api:
         copy_gbs, write_gbs = measure_copy_bandwidth(torch, device)
         print(json.dumps({"copy_peak_GBs": copy_gbs, "write_stream_peak_GBs": write_gbs,

@@ -63,6 +63,11 @@ PROTOTYPES = {
     "crl_version": (_I, []),
     "crl_device_count": (_I, []),
     "crl_destroy": (None, [_VP]),
+    "crl_host_alloc": (_I, [C.c_size_t, C.POINTER(_VP), C.POINTER(_VP)]),
+    "crl_host_free": (_I, [_VP]),
+    "crl_stream_create": (_I, [C.POINTER(_VP)]),
+    "crl_stream_destroy": (_I, [_VP]),
+    "crl_stream_synchronize": (_I, [_VP]),
     "crl_philox4x32": (_I, [_VP, _U32, _U32, _VP, _I64, _VP]),
     "crl_tron_create": (_I, [_I, _I, _VP, _VP, C.POINTER(_VP)]),
     "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -80,6 +85,8 @@ PROTOTYPES = {
     "crl_ttt_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "crl_ttt_valid": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
+    "crl_ttt_step_board": (_I, [_VP, _I64] + [_VP] * 9 + [_I, _U32, _VP]),
+    "crl_ttt_observe_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP, _VP]),
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
     "crl_ttt_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _I, _VP, _VP]),
     "crl_ttt_step_observe": (_I, [_VP, _I64, _U64, _U64] + [_VP] * 10 + [_I, _U32, _VP]),
@@ -89,6 +96,10 @@ PROTOTYPES = {
     "crl_blokus_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "crl_blokus_valid": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "crl_blokus_valid_list": (_I, [_VP, _I64] + [_VP] * 8 + [_I, _VP]),
+    "crl_blokus_select": (_I, [_VP, _I64] + [_VP] * 9 + [_VP]),
+    "crl_blokus_is_valid": (_I, [_VP, _I64] + [_VP] * 8 + [_VP]),
+    "crl_blokus_pack": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_blokus_board": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_blokus_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, _VP, BlokusStats, _VP]),

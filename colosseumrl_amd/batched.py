@@ -231,8 +231,8 @@ class TronBatch:
         agent at each game's step counter, which then advances) and returns the observations of ALL P players of the
         resulting states together with the step outputs:
         {'board' [P, B, N, N], 'heads' [P, P, B], 'directions', 'deaths', 'rewards' [P, B], 'terminal' [B], 'winners' [B]}.
-        Equals ``step(sample(seed) or actions, auto_reset); observe_all()``.  Pass a previous result as `out` to reuse
-        its observation buffers."""
+        Equals ``step(sample(seed) or actions, auto_reset); observe_all()``; one launch on every board size and player
+        count.  Pass a previous result as `out` to reuse its observation buffers."""
         P, B, N = self.P, self.B, self.N
         if actions is not None:
             _want(actions, torch.int8, (P, B), self.device, "actions")
@@ -407,6 +407,56 @@ class TTTBatch:
         return torch.stack(cols, dim=1).contiguous()
 
 
+class TTTBoards:
+    """B TicTacToe games held in the REFERENCE's layout (``board int8 [B, cells]`` with -1 = empty, ``winner``,
+    ``to_move``) and stepped there by ``crl_ttt_step_board`` / ``crl_ttt_observe_board`` -- what the single-state
+    drop-in classes run at B = 1; `TTTBatch` (bit masks) is the layout for throughput."""
+
+    def __init__(self, dims: Sequence[int] = (3, 3), k: int = 3, num_players: int = 2, batch: int = 1, device="cuda"):
+        lib = _native.require_gpu()
+        self.dims = tuple(int(d) for d in dims)
+        d3 = (1,) * (3 - len(self.dims)) + self.dims
+        self.K, self.P, self.B = int(k), int(num_players), int(batch)
+        self.n_cells = d3[0] * d3[1] * d3[2]
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        handle = C.c_void_p()
+        check(lib.crl_ttt_create(d3[0], d3[1], d3[2], self.K, self.P, C.byref(handle)), "crl_ttt_create")
+        self._ctx = _Ctx(handle)
+        self._lib = lib
+        dev, B = self.device, self.B
+        self.board = torch.full((B, self.n_cells), -1, dtype=torch.int8, device=dev)
+        self.winner = torch.full((B,), -1, dtype=torch.int8, device=dev)
+        self.to_move = torch.zeros((B,), dtype=torch.int8, device=dev)
+        self.reward = torch.zeros((B,), dtype=torch.int8, device=dev)
+        self.terminal = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self.winners = torch.zeros((B,), dtype=torch.int8, device=dev)
+        self.valid = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.obs = torch.zeros((B, self.n_cells), dtype=torch.int8, device=dev)
+
+    def step(self, action: torch.Tensor, auto_reset: bool = False, rel_mod: Optional[int] = None):
+        _want(action, torch.int8, (self.B,), self.device, "action")
+        with _DevGuard(self.device):
+            check(self._lib.crl_ttt_step_board(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.winner), _ptr(self.to_move),
+                                               _ptr(action), _ptr(self.reward), _ptr(self.terminal), _ptr(self.winners),
+                                               _ptr(self.valid), _ptr(self.obs), int(rel_mod if rel_mod else self.P),
+                                               CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()), "crl_ttt_step_board")
+        return self.reward, self.terminal, self.winners
+
+    def observe(self, player: Optional[torch.Tensor] = None, rel_mod: Optional[int] = None):
+        """(obs int8 [B, cells] relative to player[b] -- absolute when player is None --, empties mask int32 [B])"""
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        obs = torch.empty_like(self.board)
+        valid = torch.empty_like(self.valid)
+        with _DevGuard(self.device):
+            check(self._lib.crl_ttt_observe_board(self._ctx.handle, self.B, _ptr(self.board), _ptr(player),
+                                                  int(rel_mod if rel_mod else self.P), _ptr(obs), _ptr(valid), _stream()),
+                  "crl_ttt_observe_board")
+        return obs, valid
+
+
 class BlokusBatch:
     """B games of 4-player 20x20 Blokus (reference: envs/blokus/*).
 
@@ -478,6 +528,50 @@ class BlokusBatch:
             check(self._lib.crl_blokus_valid(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(count),
                                              _ptr(mask), _stream()), "crl_blokus_valid")
         return (count, mask) if want_mask else count
+
+    def valid_list(self, cap: int = 2048, player: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """The ordered legal-action LIST of `player` (default: the player to move), compacted: (count int32 [B],
+        ids int32 [B, cap]) with ``ids[b, :min(count[b], cap)]`` = the dense ids in ascending order = the reference's
+        ``valid_actions`` order (BlokusEnvironment.py:453-500); entries beyond are -1 (or whatever `out` held)."""
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        count = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        ids = out if out is not None else torch.full((self.B, int(cap)), -1, dtype=torch.int32, device=self.device)
+        _want(ids, torch.int32, (self.B, int(cap)), self.device, "out")
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_valid_list(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(ids),
+                                                  _ptr(count), int(cap), _stream()), "crl_blokus_valid_list")
+        return count, ids
+
+    def select(self, rank: torch.Tensor, player: Optional[torch.Tensor] = None):
+        """Dense id of the rank[b]-th legal action (reference order) of `player` (default: the player to move) without
+        materialising the list; -1 where rank is outside [0, count).  -> (action int32 [B], count int32 [B])."""
+        _want(rank, torch.int32, (self.B,), self.device, "rank")
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        act = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        count = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_select(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(rank), _ptr(act),
+                                              _ptr(count), _stream()), "crl_blokus_select")
+        return act, count
+
+    def is_valid(self, action: torch.Tensor, player: Optional[torch.Tensor] = None):
+        """``is_valid_action`` for all games: uint8 [B], 1 iff the dense id action[b] is a legal action of `player`."""
+        _want(action, torch.int32, (self.B,), self.device, "action")
+        if player is not None:
+            _want(player, torch.int8, (self.B,), self.device, "player")
+        ok = torch.empty((self.B,), dtype=torch.uint8, device=self.device)
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_is_valid(self._ctx.handle, self.B, *self._state(), _ptr(player), _ptr(action), _ptr(ok),
+                                                _stream()), "crl_blokus_is_valid")
+        return ok
+
+    def set_board(self, board: torch.Tensor):
+        """Loads ``Board.board_contents`` (int8 [B, 20, 20], 0 empty else colour) into the row bitboards."""
+        _want(board, torch.int8, (self.B, 20, 20), self.device, "board")
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_pack(self._ctx.handle, self.B, _ptr(board), _ptr(self.occ), _stream()), "crl_blokus_pack")
 
     def sample(self, seed: int = 0, advance: bool = True):
         """The rollout's random agent for one step: int32 [B] dense action id of a uniformly drawn legal action of the

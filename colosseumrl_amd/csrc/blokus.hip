@@ -968,6 +968,194 @@ blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const u
     blk_write_observation(s_occ[wave], iv, sc, pl, b, lane, obs_board, obs_pieces, obs_score);
 }
 
+// ---- the ordered legal-action list, compacted (what BlokusEnvironment.valid_actions returns, :453-500) -------------------
+// fit table of all 8 orientations of `piece` for player q into L.u.sel.fit (as level 1 of blk_select)
+__device__ __forceinline__ void blk_build_fit(const BlkTables &T, WaveLds &L, const int q, const int piece, const int lane)
+{
+    for (int i = lane; i < 8 * 12; i += 64) {
+        const int o = i / 12, k = i - o * 12;
+        L.u.sel.fit[o][k < 4 ? k : k + BN] = 0u;
+    }
+    for (int i = lane; i < 8 * BN; i += 64) {
+        const int o = i / BN, y = i - o * BN;
+        const ShapeRegs s = blk_load_shape(T, piece, o);
+        uint32_t F = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
+        L.u.sel.fit[o][y + 4] = F;
+    }
+    wave_sync();
+}
+
+// anchors of player q in row-major order into L.u.sel.alist (y << 8 | x); returns their number
+__device__ __forceinline__ int blk_build_anchors(WaveLds &L, const int q, const int lane)
+{
+    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
+    const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
+    uint32_t m = crow;
+    int pos = (int)rinc - __popc(crow);
+    while (m) {
+        const int x = __builtin_ctz(m);
+        m &= m - 1;
+        L.u.sel.alist[pos++] = (uint16_t)((lane << 8) | x);
+    }
+    wave_sync();
+    return __builtin_amdgcn_readlane((int)rinc, BN - 1);
+}
+
+// legal (orientation, shift) pairs of `piece` (n cells) with its cell `shift` on anchor (ax, ay): bit o * n + j.
+// blk_build_fit(piece) must have run.  One lane per anchor (40 bit tests of the fit table).
+__device__ __forceinline__ unsigned long long blk_anchor_pairs(const BlkTables &T, const WaveLds &L, const int piece, const int n,
+                                                               const int ax, const int ay)
+{
+    unsigned long long m = 0;
+    for (int o = 0; o < 8; ++o)
+        for (int j = 0; j < n; ++j) {
+            const uint32_t cb = T.cells[piece * 8 + o][j];
+            const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
+            const uint32_t bit = (L.u.sel.fit[o][ay + 8 - dy4] >> (ax + 8 - dx4)) & 1u;
+            m |= (unsigned long long)bit << (o * n + j);
+        }
+    return m;
+}
+
+// count[b] and ids[b][0 .. min(count, cap)) = the dense ids of every legal action of `player` in ascending order, which is
+// the reference's order (piece -> anchor row-major -> orientation -> shift, board.py:184-189)
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+blokus_list_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
+                   const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
+                   const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
+                   const int8_t *__restrict__ player, int32_t *__restrict__ ids, int32_t *__restrict__ count, const int cap)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
+    uint32_t iq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    const uint32_t total = blk_count(T, L, q, iq, lane);
+    if (lane == 0 && count) count[b] = (int32_t)total;
+    if (!ids || total == 0) return;
+    int32_t *out = ids + b * (int64_t)cap;
+    // the per-piece counts leave LDS before the select tables overwrite the count pass's (pcnt itself is not in the union)
+    const int n_anchor = blk_build_anchors(L, q, lane);
+    uint32_t base = 0;
+    for (int piece = 0; piece < NPIECE; ++piece) {
+        const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[piece]);
+        if (pc == 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
+        blk_build_fit(T, L, q, piece, lane);
+        for (int a0 = 0; a0 < n_anchor; a0 += 64) {
+            const bool have = a0 + lane < n_anchor;
+            const int packed = have ? (int)L.u.sel.alist[a0 + lane] : 0;
+            const int ay = packed >> 8, ax = packed & 0xff;
+            const unsigned long long pairs = have ? blk_anchor_pairs(T, L, piece, n, ax, ay) : 0ull;
+            const uint32_t mine = (uint32_t)__builtin_popcountll(pairs);
+            const uint32_t incl = wave_scan_incl(mine, lane);
+            uint32_t pos = base + incl - mine;
+            unsigned long long m = pairs;
+            while (m) {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1;
+                const int o = k / n, j = k - o * n;
+                if (pos < (uint32_t)cap) out[pos] = ((piece * 400 + ay * BN + ax) * 8 + o) * 5 + j;
+                ++pos;
+            }
+            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        wave_sync();                                       // the next piece rewrites the fit table
+    }
+}
+
+// the rank[b]-th legal action of `player` in reference order as a dense id (-1 when rank is outside [0, count)):
+// blk_select with the rank from memory instead of the rollout's Philox draw
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+blokus_select_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
+                     const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
+                     const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
+                     const int8_t *__restrict__ player, const int32_t *__restrict__ rank, int32_t *__restrict__ action,
+                     int32_t *__restrict__ count)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
+    uint32_t iq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    const uint32_t total = blk_count(T, L, q, iq, lane);
+    const int r = __builtin_amdgcn_readfirstlane(rank[b]);
+    int id = -1;
+    if (r >= 0 && (uint32_t)r < total) {
+        const BlkMove mv = blk_select(T, L, q, iq, (uint32_t)r, lane);
+        id = ((mv.piece * 400 + mv.y * BN + mv.x) * 8 + mv.orient) * 5 + mv.shift;
+    }
+    if (lane == 0) {
+        action[b] = id;
+        if (count) count[b] = (int32_t)total;
+    }
+}
+
+// is_valid_action (BlokusEnvironment.py:667-719: membership in valid_actions) without the enumeration: the piece is held,
+// `shift` names one of its cells, that cell's target is an anchor of the player, and every cell lands on an allowed cell
+__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+blokus_is_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
+                       const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
+                       const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
+                       const int8_t *__restrict__ player, const int32_t *__restrict__ action, uint8_t *__restrict__ ok)
+{
+    BLK_SHARED_SETUP();
+    uint32_t inv[4];
+    int score[4];
+    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
+    uint32_t iq = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    const int id = __builtin_amdgcn_readfirstlane(action[b]);
+    bool good = false;
+    if (id >= 0 && id < ACTION_IDS) {
+        const BlkMove mv = blk_decode(id);
+        const ShapeRegs s = blk_load_shape(T, mv.piece, mv.orient);
+        if (((iq >> mv.piece) & 1u) && mv.shift < s.n) {
+            int ox = 0, oy = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh(j) : ox; oy = (j == mv.shift) ? s.ro(j) : oy; }
+            bool cell_ok = true;
+            if (lane < s.n) {
+                int cx = 0, cy = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh(j) : cx; cy = (j == lane) ? s.ro(j) : cy; }
+                const int x = mv.x + cx - ox, y = mv.y + cy - oy;
+                cell_ok = x >= 0 && x < BN && y >= 0 && y < BN && ((L.ac[q][y + 4].x >> (x + 8)) & 1u);
+            }
+            const bool anchor = (L.ac[q][mv.y + 4].y >> (mv.x + 8)) & 1u;
+            good = anchor && __ballot(!cell_ok) == 0ull;
+        }
+    }
+    if (lane == 0) ok[b] = good ? 1 : 0;
+}
+
+// occ rows from Board.board_contents (int8 [B][20][20], 0 empty else colour): the inverse of blokus_board_kernel
+__global__ void __launch_bounds__(256)
+blokus_pack_kernel(const int64_t B, const int8_t *__restrict__ board, uint32_t *__restrict__ occ)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 4 * BN) return;
+    const int64_t b = i / (4 * BN);
+    const int k = (int)(i - b * 4 * BN), c = k / BN, y = k - c * BN;
+    const int8_t *row = board + (b * BN + y) * BN;
+    uint32_t m = 0;
+    for (int x = 0; x < BN; ++x) m |= (row[x] == c + 1) ? (1u << x) : 0u;
+    occ[i] = m;
+}
+
 } // namespace
 
 void crl_blokus_free(void *tables)
@@ -1067,6 +1255,56 @@ int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const u
     if (mask) CRL_HIP(hipMemsetAsync(mask, 0, (size_t)B * MASK_WORDS * 4, (hipStream_t)stream));
     hipLaunchKernelGGL(blokus_valid_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, count, mask);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_valid_list(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                          const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *ids, int32_t *count,
+                          int cap, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_valid_list");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_valid_list: NULL state pointer");
+    CRL_REQUIRE(ids || count, "crl_blokus_valid_list: nothing to compute (ids and count are NULL)");
+    CRL_REQUIRE(ids == nullptr || cap > 0, "crl_blokus_valid_list: cap must be positive");
+    hipLaunchKernelGGL(blokus_list_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, ids, count, cap);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_select(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                      const int32_t *round, const int32_t *to_move, const int8_t *player, const int32_t *rank,
+                      int32_t *action, int32_t *count, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_select");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_select: NULL state pointer");
+    CRL_REQUIRE(rank && action, "crl_blokus_select: NULL rank / action pointer");
+    hipLaunchKernelGGL(blokus_select_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, rank, action, count);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_is_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                        const int32_t *round, const int32_t *to_move, const int8_t *player, const int32_t *action,
+                        uint8_t *ok, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_is_valid");
+    CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_is_valid: NULL state pointer");
+    CRL_REQUIRE(action && ok, "crl_blokus_is_valid: NULL action / ok pointer");
+    hipLaunchKernelGGL(blokus_is_valid_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, action, ok);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_pack(const crl_ctx *ctx, int64_t B, const int8_t *board, uint32_t *occ, void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_pack");
+    CRL_REQUIRE(board && occ, "crl_blokus_pack: NULL pointer");
+    const int64_t n = B * 4 * BN;
+    hipLaunchKernelGGL(blokus_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, board, occ);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -51,6 +51,52 @@ void crl_destroy(crl_ctx *ctx)
     delete ctx;
 }
 
+// ---- host staging for single-state callers (the reference's one-state-per-call API, see colosseum_hip.h)
+int crl_host_alloc(size_t bytes, void **host, void **device)
+{
+    CRL_REQUIRE(host != nullptr && bytes > 0, "crl_host_alloc: bad argument");
+    void *p = nullptr;
+    CRL_HIP(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(p, 0, bytes);
+    void *d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, p, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(p);
+        crl_set_error("hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+        return CRL_EHIP;
+    }
+    *host = p;
+    if (device) *device = d;
+    return CRL_OK;
+}
+
+int crl_host_free(void *host)
+{
+    if (host) CRL_HIP(hipHostFree(host));
+    return CRL_OK;
+}
+
+int crl_stream_create(void **stream)
+{
+    CRL_REQUIRE(stream != nullptr, "crl_stream_create: stream is NULL");
+    hipStream_t s = nullptr;
+    CRL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return CRL_OK;
+}
+
+int crl_stream_destroy(void *stream)
+{
+    if (stream) CRL_HIP(hipStreamDestroy((hipStream_t)stream));
+    return CRL_OK;
+}
+
+int crl_stream_synchronize(void *stream)
+{
+    CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return CRL_OK;
+}
+
 int crl_philox4x32(const uint32_t *ctr, uint32_t key0, uint32_t key1, uint32_t *out, int64_t n, void *stream)
 {
     CRL_REQUIRE(ctr && out, "crl_philox4x32: NULL pointer");

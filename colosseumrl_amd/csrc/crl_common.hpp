@@ -21,10 +21,19 @@ struct crl_ttt_cfg {
     uint32_t full;
 };
 
+// win-line directions of a TicTacToe board as kernel arguments (ttt.hip)
+struct ttt_dirs {
+    int32_t n_dirs, K, P, n_cells;
+    uint32_t full;
+    int32_t stride[13];
+    uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
+};
+
 struct crl_ctx {
     int game;
     crl_tron_cfg tron;
     crl_ttt_cfg ttt;
+    ttt_dirs ttt_dd;
     uint32_t ttt_lines_host[CRL_TTT_MAX_LINES];
     uint32_t *ttt_lines_dev;   // DEVICE copy of the win-line table
     void *blokus;              // blokus tables (blokus.hip)

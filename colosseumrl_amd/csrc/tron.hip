@@ -2728,6 +2728,90 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
     }
 }
 
+// The same fused call for every shape the kernel above cannot take (N*N % 16 != 0 -- the reference's default 19x19 board
+// among them --, P = 8, boards too large for 16 slabs of LDS): ONE GAME PER WORKGROUP, byte granularity throughout.  The
+// board goes into LDS with coalesced byte loads, thread 0 plays the step there (mirroring the <= P trail bytes to HBM),
+// and all threads write the P relabelled copies (CyTronGrid.pyx:70-71 in arithmetic).  Also what a single-state caller
+// (B = 1, host-mapped memory) runs: one launch, any board.  Before round 3 these shapes took three launches (sample,
+// step, observe_all) and needed explicit actions.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_step_observe_any_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
+                             const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
+                             int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                             int8_t *__restrict__ deaths, const int8_t *__restrict__ actions, uint32_t *__restrict__ tcount,
+                             int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                             int8_t *__restrict__ obs_board, int16_t *__restrict__ oh, int8_t *__restrict__ od,
+                             int8_t *__restrict__ ok, const uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ int s_reset;
+    const int NN = g.NN;
+    const int64_t b = blockIdx.x;
+    int8_t *gb = board + b * NN;
+    for (int c = threadIdx.x; c < NN; c += 256) lds[c] = (uint8_t)gb[c];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TronRegs<P> s;
+        int act[P], rew[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = heads[p * B + b];
+            s.d[p] = dirs[p * B + b];
+            s.k[p] = deaths[p * B + b];
+            act[p] = actions ? actions[p * B + b] : 0;
+        }
+        if (!actions) {                                         // the rollout's random agent at this game's step counter
+            const uint32_t c = tcount[b];
+            tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c, seed_lo, seed_hi, act);
+            tcount[b] = c + 1u;
+        }
+        tron_split_heads<P>(g, s);
+        int term, wm;
+        const DualBoard bd{lds, gb};
+        tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
+        const bool do_reset = term && (flags & CRL_STEP_AUTO_RESET);
+        s_reset = do_reset ? 1 : 0;
+        if (do_reset) tron_regs_to_start<P>(cfg, g, s);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            rewards[p * B + b] = (int8_t)rew[p];
+            heads[p * B + b] = (int16_t)s.h[p];
+            dirs[p * B + b] = (int8_t)s.d[p];
+            deaths[p * B + b] = (int8_t)s.k[p];
+        }
+        terminal[b] = (uint8_t)term;
+        winners[b] = (uint8_t)wm;
+#pragma unroll
+        for (int p = 0; p < P; ++p)                             // TronGridEnvironment.py:392-396: rolled so index 0 is the observer
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int src = (i + p) % P;
+                oh[((int64_t)p * P + i) * B + b] = (int16_t)s.h[src];
+                od[((int64_t)p * P + i) * B + b] = (int8_t)s.d[src];
+                ok[((int64_t)p * P + i) * B + b] = (int8_t)s.k[src];
+            }
+    }
+    __syncthreads();
+    const bool fresh = s_reset != 0;
+    const int64_t plane = B * (int64_t)NN;
+    for (int c = threadIdx.x; c < NN; c += 256) {
+        int v = lds[c];
+        if (fresh) {                                            // new_state: the fresh board replaces the finished one
+            v = 0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) v = (cfg.start_heads[p] == c) ? p + 1 : v;
+            gb[c] = (int8_t)v;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int n = v - (p + 1);                                // CyTronGrid.pyx:70-71, v in 1..P
+            n = n < 0 ? n + P : n;
+            obs_board[(int64_t)p * plane + b * NN + c] = (int8_t)(v > 0 ? n + 1 : v);
+        }
+    }
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 inline TronGeom geom_of(const crl_tron_cfg &cfg)
@@ -3085,11 +3169,16 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
         CRL_LAUNCH_CHECK();
         return CRL_OK;
     }
-    CRL_REQUIRE(actions != nullptr, "crl_tron_step_observe: this board / player count takes the unfused path, which needs "
-                                    "explicit actions (call crl_tron_sample first)");
-    int rc = crl_tron_step(ctx, B, board, heads, dirs, deaths, actions, rewards, terminal, winners, flags, stream);
-    if (rc != CRL_OK) return rc;
-    return crl_tron_observe_all(ctx, B, board, heads, dirs, deaths, obs_board, obs_heads, obs_dirs, obs_deaths, stream);
+    // every other shape: one game per workgroup, bytes (tron_step_observe_any_kernel)
+    CRL_REQUIRE(B < ((int64_t)1 << 31), "crl_tron_step_observe: B too large for the one-game-per-workgroup kernel");
+    CRL_REQUIRE(NN <= 60 * 1024, "crl_tron_step_observe: board too large for LDS");
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_step_observe_any_kernel<PP>), dim3((unsigned)B), dim3(256), (size_t)((NN + 15) & ~15), s, cfg, g, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,
+                           actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
 }
 
 int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *deaths, int8_t *rank, void *stream)

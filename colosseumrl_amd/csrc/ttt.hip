@@ -18,12 +18,6 @@
 
 namespace {
 
-struct ttt_dirs {
-    int32_t n_dirs, K, P, n_cells;
-    uint32_t full;
-    int32_t stride[13];
-    uint32_t start[13];   // bit c set: the K-window starting at cell c along this direction is on the board
-};
 
 // ND = 4 (boards with at most 4 line directions: everything 1-D / 2-D) or 13 (3-D).  Strides and start masks are plain
 // SGPR operands and no direction needs its own branch (unused slots have start == 0).  A K-window along stride s is
@@ -431,6 +425,98 @@ ttt_board_kernel(const int n_cells, const uint32_t inv_cells, const int64_t B, c
     ttt_write_boards<P>(s_occ, s_rel, n_cells, inv_cells, rel_mod, g0, B, board);
 }
 
+// ---- the same calls on states in the REFERENCE's own layout (tictactoe_2p_env.py:165-169): board int8 [B][cells], -1 =
+// empty, else the owner's id.  For callers that hold reference states -- the single-state drop-in classes above all
+// (one launch per next_state on host-mapped memory, crl_host_alloc) -- and never see the occupancy masks.  One lane per
+// game: it gathers its cells into the per-player masks, plays the very ttt_step_core of crl_ttt_step, and writes back
+// what changed.
+template <int P>
+__device__ __forceinline__ void ttt_masks_of_board(const int8_t *__restrict__ cells, const int n_cells, uint32_t (&o)[P])
+{
+#pragma unroll
+    for (int p = 0; p < P; ++p) o[p] = 0u;
+    for (int c = 0; c < n_cells; ++c) {
+        const int v = cells[c];
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] |= (v == p) ? (1u << c) : 0u;
+    }
+}
+
+// observation of one game: ids relative to `rel` (python's non-negative modulo by rel_mod), -1 stays -1
+template <int P>
+__device__ __forceinline__ void ttt_write_relative(const uint32_t (&o)[P], const int n_cells, const int rel, const int rel_mod,
+                                                   int8_t *__restrict__ out)
+{
+    for (int c = 0; c < n_cells; ++c) {
+        int v = -1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) v = ((o[p] >> c) & 1u) ? p : v;
+        if (v >= 0 && rel >= 0) {
+            const int rr = (v - rel) % rel_mod;
+            v = rr < 0 ? rr + rel_mod : rr;
+        }
+        out[c] = (int8_t)v;
+    }
+}
+
+template <int P, int ND>
+__global__ void __launch_bounds__(256)
+ttt_step_board_kernel(const ttt_dirs dd, const int64_t B, int8_t *__restrict__ board, int8_t *__restrict__ winner,
+                      int8_t *__restrict__ to_move, const int8_t *__restrict__ action, int8_t *__restrict__ reward,
+                      uint8_t *__restrict__ terminal, int8_t *__restrict__ winners, uint32_t *__restrict__ valid,
+                      int8_t *__restrict__ obs, const int rel_mod, const uint32_t flags)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int8_t *cells = board + b * dd.n_cells;
+    uint32_t o[P];
+    ttt_masks_of_board<P>(cells, dd.n_cells, o);
+    uint32_t before = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) before |= o[p];
+    int w = winner[b], tm = to_move[b], r, t, ws;
+    const int pl = tm, act = action[b];
+    ttt_step_core<P, ND>(dd, o, w, tm, act, r, t, ws);
+    reward[b] = (int8_t)r;
+    terminal[b] = (uint8_t)t;
+    winners[b] = (int8_t)ws;
+    uint32_t all = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) all |= o[p];
+    if (t && (flags & CRL_STEP_AUTO_RESET)) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = 0;
+        all = 0; w = -1; tm = 0;
+        for (int c = 0; c < dd.n_cells; ++c) cells[c] = (int8_t)-1;
+    } else if (all != before) {
+        cells[act] = (int8_t)pl;                   // the one cell the move filled (tictactoe_2p_env.py:295)
+    }
+    winner[b] = (int8_t)w;
+    to_move[b] = (int8_t)tm;
+    if (valid) valid[b] = dd.full & ~all;          // valid_actions of the player to move next (:317-348)
+    if (obs) ttt_write_relative<P>(o, dd.n_cells, tm, rel_mod, obs + b * dd.n_cells);
+}
+
+// valid_actions (empties mask) and / or state_to_observation (ids relative to player[b]) of reference-layout boards
+template <int P>
+__global__ void __launch_bounds__(256)
+ttt_observe_board_kernel(const int n_cells, const uint32_t full, const int64_t B, const int8_t *__restrict__ board,
+                         const int8_t *__restrict__ player, const int rel_mod, int8_t *__restrict__ obs,
+                         uint32_t *__restrict__ valid)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t o[P];
+    ttt_masks_of_board<P>(board + b * n_cells, n_cells, o);
+    if (valid) {
+        uint32_t all = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) all |= o[p];
+        valid[b] = full & ~all;
+    }
+    if (obs) ttt_write_relative<P>(o, n_cells, player ? (int)player[b] : -1, rel_mod, obs + b * n_cells);
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // host: enumerate directions / lines exactly like the oracle does, independently written
@@ -468,14 +554,7 @@ int build_dirs(const crl_ttt_cfg &c, ttt_dirs &dd, uint32_t *lines, int &n_lines
     return 0;
 }
 
-ttt_dirs dirs_of(const crl_ctx *ctx)
-{
-    ttt_dirs dd;
-    uint32_t tmp[CRL_TTT_MAX_LINES];
-    int n;
-    build_dirs(ctx->ttt, dd, tmp, n);
-    return dd;
-}
+inline const ttt_dirs &dirs_of(const crl_ctx *ctx) { return ctx->ttt_dd; }     // built once, in crl_ttt_create
 
 } // namespace
 
@@ -518,6 +597,7 @@ int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out)
         return CRL_EUNSUPPORTED;
     }
     c->ttt.n_lines = n_lines;
+    c->ttt_dd = dd;
     *out = c;
     return CRL_OK;
 }
@@ -619,6 +699,44 @@ int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t 
             hipLaunchKernelGGL((ttt_step_observe_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd,
                                inv_cells, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, occ, winner, to_move, action,
                                tcount, reward, terminal, winners, obs_board, valid, rel_mod, flags);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_step_board(const crl_ctx *ctx, int64_t B, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
+                       int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
+                       uint32_t flags, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_step_board");
+    CRL_REQUIRE(board && winner && to_move, "crl_ttt_step_board: NULL state pointer");
+    CRL_REQUIRE(action && reward && terminal && winners, "crl_ttt_step_board: NULL action/output pointer");
+    CRL_REQUIRE(obs_board == nullptr || rel_mod >= 1, "crl_ttt_step_board: rel_mod must be >= 1 when obs_board is given");
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_ttt_step_board: unknown flags 0x%x", flags);
+    const ttt_dirs dd = dirs_of(ctx);
+    const int rm = rel_mod < 1 ? 1 : rel_mod;
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        if (dd.n_dirs <= 4)
+            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags);
+        else
+            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_ttt_observe_board(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *player, int rel_mod,
+                          int8_t *obs_board, uint32_t *valid, void *stream)
+{
+    TTT_CTX_CHECK("crl_ttt_observe_board");
+    CRL_REQUIRE(board != nullptr, "crl_ttt_observe_board: board is NULL");
+    CRL_REQUIRE(obs_board || valid, "crl_ttt_observe_board: nothing to compute (obs_board and valid are NULL)");
+    CRL_REQUIRE(player == nullptr || rel_mod >= 1, "crl_ttt_observe_board: rel_mod must be >= 1 when player is given");
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        hipLaunchKernelGGL((ttt_observe_board_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream,
+                           ctx->ttt.n_cells, ctx->ttt.full, B, board, player, rel_mod < 1 ? 1 : rel_mod, obs_board, valid);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

@@ -2,7 +2,8 @@
 
 Same state tuple ``(Board, round_count, [AI x 4])``, action strings and return types as the reference
 (colosseumrl/envs/blokus/BlokusEnvironment.py:188-768).  Move generation and the step rule run on the GPU
-through a B=1 ``BlokusBatch`` (HIP kernels behind the C ABI); without an MI355X these methods raise.
+through ``colosseumrl_amd.single.SingleBlokus`` (HIP kernels behind the C ABI on host memory the GPU maps: no copies, one
+synchronise per call); without an MI355X these methods raise.
 For throughput use ``colosseumrl_amd.batched.BlokusBatch`` directly.
 """
 from typing import Dict, List, Tuple, Union
@@ -36,6 +37,7 @@ class BlokusEnvironment(BaseEnvironment):
         super().__init__(config)
         self._device = device
         self._stepper = None
+        self._seen = None      # (state key, mover, ordered legal ids, observation) of the state the last next_state returned
 
     @property
     def min_players(self) -> int:
@@ -62,51 +64,50 @@ class BlokusEnvironment(BaseEnvironment):
         return ORIENTATIONS
 
     # ---- device plumbing ------------------------------------------------------------------
-    def _batch(self):
+    def _single(self):
+        """The single-state HIP stepper behind this instance (``colosseumrl_amd.single.SingleBlokus``: host-mapped
+        staging, private stream; created on first use; raises without a GPU)."""
         if self._stepper is None:
-            from ...batched import BlokusBatch
-            self._stepper = BlokusBatch(1, device=self._device)
+            from ...single import SingleBlokus
+            self._stepper = SingleBlokus()
         return self._stepper
 
-    def _upload(self, state, mover: int):
-        import torch
+    @staticmethod
+    def _key(state):
+        """Value identity of a state: board bytes, round, and every player's (score, inventory)."""
         board, round_count, players = state
-        bb = self._batch()
-        cells = np.asarray(board.board_contents)
-        occ = np.zeros((1, 4, 20), dtype=np.uint32)
-        weights = (np.uint32(1) << np.arange(20, dtype=np.uint32))
-        for c in range(4):
-            occ[0, c] = ((cells == c + 1).astype(np.uint32) * weights[None, :]).sum(axis=1)
-        bb.occ.copy_(torch.from_numpy(occ.view(np.int32)))
-        inv = np.array([[sum(1 << PIECE_NAME_TO_INDEX[p] for p in ai.current_pieces) for ai in players]], dtype=np.int32)
-        bb.inv.copy_(torch.from_numpy(inv))
-        bb.score.copy_(torch.from_numpy(np.array([[ai.player_score for ai in players]], dtype=np.int32)))
-        bb.round.fill_(int(round_count))
-        bb.to_move.fill_(int(mover))
-        return bb
+        return (np.asarray(board.board_contents).tobytes(), int(round_count),
+                tuple((int(ai.player_score), tuple(ai.current_pieces)) for ai in players))
 
-    def _download(self, bb):
+    def _load(self, state, mover: int):
+        board, round_count, players = state
+        st = self._single()
+        inv = [sum(1 << PIECE_NAME_TO_INDEX[p] for p in ai.current_pieces) for ai in players]
+        st.load(board.board_contents, inv, [ai.player_score for ai in players], int(round_count), int(mover))
+        return st
+
+    def _unload(self, st):
+        """The stepper's state as the reference's ``(Board, round_count, [AI x 4])`` objects."""
+        v = st.v
         board = Board()
-        board.board_contents = bb.board().cpu().numpy().astype(np.int64).reshape(20, 20)
-        inv = bb.inv.cpu().numpy().view(np.uint32)[0]
-        score = bb.score.cpu().numpy()[0]
+        board.board_contents = v["board"].astype(np.int64).reshape(20, 20)
         players = []
         for c in range(4):
             ai = AI(board, c + 1)
-            ai.player_score = int(score[c])
-            ai.current_pieces = [name for i, name in enumerate(A.PIECE_NAMES) if (int(inv[c]) >> i) & 1]
+            ai.player_score = int(v["score"][c])
+            mask = int(v["inv"][c])
+            ai.current_pieces = [name for i, name in enumerate(A.PIECE_NAMES) if (mask >> i) & 1]
             players.append(ai)
-        return board, int(bb.round.cpu().numpy()[0]), players
+        return board, int(v["round"][0]), players
 
     def _legal_ids(self, state, player: int) -> np.ndarray:
-        """Dense ids of every legal action of `player`, ascending (= reference order)."""
-        import torch
-        bb = self._upload(state, player)
-        count, mask = bb.valid(player=torch.tensor([player], dtype=torch.int8, device=bb.device), want_mask=True)
-        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8)[0], bitorder="little")
-        ids = np.nonzero(bits)[0]
-        assert len(ids) == int(count.cpu().numpy()[0])
-        return ids
+        """Dense ids of every legal action of `player`, ascending (= reference order): the compacted list the GPU
+        writes (``crl_blokus_valid_list``); for the state and mover the last ``next_state`` returned it is already
+        there."""
+        seen = self._seen
+        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+            return seen[2]
+        return self._load(state, player).legal_ids(player)
 
     # ---- dynamics ---------------------------------------------------------------------------
     def new_state(self, num_players: int = 4) -> State:
@@ -134,25 +135,31 @@ class BlokusEnvironment(BaseEnvironment):
         return [p.player_score for p in state[2]]
 
     def next_state(self, state: object, players: List[int], actions: List[str]):
-        """One move (or pass ``''``) of ``players[0]`` (reference :357-451), evaluated by the HIP kernel.
+        """One move (or pass ``''``) of ``players[0]`` (reference :357-451), evaluated by the HIP kernels on
+        host-mapped memory: pack -> step (+ the next mover's observation) -> board -> the next mover's ordered legal
+        list, four launches on one stream, no copies, one synchronise.
 
         As in the reference the action is NOT checked for legality here (callers use ``is_valid_action``);
         a piece missing from the mover's inventory raises ``ValueError`` like ``list.remove`` does there.
         """
-        import torch
         player_num, action = players[0], actions[0]
         action_id = A.string_to_id(action) if len(action) > 0 else A.PASS
         if action_id >= 0:
             piece_name = A.PIECE_NAMES[action_id // 16000]
             if piece_name not in state[2][player_num].current_pieces:
                 raise ValueError("list.remove(x): x not in list")
-        bb = self._upload(state, player_num)
-        reward, terminal, winners = bb.step(torch.tensor([action_id], dtype=torch.int32, device=bb.device))
-        new_state = self._download(bb)
-        term = bool(terminal.cpu().numpy()[0])
-        wmask = int(winners.cpu().numpy()[0])
+        st = self._load(state, player_num)
+        st.step(action_id)
+        v = st.v
+        new_state = self._unload(st)
+        mover = int(v["to_move"][0])
+        term = bool(v["terminal"][0])
+        wmask = int(v["winners"][0])
         win = [p for p in range(4) if (wmask >> p) & 1] if term else None
-        return new_state, [int(bb.to_move.cpu().numpy()[0])], [int(reward.cpu().numpy()[0])], term, win
+        obs = {"board": v["obs_board"].astype(np.int64).reshape(20, 20), "pieces": v["obs_pieces"].copy().reshape(4, 21),
+               "score": v["obs_score"].astype(np.int64), "player": np.array([mover])}
+        self._seen = (self._key(new_state), mover, st.ids(), obs)
+        return new_state, [mover], [int(v["reward"][0])], term, win
 
     def valid_actions(self, state: object, player: int) -> List[str]:
         """Every legal action string in the reference's order, or ``['']`` (reference :453-500)."""
@@ -194,27 +201,36 @@ class BlokusEnvironment(BaseEnvironment):
         return action_to_string(piece_type, index, name + offset)
 
     def is_valid_action(self, state: object, player: int, action: str) -> bool:
-        """Membership in the legal-move set of ``player`` (reference :667-719); ``''`` is never valid."""
+        """Membership in the legal-move set of ``player`` (reference :667-719); ``''`` is never valid.  Tested on the
+        GPU directly (``crl_blokus_is_valid``: piece held, anchor, every cell allowed) instead of enumerating."""
         if len(action) == 0:
             return False
         piece_type, index, orientation = string_to_action(action)
         try:
             o = A.ORIENTATION_INDEX[orientation[:-1]]
-            wanted = A.encode(PIECE_NAME_TO_INDEX[piece_type], index[0], index[1], o, int(orientation[-1]))
+            shift = int(orientation[-1])
+            piece = PIECE_NAME_TO_INDEX[piece_type]
         except (KeyError, ValueError, IndexError):
             return False
-        if not (0 <= index[0] < 20 and 0 <= index[1] < 20):
+        if not (0 <= index[0] < 20 and 0 <= index[1] < 20 and 0 <= shift < 5):
             return False
-        return bool(np.isin(wanted, self._legal_ids(state, player)))
+        wanted = A.encode(piece, index[0], index[1], o, shift)
+        seen = self._seen
+        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+            ids = seen[2]
+            k = int(np.searchsorted(ids, wanted))
+            return bool(k < len(ids) and ids[k] == wanted)
+        return self._load(state, player).is_valid(player, wanted)
 
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
         """Relative player ids (-1 empty), board rotated into the observer's viewpoint, inventories as a
         (4, 21) uint8 matrix in relative player order, scores rolled (reference :721-768); evaluated by
-        ``crl_blokus_observe``."""
-        import torch
-        bb = self._upload(state, player)
-        obs = bb.observe(torch.tensor([player], dtype=torch.int8, device=bb.device))
-        return {"board": obs["board"].cpu().numpy().astype(np.int64).reshape(20, 20),
-                "pieces": obs["pieces"].cpu().numpy().reshape(4, 21),
-                "score": obs["score"].cpu().numpy().astype(np.int64).reshape(4),
-                "player": np.array([player])}
+        ``crl_blokus_observe`` (already done by the fused step for the state and mover ``next_state`` returned)."""
+        seen = self._seen
+        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+            return {k: a.copy() for k, a in seen[3].items()}
+        st = self._load(state, player)
+        st.observe(player)
+        v = st.v
+        return {"board": v["obs_board"].astype(np.int64).reshape(20, 20), "pieces": v["obs_pieces"].copy().reshape(4, 21),
+                "score": v["obs_score"].astype(np.int64), "player": np.array([player])}

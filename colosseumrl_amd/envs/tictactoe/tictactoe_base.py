@@ -3,7 +3,8 @@
 The three reference envs (colosseumrl/envs/tictactoe/tictactoe_{2,3,4}p_env.py) are the
 same program with a different board shape and player count; here they are one
 class parameterised by ``SHAPE``/``PLAYERS``/``K`` whose rules run on the GPU through
-``colosseumrl_amd.batched.TTTBatch`` (bit-mask state, B=1).
+``colosseumrl_amd.single.SingleTTT`` (the reference's own board layout in host memory the GPU maps; one launch and one
+synchronise per call, no copies).
 
 State: ``(board int8[SHAPE] with -1 = empty, winner: None | int)`` as in the reference
 (tictactoe_2p_env.py:165-169).  Canonical action string: ``str(tuple_of_python_ints)``,
@@ -42,6 +43,9 @@ class TicTacToeEnvBase(BaseEnvironment):
         super().__init__(config)
         self._device = device
         self._stepper = None
+        self._seen = None      # (state key, empties mask, mover, observation) of the state the last next_state returned
+        self._n_cells = int(np.prod(self.SHAPE))
+        self._cell_strings = [action_to_string(np.unravel_index(c, self.SHAPE)) for c in range(self._n_cells)]
 
     @property
     def min_players(self) -> int:
@@ -60,23 +64,30 @@ class TicTacToeEnvBase(BaseEnvironment):
         return ["board"]
 
     # ---- device plumbing ------------------------------------------------------------------
-    def _batch(self):
+    def _single(self):
+        """The single-state HIP stepper behind this instance (``colosseumrl_amd.single.SingleTTT``: host-mapped staging,
+        private stream; created on first use; raises without a GPU)."""
         if self._stepper is None:
-            from ...batched import TTTBatch
-            self._stepper = TTTBatch(self.SHAPE, self.K, self.PLAYERS, 1, device=self._device)
+            from ...single import SingleTTT
+            self._stepper = SingleTTT(self.SHAPE, self.K, self.PLAYERS, self.REL_MOD)
         return self._stepper
 
-    def _upload(self, state, mover: int):
-        import torch
-        board, winner = state
-        flat = np.asarray(board).ravel()
-        tb = self._batch()
-        masks = [int(sum(1 << int(c) for c in np.nonzero(flat == p)[0])) for p in range(self.PLAYERS)]
-        occ = np.array(masks, dtype=np.uint32).view(np.int32).reshape(-1, 1)
-        tb.occ.copy_(torch.from_numpy(occ))
-        tb.winner.fill_(-1 if winner is None else int(winner))
-        tb.to_move.fill_(int(mover))
-        return tb
+    @staticmethod
+    def _key(state):
+        try:
+            return (state[0].tobytes(), state[1])
+        except AttributeError:
+            return None
+
+    def _valid_mask(self, state) -> int:
+        """Empties bit mask of ``state`` (computed on the GPU; for the state the last ``next_state`` returned the fused
+        launch has already produced it)."""
+        seen = self._seen
+        if seen is not None and seen[0] == self._key(state):
+            return seen[1]
+        st = self._single()
+        st.load(state[0], state[1], 0)
+        return st.valid()
 
     def _cell_of(self, index) -> int:
         """Flat cell of an index tuple with Python indexing rules (negative wraps, out of range raises)."""
@@ -116,26 +127,27 @@ class TicTacToeEnvBase(BaseEnvironment):
         return [0 for _ in range(self.max_players)]
 
     def next_state(self, state: object, players: List[int], actions: List[str]):
-        """One move of ``players[0]`` (reference 2p:240-315), evaluated by the HIP kernel."""
-        import torch
+        """One move of ``players[0]`` (reference 2p:240-315), evaluated by the HIP kernel: one launch on host-mapped
+        memory (``crl_ttt_step_board``: the move, the win test, and -- for the new state -- the empties mask and the
+        next mover's observation, which ``valid_actions`` / ``state_to_observation`` then serve without a GPU call)."""
         action, player_num = actions[0], players[0]
         cell = -1
         if len(action) > 0:
             cell = self._cell_of(string_to_action(action))     # same exceptions as the reference's board[index]
-        tb = self._upload(state, player_num)
-        reward, terminal, winners = tb.step(torch.tensor([cell], dtype=torch.int8, device=tb.device))
-        board = tb.board().cpu().numpy().reshape(self.SHAPE)
-        w = int(tb.winner.cpu().numpy()[0])
-        ws = int(winners.cpu().numpy()[0])
-        return ((board, None if w < 0 else w), [int(tb.to_move.cpu().numpy()[0])],
-                [int(reward.cpu().numpy()[0])], bool(terminal.cpu().numpy()[0]), None if ws < 0 else [ws])
+        st = self._single()
+        st.load(state[0], state[1], player_num)
+        st.step(cell)
+        v = st.v
+        board = v["board"].copy().reshape(self.SHAPE)
+        w, ws, mover = int(v["winner"][0]), int(v["winners"][0]), int(v["to_move"][0])
+        new_state = (board, None if w < 0 else w)
+        self._seen = (self._key(new_state), int(v["valid"][0]), mover, v["obs_board"].copy())
+        return (new_state, [mover], [int(v["reward"][0])], bool(v["terminal"][0]), None if ws < 0 else [ws])
 
     def valid_actions(self, state: object, player: int) -> List[str]:
         """Every empty cell in row-major order, or ``['']`` when the board is full (reference 2p:317-348)."""
-        tb = self._upload(state, player)
-        mask = int(tb.valid_mask().cpu().numpy().view(np.uint32)[0])
-        cells = [c for c in range(tb.n_cells) if (mask >> c) & 1]
-        out = [action_to_string(np.unravel_index(c, self.SHAPE)) for c in cells]
+        mask = self._valid_mask(state)
+        out = [self._cell_strings[c] for c in range(self._n_cells) if (mask >> c) & 1]
         return out if out else [""]
 
     def is_valid_action(self, state: object, player_num: int, action: str) -> bool:
@@ -143,14 +155,14 @@ class TicTacToeEnvBase(BaseEnvironment):
         if len(action) == 0:
             return False
         cell = self._cell_of(string_to_action(action))
-        tb = self._upload(state, player_num)
-        mask = int(tb.valid_mask().cpu().numpy().view(np.uint32)[0])
-        return bool((mask >> cell) & 1)
+        return bool((self._valid_mask(state) >> cell) & 1)
 
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
         """Board with ids relative to the observer (reference 2p:382-407; modulus per file, see REL_MOD)."""
-        import torch
-        tb = self._upload(state, player)
-        pl = torch.tensor([player], dtype=torch.int8, device=tb.device)
-        board = tb.board(pl, self.REL_MOD).cpu().numpy().reshape(self.SHAPE)
-        return {"board": board}
+        seen = self._seen
+        if seen is not None and seen[2] == player and seen[0] == self._key(state):
+            return {"board": seen[3].copy().reshape(self.SHAPE)}
+        st = self._single()
+        st.load(state[0], state[1], 0)
+        st.observe(player)
+        return {"board": st.v["obs_board"].copy().reshape(self.SHAPE)}

@@ -5,8 +5,8 @@ state tuple ``(board int64[N,N], heads int64[P], directions int64[P],
 deaths int64[P])``, action strings and return types as the reference
 (colosseumrl/envs/tron/TronGridEnvironment.py:61-508).  The game rules are NOT
 evaluated in Python: ``next_state``/``new_state``/``state_to_observation``
-upload the state into a B=1 ``TronBatch`` and run the HIP kernels; without an
-MI355X they raise.  For throughput use ``colosseumrl_amd.batched.TronBatch``
+write the state into host memory the GPU maps (``colosseumrl_amd.single.SingleTron``) and run the HIP kernels on it --
+no copies, one launch and one synchronise per call; without an MI355X they raise.  For throughput use ``colosseumrl_amd.batched.TronBatch``
 directly -- this class exists so existing agents and servers drop in unchanged.
 """
 from time import time
@@ -68,6 +68,8 @@ class TronGridEnvironment(BaseEnvironment):
         self._moves = np.zeros(num_players, dtype=np.int64)
         self._device = device
         self._stepper = None
+        self._start_boards = {}                      # spawn layout -> start board (new_state)
+        self._observed = None                        # (state key, observations of all players) of the last next_state
 
     def __repr__(self):
         return ("Tron Finite Grid Environment\n" + "=" * 50 + "\n"
@@ -97,29 +99,22 @@ class TronGridEnvironment(BaseEnvironment):
         return {"board": (self.N, self.N), "heads": p, "directions": p, "deaths": p}
 
     # ---- device plumbing ------------------------------------------------------------------
-    def _batch(self):
-        """The B=1 HIP stepper behind this instance (created on first use; raises without a GPU)."""
+    def _single(self):
+        """The single-state HIP stepper behind this instance: host-mapped staging + private stream
+        (``colosseumrl_amd.single.SingleTron``; created on first use; raises without a GPU)."""
         if self._stepper is None:
-            from ...batched import TronBatch
-            self._stepper = TronBatch(self.N, self.num_players, 1, device=self._device)
+            from ...single import SingleTron
+            # (the context's spawn layout only matters to auto-reset, which the single-state calls never ask for)
+            self._stepper = SingleTron(self.N, self.num_players, list(range(self.num_players)), [0] * self.num_players)
         return self._stepper
 
-    def _upload(self, state):
-        import torch
-        board, heads, directions, deaths = state
-        tb = self._batch()
-        tb.board.copy_(torch.from_numpy(np.ascontiguousarray(board, dtype=np.int64).reshape(1, -1).astype(np.int8)))
-        tb.heads.copy_(torch.from_numpy(np.asarray(heads, dtype=np.int64).reshape(-1, 1).astype(np.int16)))
-        tb.dirs.copy_(torch.from_numpy(np.asarray(directions, dtype=np.int64).reshape(-1, 1).astype(np.int8)))
-        tb.deaths.copy_(torch.from_numpy(np.asarray(deaths, dtype=np.int64).reshape(-1, 1).astype(np.int8)))
-        return tb
-
-    def _download(self, tb):
-        n = self.N
-        return (tb.board.cpu().numpy().astype(np.int64).reshape(n, n),
-                tb.heads.cpu().numpy().astype(np.int64).reshape(-1),
-                tb.dirs.cpu().numpy().astype(np.int64).reshape(-1),
-                tb.deaths.cpu().numpy().astype(np.int64).reshape(-1))
+    @staticmethod
+    def _key(state):
+        """Value identity of a state (bytes of its four arrays), or None for anything that is not four numpy arrays."""
+        try:
+            return (state[0].tobytes(), state[1].tobytes(), state[2].tobytes(), state[3].tobytes())
+        except AttributeError:
+            return None
 
     # ---- dynamics ---------------------------------------------------------------------------
     def generate_start_positions(self, ring_offset: int = 1, spawn_offset=0):
@@ -135,28 +130,40 @@ class TronGridEnvironment(BaseEnvironment):
         return np.asarray(heads, dtype=np.int64), np.asarray(dirs, dtype=np.int64)
 
     def new_state(self, num_players: int = None, ring_offset: int = 1, spawn_offset=2):
-        """Initial state and the acting players (reference :228-263)."""
+        """Initial state and the acting players (reference :228-263).  The board of a given spawn layout is produced
+        once by the GPU's reset kernel (``crl_tron_reset``) and served from a per-instance cache afterwards."""
         num_players = self.num_players if num_players is None else num_players
         assert num_players == self.num_players, "Do not change the number of players from the game configuration."
         np.random.seed(int(time()))                   # reference :255 (observable only with tuple offsets)
         heads, directions = self.generate_start_positions(ring_offset, spawn_offset)
-        from ...batched import TronBatch
-        tb = TronBatch(self.N, self.num_players, 1, device=self._device, start=(heads.tolist(), directions.tolist()))
-        return self._download(tb), self.player_array
+        key = (heads.tobytes(), directions.tobytes())
+        board = self._start_boards.get(key)
+        if board is None:
+            from ...single import SingleTron
+            fresh = SingleTron(self.N, self.num_players, heads.tolist(), directions.tolist())
+            fresh.reset()
+            board = fresh.state64()[0]
+            if len(self._start_boards) < 4096:
+                self._start_boards[key] = board
+        return (board.copy(), heads, directions, np.zeros(self.num_players, dtype=np.int64)), self.player_array
 
     def next_state(self, state: object, players: List[int], actions: List[str]):
-        """One simultaneous move of every listed player (reference :265-323), evaluated on the GPU."""
-        import torch
+        """One simultaneous move of every listed player (reference :265-323), evaluated on the GPU: one fused launch
+        (next_state + the observations of every player of the new state, which ``state_to_observation`` then serves
+        without another GPU call), no copies, one synchronise."""
         for player, action in zip(players, actions):
             self._moves[player] = self.STRING_TO_ACTION[action]      # KeyError on an unknown string, like the reference
-        tb = self._upload(state)
-        act = torch.from_numpy(self._moves.astype(np.int8).reshape(-1, 1)).to(tb.device)
-        rewards, terminal, winners = tb.step(act)
-        new_state = self._download(tb)
-        deaths = new_state[3]
-        new_players = np.where(deaths == 0)[0]
-        rewards = rewards.cpu().numpy().astype(np.int64).reshape(-1)
-        term = np.bool_(bool(terminal.cpu().numpy()[0]))
+        st = self._single()
+        st.load(*state)
+        st.step_observe(self._moves)
+        new_state = st.state64()
+        v = st.v
+        P, NN = self.num_players, self.N * self.N
+        self._observed = (self._key(new_state), v["obs_board"].copy(), v["obs_heads"].copy(), v["obs_dirs"].copy(),
+                          v["obs_deaths"].copy())
+        new_players = np.where(new_state[3] == 0)[0]
+        rewards = v["rewards"].astype(np.int64)
+        term = np.bool_(bool(v["terminal"][0]))
         return new_state, new_players, rewards, term, (new_players if term else None)
 
     def valid_actions(self, state: object, player: int) -> List[str]:
@@ -166,14 +173,27 @@ class TronGridEnvironment(BaseEnvironment):
         return True                                   # reference :343-361
 
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
-        """Board relabelled so the observer is player 1; per-player vectors rolled (reference :363-420)."""
-        import torch
-        tb = self._upload(state)
-        obs = tb.observe(torch.tensor([player], dtype=torch.int8, device=tb.device))
-        board = obs["board"].cpu().numpy().astype(np.int64).reshape(self.N, self.N)
-        heads = obs["heads"].cpu().numpy().astype(np.int64).reshape(-1)
-        directions = obs["directions"].cpu().numpy().astype(np.int64).reshape(-1)
-        deaths = obs["deaths"].cpu().numpy().astype(np.int64).reshape(-1)
+        """Board relabelled so the observer is player 1; per-player vectors rolled (reference :363-420).  For the
+        state the last ``next_state`` returned the observation is already there (the fused launch wrote it for
+        every player); any other state takes one ``crl_tron_observe`` call."""
+        P, N = self.num_players, self.N
+        NN = N * N
+        seen = self._observed
+        pl = player if 0 <= player < P else 0         # ids outside 0..P-1 observe as player 0 (crl_tron_observe)
+        if seen is not None and seen[0] == self._key(state):
+            board = seen[1][pl * NN:(pl + 1) * NN].astype(np.int64).reshape(N, N)
+            heads = seen[2][pl * P:(pl + 1) * P].astype(np.int64)
+            directions = seen[3][pl * P:(pl + 1) * P].astype(np.int64)
+            deaths = seen[4][pl * P:(pl + 1) * P].astype(np.int64)
+        else:
+            st = self._single()
+            st.load(*state)
+            st.observe(player)
+            v = st.v
+            board = v["obs_board"][:NN].astype(np.int64).reshape(N, N)
+            heads = v["obs_heads"][:P].astype(np.int64)
+            directions = v["obs_dirs"][:P].astype(np.int64)
+            deaths = v["obs_deaths"][:P].astype(np.int64)
         if self.fully_observable:
             return {"board": board, "heads": heads, "directions": directions, "deaths": deaths}
         # unfinished window branch of the reference (:407-420): no 'directions', python slice semantics
@@ -208,7 +228,8 @@ class TronGridEnvironment(BaseEnvironment):
     def compute_ranking(self, state: object, players: List[int], winners: List[int]) -> Dict[int, int]:
         """Competition ranking by trail length with the mutual-kill tie rule (reference :483-508), on the GPU
         (``crl_tron_ranking``).  Keys are numpy integers ordered by rank like the reference's ``most_common()`` walk."""
-        tb = self._upload(state)
-        ranks = tb.ranking().cpu().numpy().reshape(-1)
+        st = self._single()
+        st.load(*state)
+        ranks = st.ranking().copy()
         order = sorted(range(len(ranks)), key=lambda p: (int(ranks[p]), p))
         return {np.int64(p): int(ranks[p]) for p in order}

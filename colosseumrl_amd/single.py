@@ -1,0 +1,284 @@
+"""Single-state steppers on host-mapped memory: what the drop-in ``BaseEnvironment`` classes run.
+
+The reference's API is one state per call (``match_server.py:193,201-203,218``, ``ClientEnvironment.py:327-328``).
+A B = 1 call through device tensors costs a dozen blocking copies (round 2: ~165 us per ``next_state``); here every
+env instance owns ONE block of page-locked host memory that the GPU maps (``crl_host_alloc``) and a private stream:
+the call writes the reference-layout state into numpy views of that block, the HIP kernels read it and write their
+results there over PCIe, and one ``crl_stream_synchronize`` ends the call -- no hipMemcpy, one blocking operation.
+The kernels are the very ones of the batched steppers (same C ABI, B = 1).  No torch tensors are involved.
+
+No CPU path: constructing a stepper without a visible MI355X raises.
+"""
+import ctypes as C
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+
+from . import _native
+from ._native import check
+
+
+class HostBlob:
+    """`crl_host_alloc` memory carved into named numpy views (``.v[name]``) with their device addresses (``.d[name]``)."""
+
+    def __init__(self, lib, fields: Sequence[Tuple[str, type, int]]):
+        self._lib = lib
+        offs, off = {}, 0
+        for name, dtype, count in fields:
+            off = (off + 15) & ~15
+            offs[name] = (off, np.dtype(dtype), int(count))
+            off += np.dtype(dtype).itemsize * int(count)
+        self.nbytes = max(off, 16)
+        host, dev = C.c_void_p(), C.c_void_p()
+        check(lib.crl_host_alloc(self.nbytes, C.byref(host), C.byref(dev)), "crl_host_alloc")
+        self._host = host
+        raw = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(host.value))
+        self.v: Dict[str, np.ndarray] = {}
+        self.d: Dict[str, C.c_void_p] = {}
+        for name, (o, dt, n) in offs.items():
+            self.v[name] = raw[o:o + dt.itemsize * n].view(dt)
+            self.d[name] = C.c_void_p(dev.value + o)
+
+    def __del__(self):
+        try:
+            if self._host:
+                self.v.clear()
+                self._lib.crl_host_free(self._host)
+                self._host = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class _Single:
+    """Context + stream + blob of one env instance."""
+
+    def __init__(self):
+        self._lib = _native.require_gpu()
+        self._handle = C.c_void_p()
+        self._stream = C.c_void_p()
+
+    def _open_stream(self):
+        check(self._lib.crl_stream_create(C.byref(self._stream)), "crl_stream_create")
+
+    def sync(self):
+        rc = self._lib.crl_stream_synchronize(self._stream)
+        if rc:
+            check(rc, "crl_stream_synchronize")
+
+    def __del__(self):
+        try:
+            if self._stream:
+                self._lib.crl_stream_destroy(self._stream)
+                self._stream = None
+            if self._handle:
+                self._lib.crl_destroy(self._handle)
+                self._handle = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class SingleTron(_Single):
+    """One Tron game in the reference's layout (board [N*N], heads / dirs / deaths [P]) on host-mapped memory."""
+
+    def __init__(self, board_size: int, num_players: int, start_heads: Sequence[int], start_dirs: Sequence[int]):
+        super().__init__()
+        lib, N, P = self._lib, int(board_size), int(num_players)
+        self.N, self.P, self.NN = N, P, N * N
+        sh = (C.c_int16 * P)(*[int(h) for h in start_heads])
+        sd = (C.c_int8 * P)(*[int(d) for d in start_dirs])
+        check(lib.crl_tron_create(N, P, sh, sd, C.byref(self._handle)), "crl_tron_create")
+        self._open_stream()
+        NN = self.NN
+        self.blob = HostBlob(lib, [
+            ("board", np.int8, NN), ("obs_board", np.int8, P * NN), ("heads", np.int16, P), ("dirs", np.int8, P),
+            ("deaths", np.int8, P), ("actions", np.int8, P), ("rewards", np.int8, P), ("terminal", np.uint8, 1),
+            ("winners", np.uint8, 1), ("obs_heads", np.int16, P * P), ("obs_dirs", np.int8, P * P),
+            ("obs_deaths", np.int8, P * P), ("player", np.int8, 1), ("rank", np.int8, P)])
+        v, d = self.blob.v, self.blob.d
+        self.v = v
+        h, s = self._handle, self._stream
+        # argument tuples bound once (ctypes converts them per call; the pointers never change)
+        self._a_step = (h, 1, 0, 0, d["board"], d["heads"], d["dirs"], d["deaths"], d["actions"], None, d["rewards"],
+                        d["terminal"], d["winners"], d["obs_board"], d["obs_heads"], d["obs_dirs"], d["obs_deaths"], 0, s)
+        self._a_observe = (h, 1, d["board"], d["heads"], d["dirs"], d["deaths"], d["player"], d["obs_board"],
+                           d["obs_heads"], d["obs_dirs"], d["obs_deaths"], s)
+        self._a_rank = (h, 1, d["board"], d["deaths"], d["rank"], s)
+        self._a_reset = (h, 1, None, d["board"], d["heads"], d["dirs"], d["deaths"], s)
+
+    def load(self, board, heads, dirs, deaths):
+        v = self.v
+        np.copyto(v["board"], np.asarray(board).reshape(-1), casting="unsafe")
+        np.copyto(v["heads"], heads, casting="unsafe")
+        np.copyto(v["dirs"], dirs, casting="unsafe")
+        np.copyto(v["deaths"], deaths, casting="unsafe")
+
+    def state64(self):
+        """The blob's state as the reference's int64 arrays."""
+        v = self.v
+        return (v["board"].astype(np.int64).reshape(self.N, self.N), v["heads"].astype(np.int64),
+                v["dirs"].astype(np.int64), v["deaths"].astype(np.int64))
+
+    def step_observe(self, actions):
+        """next_state + the observations of all P players, one launch (``crl_tron_step_observe``)."""
+        np.copyto(self.v["actions"], actions, casting="unsafe")
+        rc = self._lib.crl_tron_step_observe(*self._a_step)
+        if rc:
+            check(rc, "crl_tron_step_observe")
+        self.sync()
+
+    def observe(self, player: int):
+        self.v["player"][0] = player
+        rc = self._lib.crl_tron_observe(*self._a_observe)
+        if rc:
+            check(rc, "crl_tron_observe")
+        self.sync()
+
+    def ranking(self):
+        rc = self._lib.crl_tron_ranking(*self._a_rank)
+        if rc:
+            check(rc, "crl_tron_ranking")
+        self.sync()
+        return self.v["rank"]
+
+    def reset(self):
+        rc = self._lib.crl_tron_reset(*self._a_reset)
+        if rc:
+            check(rc, "crl_tron_reset")
+        self.sync()
+
+
+class SingleTTT(_Single):
+    """One TicTacToe game in the reference's layout (board int8 [cells] with -1 = empty, winner, to_move)."""
+
+    def __init__(self, dims: Sequence[int], k: int, num_players: int, rel_mod: int):
+        super().__init__()
+        lib = self._lib
+        d3 = (1,) * (3 - len(dims)) + tuple(int(x) for x in dims)
+        self.n_cells = d3[0] * d3[1] * d3[2]
+        self.P = int(num_players)
+        check(lib.crl_ttt_create(d3[0], d3[1], d3[2], int(k), self.P, C.byref(self._handle)), "crl_ttt_create")
+        self._open_stream()
+        n = self.n_cells
+        self.blob = HostBlob(lib, [("board", np.int8, n), ("obs_board", np.int8, n), ("winner", np.int8, 1),
+                                   ("to_move", np.int8, 1), ("action", np.int8, 1), ("reward", np.int8, 1),
+                                   ("terminal", np.uint8, 1), ("winners", np.int8, 1), ("valid", np.uint32, 1),
+                                   ("player", np.int8, 1)])
+        v, d = self.blob.v, self.blob.d
+        self.v = v
+        h, s = self._handle, self._stream
+        self._a_step = (h, 1, d["board"], d["winner"], d["to_move"], d["action"], d["reward"], d["terminal"],
+                        d["winners"], d["valid"], d["obs_board"], int(rel_mod), 0, s)
+        self._a_valid = (h, 1, d["board"], None, int(rel_mod), None, d["valid"], s)
+        self._a_obs = (h, 1, d["board"], d["player"], int(rel_mod), d["obs_board"], d["valid"], s)
+
+    def load(self, board, winner, mover: int):
+        v = self.v
+        np.copyto(v["board"], np.asarray(board).reshape(-1), casting="unsafe")
+        v["winner"][0] = -1 if winner is None else int(winner)
+        v["to_move"][0] = int(mover)
+
+    def step(self, cell: int):
+        """next_state + empties mask and observation for the player to move next, one launch."""
+        self.v["action"][0] = cell
+        rc = self._lib.crl_ttt_step_board(*self._a_step)
+        if rc:
+            check(rc, "crl_ttt_step_board")
+        self.sync()
+
+    def valid(self) -> int:
+        rc = self._lib.crl_ttt_observe_board(*self._a_valid)
+        if rc:
+            check(rc, "crl_ttt_observe_board")
+        self.sync()
+        return int(self.v["valid"][0])
+
+    def observe(self, player: int):
+        self.v["player"][0] = player
+        rc = self._lib.crl_ttt_observe_board(*self._a_obs)
+        if rc:
+            check(rc, "crl_ttt_observe_board")
+        self.sync()
+
+
+class SingleBlokus(_Single):
+    """One Blokus game: ``Board.board_contents`` (int8 [20][20], 0 empty else colour), inventories as bit masks,
+    scores, round, mover -- on host-mapped memory; the row bitboards the kernels work on are derived on the GPU
+    (``crl_blokus_pack``) in the same stream."""
+    CAP = 4096          # legal actions per state the list can hold (observed maximum in reference games: 1,693)
+
+    def __init__(self):
+        super().__init__()
+        lib = self._lib
+        check(lib.crl_blokus_create(C.byref(self._handle)), "crl_blokus_create")
+        self._open_stream()
+        self.blob = HostBlob(lib, [
+            ("board", np.int8, 400), ("obs_board", np.int8, 400), ("occ", np.uint32, 80), ("inv", np.uint32, 4),
+            ("score", np.int32, 4), ("round", np.int32, 1), ("to_move", np.int32, 1), ("action", np.int32, 1),
+            ("reward", np.int8, 1), ("terminal", np.uint8, 1), ("winners", np.uint8, 1), ("n_valid", np.int32, 1),
+            ("obs_pieces", np.uint8, 84), ("obs_score", np.int32, 4), ("obs_player", np.int8, 1), ("player", np.int8, 1),
+            ("count", np.int32, 1), ("ok", np.uint8, 1), ("ids", np.int32, self.CAP)])
+        v, d = self.blob.v, self.blob.d
+        self.v = v
+        h, s = self._handle, self._stream
+        st = (d["occ"], d["inv"], d["score"], d["round"], d["to_move"])
+        self._a_pack = (h, 1, d["board"], d["occ"], s)
+        self._a_unpack = (h, 1, d["occ"], d["board"], s)
+        self._a_step = (h, 1, 0, 0) + st + (d["action"], None, d["reward"], d["terminal"], d["winners"], d["n_valid"],
+                                            d["obs_board"], d["obs_pieces"], d["obs_score"], d["obs_player"], 0, s)
+        self._a_list_mover = (h, 1) + st + (None, d["ids"], d["count"], self.CAP, s)
+        self._a_list = (h, 1) + st + (d["player"], d["ids"], d["count"], self.CAP, s)
+        self._a_is_valid = (h, 1) + st + (d["player"], d["action"], d["ok"], s)
+        self._a_observe = (h, 1, d["occ"], d["inv"], d["score"], d["player"], d["obs_board"], d["obs_pieces"],
+                           d["obs_score"], s)
+
+    def load(self, cells, inv_masks, scores, round_count: int, mover: int):
+        v = self.v
+        np.copyto(v["board"], np.asarray(cells).reshape(-1), casting="unsafe")
+        v["inv"][:] = inv_masks
+        v["score"][:] = scores
+        v["round"][0] = round_count
+        v["to_move"][0] = mover
+        rc = self._lib.crl_blokus_pack(*self._a_pack)              # async: the next launch on this stream sees occ
+        if rc:
+            check(rc, "crl_blokus_pack")
+
+    def step(self, action_id: int):
+        """next_state, then -- for the NEW state and its mover -- the board, the ordered legal list and the observation:
+        three launches, one synchronise."""
+        lib = self._lib
+        self.v["action"][0] = action_id
+        rc = lib.crl_blokus_step_observe(*self._a_step) or lib.crl_blokus_board(*self._a_unpack) \
+            or lib.crl_blokus_valid_list(*self._a_list_mover)
+        if rc:
+            check(rc, "crl_blokus_step_observe / board / valid_list")
+        self.sync()
+
+    def legal_ids(self, player: int) -> np.ndarray:
+        self.v["player"][0] = player
+        rc = self._lib.crl_blokus_valid_list(*self._a_list)
+        if rc:
+            check(rc, "crl_blokus_valid_list")
+        self.sync()
+        return self.ids()
+
+    def ids(self) -> np.ndarray:
+        n = int(self.v["count"][0])
+        if n > self.CAP:
+            raise _native.NativeError("%d legal Blokus actions exceed the list capacity %d" % (n, self.CAP))
+        return self.v["ids"][:n].copy()
+
+    def is_valid(self, player: int, action_id: int) -> bool:
+        self.v["player"][0] = player
+        self.v["action"][0] = action_id
+        rc = self._lib.crl_blokus_is_valid(*self._a_is_valid)
+        if rc:
+            check(rc, "crl_blokus_is_valid")
+        self.sync()
+        return bool(self.v["ok"][0])
+
+    def observe(self, player: int):
+        self.v["player"][0] = player
+        rc = self._lib.crl_blokus_observe(*self._a_observe)
+        if rc:
+            check(rc, "crl_blokus_observe")
+        self.sync()

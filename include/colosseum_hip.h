@@ -29,6 +29,7 @@
  */
 #ifndef COLOSSEUM_HIP_H
 #define COLOSSEUM_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -63,6 +64,22 @@ int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
 void crl_destroy(crl_ctx *ctx);
+
+/* ------------------------------------------------------------------ host staging for single-state callers
+ * The reference's API is one state per call (BaseEnvironment.next_state, match_server.py:201-203): for such a caller a
+ * hipMemcpy each way costs more than the step.  crl_host_alloc returns `bytes` of zeroed, page-locked host memory that
+ * the GPU maps (hipHostMalloc, mapped + coherent): every entry point of this header accepts `*device` (+ offsets)
+ * wherever it takes a DEVICE pointer, so a B = 1 call reads its state from and writes its results to host memory
+ * directly -- no copy, one crl_stream_synchronize per call.  `device` may be NULL when the caller only needs `*host`
+ * (both name the same bytes; under ROCm's unified addressing they are usually equal).
+ * crl_stream_create gives a non-blocking stream of the current device, so that env instances on different host
+ * threads (MatchmakingServer.py:128-135) do not wait for each other's work. */
+int crl_host_alloc(size_t bytes, void **host, void **device);
+int crl_host_free(void *host);
+int crl_stream_create(void **stream);
+int crl_stream_destroy(void *stream);
+/* the ONLY blocking call of the ABI besides create / destroy */
+int crl_stream_synchronize(void *stream);
 
 /* ------------------------------------------------------------------ RNG (exposed for parity tests) */
 /* out[i*4..i*4+3] = Philox-4x32-10(ctr[i*4..], key); n counters; DEVICE pointers */
@@ -165,7 +182,8 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
  * with actions == NULL meaning "draw them with the rollout's random agent at tcount[b] and advance tcount" (tcount may be
  * NULL when actions are given; it is not touched then).  The boards are read from HBM once (coalesced, into LDS),
  * stepped there, and the P relabelled copies streamed out: N*N bytes in + P*N*N bytes out per game.  Boards with
- * N*N % 16 != 0, P = 8, or boards too large for LDS take the three separate kernels internally (actions required). */
+ * N*N % 16 != 0 (the reference's default 19x19 among them), P = 8, or too large for 16 LDS slabs take a second kernel
+ * with one game per workgroup and byte accesses: still one launch, same results, actions == NULL allowed. */
 int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
                           int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                           const int8_t *actions, uint32_t *tcount,
@@ -210,6 +228,20 @@ int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t 
                          uint32_t *occ, int8_t *winner, int8_t *to_move, const int8_t *action, uint32_t *tcount,
                          int8_t *reward, uint8_t *terminal, int8_t *winners, int8_t *obs_board, uint32_t *valid,
                          int rel_mod, uint32_t flags, void *stream);
+/* The same calls on states in the REFERENCE's own layout (tictactoe_2p_env.py:165-169): board int8 [B][cells], -1 = empty,
+ * else the owner's id; winner / to_move as above.  For callers that hold reference states (the single-state drop-in
+ * classes, on crl_host_alloc memory: one launch per next_state) and never see the occupancy masks.
+ * crl_ttt_step_board == crl_ttt_step on the equivalent masks, the board updated in place (the one cell the move filled;
+ * all -1 after an auto-reset), plus -- each optional, NULL to skip -- valid uint32 [B] = empties mask of the NEW state
+ * (valid_actions of the player to move next) and obs_board int8 [B][cells] = the new board with ids relative to the
+ * player to move next (state_to_observation, _relative_player_id modulo rel_mod). */
+int crl_ttt_step_board(const crl_ctx *ctx, int64_t B, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
+                       int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
+                       uint32_t flags, void *stream);
+/* valid_actions (valid uint32 [B] empties mask; may be NULL) and / or state_to_observation (obs_board int8 [B][cells]
+ * relative to player[b] modulo rel_mod, absolute ids when player == NULL; may be NULL) of reference-layout boards */
+int crl_ttt_observe_board(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *player, int rel_mod,
+                          int8_t *obs_board, uint32_t *valid, void *stream);
 typedef struct {
     uint32_t *tcount, *tstep, *n_episodes;   /* tcount = the env's rollout step count (RNG counter) */
     uint32_t *win_count;   /* [P][B] */
@@ -266,6 +298,30 @@ int crl_blokus_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const u
  * obs_pieces uint8 [B][4][21] (row r = player (r + observer) % 4), obs_score int32 [B][4] (rolled by -observer) */
 int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                        const int8_t *player, int8_t *obs_board, uint8_t *obs_pieces, int32_t *obs_score, void *stream);
+/* The ordered legal-action LIST, compacted: what BlokusEnvironment.valid_actions returns (BlokusEnvironment.py:453-500,
+ * board.py:170-193) in a form a policy can consume for a whole batch.  count int32 [B] = number of legal actions of `player`
+ * (int8 [B]; NULL = the player to move); ids int32 [B][cap]: ids[b][0 .. min(count[b], cap)) = their dense ids in
+ * ascending order = the reference's order (piece -> anchor row-major -> orientation -> shift); entries beyond are left
+ * untouched.  Either output may be NULL.  (Observed maximum in reference-played games: 1,693 actions; cap = 2048 is safe
+ * for play from the empty board, and count tells when a list was cut.) */
+int crl_blokus_valid_list(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                          const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *ids, int32_t *count,
+                          int cap, void *stream);
+/* action[b] = dense id of the rank[b]-th (0-based) entry of that list without materialising it, -1 when rank[b] is outside
+ * [0, count): "play the r-th legal action" for caller-chosen ranks (crl_blokus_sample draws the rank itself).
+ * count (may be NULL) receives the list length. */
+int crl_blokus_select(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                      const int32_t *round, const int32_t *to_move, const int8_t *player, const int32_t *rank,
+                      int32_t *action, int32_t *count, void *stream);
+/* replaces BlokusEnvironment.is_valid_action (BlokusEnvironment.py:667-719, called per move from match_server.py:193):
+ * ok uint8 [B] = 1 iff action[b] (dense id) is in valid_actions(player) -- tested directly (piece held, the shift names a
+ * cell of the piece, that cell's target is an anchor, every cell lands on an allowed cell), no enumeration */
+int crl_blokus_is_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
+                        const int32_t *round, const int32_t *to_move, const int8_t *player, const int32_t *action,
+                        uint8_t *ok, void *stream);
+/* occ rows from Board.board_contents as int8 [B][20][20] (0 empty, else colour): the inverse of crl_blokus_board, for
+ * callers that hold reference-layout boards */
+int crl_blokus_pack(const crl_ctx *ctx, int64_t B, const int8_t *board, uint32_t *occ, void *stream);
 /* Board.board_contents as int8 [B][20][20] (0 empty, else colour) */
 int crl_blokus_board(const crl_ctx *ctx, int64_t B, const uint32_t *occ, int8_t *board, void *stream);
 /* One launch for a ply of every game, as a learner / vector env needs it: [sample ->] next_state -> number of legal actions and

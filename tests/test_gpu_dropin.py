@@ -1,0 +1,266 @@
+"""The single-state drop-in path (host-mapped staging, colosseumrl_amd/single.py) and the entry points added for it:
+reference-layout TicTacToe calls, the any-shape fused Tron step, Blokus valid_list / select / is_valid / pack."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from backends import HipBlokus, OracleBlokus, OracleTron
+from blokus_replay import GAMES, replay_games
+
+
+# ------------------------------------------------------------------ TicTacToe, reference layout
+@pytest.mark.parametrize("dims,K,P,B,rel_mod", [((3, 3), 3, 2, 1000 + 7, None), ((3, 5), 3, 3, 513, None),
+                                                ((3, 3, 3), 3, 4, 300, 3), ((5, 5), 4, 3, 257, None), ((4, 8), 4, 5, 65, None)])
+def test_ttt_reference_layout_calls_match_the_mask_calls(dims, K, P, B, rel_mod):
+    """crl_ttt_step_board / crl_ttt_observe_board (int8 boards, -1 empty) in lockstep with crl_ttt_step / _valid / _board on
+    the occupancy masks and with the oracle: legal, occupied, out-of-range and '' actions, auto-reset on and off."""
+    import torch
+    from colosseumrl_amd.batched import TTTBatch, TTTBoards
+    a, b = TTTBoards(dims, K, P, B), TTTBatch(dims, K, P, B)
+    ost = O.TTTState(dims, K, P, B)
+    cells = a.n_cells
+    rng = np.random.default_rng(cells * 7 + P)
+    ends = 0
+    for t in range(3 * cells):
+        auto = (t % 4) != 3
+        act = rng.integers(-2, cells + 1, size=B).astype(np.int8)          # includes -2, -1 ('') and cells (out of range)
+        dev = torch.from_numpy(act).cuda()
+        ra, ta, wa = a.step(dev, auto_reset=auto, rel_mod=rel_mod)
+        rb, tb_, wb = b.step(dev, auto_reset=auto)
+        assert torch.equal(ra, rb) and torch.equal(ta, tb_) and torch.equal(wa, wb), t
+        assert torch.equal(a.board, b.board()) and torch.equal(a.winner, b.winner) and torch.equal(a.to_move, b.to_move), t
+        assert torch.equal(a.valid, b.valid_mask()), t
+        assert torch.equal(a.obs, b.board(b.to_move, rel_mod)), t
+        r2, t2, w2 = O.ttt_step(ost, act)
+        assert np.array_equal(ra.cpu().numpy(), r2) and np.array_equal(ta.cpu().numpy(), t2) and np.array_equal(wa.cpu().numpy(), w2)
+        if auto:
+            m = t2.astype(bool)
+            ost.occ[:, m] = 0
+            ost.winner[m] = -1
+            ost.to_move[m] = 0
+            ends += int(m.sum())
+        assert np.array_equal(a.board.cpu().numpy(), ost.board().reshape(B, -1)), t
+        pl = torch.from_numpy(rng.integers(0, P, size=B).astype(np.int8)).cuda()
+        obs, valid = a.observe(pl, rel_mod)
+        assert torch.equal(obs, b.board(pl, rel_mod)) and torch.equal(valid, b.valid_mask())
+        obs_abs, _ = a.observe(None)
+        assert torch.equal(obs_abs, a.board)
+    assert ends > 0
+
+
+# ------------------------------------------------------------------ Tron: the fused step on every shape, sampled actions
+@pytest.mark.parametrize("N,P,B", [(19, 4, 300 + 1), (13, 8, 130), (7, 3, 70), (45, 2, 40), (16, 8, 65)])
+def test_tron_step_observe_any_shape_with_sampled_actions(N, P, B):
+    """Shapes the 16-byte fused kernel cannot take run the one-game-per-workgroup kernel: one launch, actions == None
+    allowed (round 2 raised there).  T x step_observe(None) leaves the state rollout(T) leaves, and every observation
+    equals observe_all of that state."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    seed, first, T = 31, 70, 24
+    a, b = TronBatch(N, P, B, first_env_id=first), TronBatch(N, P, B, first_env_id=first)
+    out = None
+    for t in range(T):
+        out = a.step_observe(None, seed=seed, out=out)
+        b.rollout(1, seed)
+        for k in ("board", "heads", "dirs", "deaths", "tcount"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (k, t)
+        obs = b.observe_all()
+        for k in ("board", "heads", "directions", "deaths"):
+            assert torch.equal(out[k], obs[k]), (k, t)
+
+
+@pytest.mark.parametrize("config", ["", "19;4", "13;8", "20;4", "7;2", "40;3"])
+def test_tron_dropin_vs_oracle(config):
+    """The BaseEnvironment class on host-mapped memory, random play, against the oracle one step at a time: the
+    reference's default 19x19 board among the shapes; observations of every player served after each step."""
+    from colosseumrl_amd import get_environment
+    env = get_environment("tron")(config)
+    N, P = env.N, env.num_players
+    rng = np.random.default_rng(N + P)
+    names = {0: "forward", 1: "right", -1: "left"}
+    sh, sd = O.tron_start_positions(N, P)
+    episodes = 0
+    for _ in range(6):
+        state, players = env.new_state()
+        orc = OracleTron(N, P, 1, sh, sd)
+        assert state[0].dtype == np.int64 and np.array_equal(state[0].reshape(-1), orc.st.board[0])
+        assert state[1].tolist() == list(sh) and state[2].tolist() == list(sd)
+        for t in range(200):
+            act = rng.integers(-1, 2, size=P)
+            state, players, rewards, terminal, winners = env.next_state(state, list(range(P)), [names[int(x)] for x in act])
+            r2, t2, w2 = orc.step(act.astype(np.int8).reshape(P, 1))
+            assert np.array_equal(state[0].reshape(-1), orc.st.board[0]) and np.array_equal(state[1], orc.st.heads[:, 0])
+            assert np.array_equal(state[2], orc.st.dirs[:, 0]) and np.array_equal(state[3], orc.st.deaths[:, 0])
+            assert rewards.tolist() == r2[:, 0].tolist() and bool(terminal) == bool(t2[0])
+            for p in range(P):
+                ob, oh, od, ok = O.tron_observe(orc.st, np.array([p], np.int8))
+                got = env.state_to_observation(state, p)
+                assert np.array_equal(got["board"].reshape(-1), ob[0]) and np.array_equal(got["heads"], oh[:, 0])
+                assert np.array_equal(got["directions"], od[:, 0]) and np.array_equal(got["deaths"], ok[:, 0])
+            if terminal:
+                assert sum(1 << int(w) for w in winners) == int(w2[0])
+                episodes += 1
+                break
+    assert episodes >= 3
+
+
+def test_dropin_results_are_cached_by_value_not_by_identity():
+    """What next_state leaves behind for valid_actions / state_to_observation is keyed by the state's VALUE: an equal
+    copy hits it, a state changed in place does not (and is evaluated afresh on the GPU)."""
+    from colosseumrl_amd import get_environment
+    # Tron
+    env, fresh = get_environment("tron")("20;4"), get_environment("tron")("20;4")
+    s, _ = env.new_state()
+    s, *_ = env.next_state(s, [0, 1, 2, 3], ["left", "forward", "right", "forward"])
+    twin = tuple(a.copy() for a in s)
+    for p in range(4):
+        a, b = env.state_to_observation(twin, p), fresh.state_to_observation(s, p)
+        assert all(np.array_equal(a[k], b[k]) for k in a)
+    s[0][0, 0] = 3                                                       # caller scribbles on the returned board
+    a, b = env.state_to_observation(s, 1), fresh.state_to_observation(s, 1)
+    assert a["board"][0, 0] == b["board"][0, 0] == 3 and np.array_equal(a["board"], b["board"])   # 3 seen by player 1 is 3
+    # TicTacToe
+    env, fresh = get_environment("tictactoe_3p")(), get_environment("tictactoe_3p")()
+    s, pl = env.new_state()
+    s, pl, *_ = env.next_state(s, pl, ["(1, 2)"])
+    assert env.valid_actions(s, pl[0]) == fresh.valid_actions(s, pl[0]) and "(1, 2)" not in env.valid_actions(s, pl[0])
+    assert np.array_equal(env.state_to_observation(s, pl[0])["board"], fresh.state_to_observation(s, pl[0])["board"])
+    assert np.array_equal(env.state_to_observation(s, 2)["board"], fresh.state_to_observation(s, 2)["board"])
+    s[0][0, 0] = 2
+    assert env.valid_actions(s, pl[0]) == fresh.valid_actions(s, pl[0]) and "(0, 0)" not in env.valid_actions(s, pl[0])
+    assert not env.is_valid_action(s, pl[0], "(0, 0)") and env.is_valid_action(s, pl[0], "(0, 1)")
+    # Blokus
+    env, fresh = get_environment("blokus")(), get_environment("blokus")()
+    s, pl = env.new_state()
+    for _ in range(5):
+        va = env.valid_actions(s, pl[0])
+        assert va == fresh.valid_actions(s, pl[0])
+        assert env.is_valid_action(s, pl[0], va[len(va) // 2]) and fresh.is_valid_action(s, pl[0], va[-1])
+        o1, o2 = env.state_to_observation(s, pl[0]), fresh.state_to_observation(s, pl[0])
+        assert all(np.array_equal(o1[k], o2[k]) for k in o1)
+        s, pl, *_ = env.next_state(s, pl, [va[len(va) // 3]])
+    s[0].board_contents[10, 10] = 4                                      # in-place change: the cached list no longer applies
+    assert env.valid_actions(s, pl[0]) == fresh.valid_actions(s, pl[0])
+    other = (pl[0] + 2) % 4
+    assert env.valid_actions(s, other) == fresh.valid_actions(s, other)
+
+
+# ------------------------------------------------------------------ Blokus: the compacted ordered list, select, is_valid, pack
+class HipBlokusList(HipBlokus):
+    """HipBlokus whose valid() is crl_blokus_valid_list (the compacted ordered ids) instead of the dense bitmap."""
+
+    def valid(self, cap, player=None):
+        pl = None if player is None else self.torch.from_numpy(np.ascontiguousarray(player, np.int8)).to(self.bb.device)
+        count, ids = self.bb.valid_list(cap, player=pl)
+        return count.cpu().numpy(), ids.cpu().numpy()
+
+
+def test_blokus_valid_list_reference_games_golden(golden):
+    """count + ORDERED id list out of crl_blokus_valid_list == the reference's valid_actions over its 8 complete games."""
+    assert replay_games(golden, HipBlokusList(len(GAMES))) >= 62
+
+
+def test_blokus_list_select_is_valid_pack_vs_oracle_random():
+    import torch
+    B, T = 97, 84
+    rng = np.random.default_rng(11)
+    hip, orc = HipBlokusList(B), OracleBlokus(B)
+    bb = hip.bb
+    for t in range(T):
+        c1, ids1 = hip.valid(2048)
+        c2, ids2 = orc.valid(2048)
+        assert np.array_equal(c1, c2) and np.array_equal(ids1, ids2), t
+        # "play the r-th legal action" for caller-chosen ranks, incl. first, last and out-of-range ones
+        rank = np.where(c2 > 0, rng.integers(0, np.maximum(c2, 1)), 0).astype(np.int32)
+        rank[t % B] = c2[t % B] - 1
+        rank[(t + 1) % B] = c2[(t + 1) % B]                              # one past the end -> -1
+        rank[(t + 2) % B] = -1
+        act, cnt = bb.select(torch.from_numpy(rank).cuda())
+        act = act.cpu().numpy()
+        assert np.array_equal(cnt.cpu().numpy(), c2)
+        for e in range(B):
+            want = ids2[e, rank[e]] if 0 <= rank[e] < c2[e] else -1
+            assert act[e] == want, (t, e, rank[e], c2[e])
+        # is_valid: the selected ids, then random ids (mostly illegal), against membership in the oracle's list
+        probe = np.where(act >= 0, act, rng.integers(0, 336000, size=B)).astype(np.int32)
+        probe[::3] = rng.integers(-3, 336003, size=len(probe[::3]))
+        ok = bb.is_valid(torch.from_numpy(probe).cuda()).cpu().numpy()
+        for e in range(B):
+            assert bool(ok[e]) == bool(probe[e] in set(ids2[e, :c2[e]].tolist())), (t, e, probe[e])
+        play = np.full(B, -1, np.int32)
+        for e in range(B):
+            if c2[e]:
+                play[e] = ids2[e, int(rng.integers(0, c2[e]))]
+        hip.step(play)
+        orc.step(play)
+        if t % 9 == 0:                                                   # other players' lists, and pack == inverse of board
+            pl = rng.integers(0, 4, size=B).astype(np.int8)
+            c1, ids1 = hip.valid(2048, player=pl)
+            c2, ids2 = orc.valid(2048, player=pl)
+            assert np.array_equal(c1, c2) and np.array_equal(ids1, ids2)
+            occ = bb.occ.clone()
+            bb.occ.zero_()
+            bb.set_board(torch.from_numpy(orc.st.board.astype(np.int8).reshape(B, 20, 20)).cuda())
+            assert torch.equal(bb.occ, occ)
+    # a list cut by a small cap: the first `cap` ids, count still the full length
+    hip2, orc2 = HipBlokusList(5), OracleBlokus(5)
+    c, ids = hip2.valid(16)
+    c2, ids2 = orc2.valid(2048)
+    assert c.tolist() == [116] * 5 and np.array_equal(ids, ids2[:, :16])
+
+
+def test_blokus_valid_list_full_size_counts():
+    """BASELINE config 4's batch: list lengths == the count pass at B = 16,384 on mid-game positions, lists ascending."""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    bb = BlokusBatch(16384)
+    bb.rollout(30, 3)
+    count, ids = bb.valid_list(2048)
+    assert torch.equal(count, bb.valid())
+    ids = ids.cpu().numpy()
+    c = count.cpu().numpy()
+    assert c.max() <= 2048 and c.max() > 200
+    for e in range(0, 16384, 257):
+        row = ids[e, :c[e]]
+        assert (np.diff(row) > 0).all() and (ids[e, c[e]:] == -1).all()
+    st = O.BlokusState(64)
+    st.occ[:] = bb.occ.cpu().numpy().view(np.uint32)[:64]
+    st.inv[:] = bb.inv.cpu().numpy().view(np.uint32)[:64]
+    st.score[:] = bb.score.cpu().numpy()[:64]
+    st.round[:] = bb.round.cpu().numpy()[:64]
+    st.to_move[:] = bb.to_move.cpu().numpy()[:64]
+    c2, ids2 = O.blokus_valid(st, cap=2048, n_threads=8)
+    assert np.array_equal(c[:64], c2) and np.array_equal(ids[:64], ids2)
+
+
+def test_blokus_dropin_vs_oracle_full_game():
+    """The Blokus BaseEnvironment class on host-mapped memory plays a whole random game next to the oracle: every
+    valid_actions list (strings in reference order), is_valid_action, next_state outcome and observation."""
+    from colosseumrl_amd import get_environment
+    from colosseumrl_amd.envs.blokus import actions as A
+    env = get_environment("blokus")()
+    orc = OracleBlokus(1)
+    rng = np.random.default_rng(3)
+    state, players = env.new_state()
+    for t in range(120):
+        pl = players[0]
+        va = env.valid_actions(state, pl)
+        c2, ids2 = orc.valid(4096)
+        want = [A.id_to_string(i) for i in ids2[0, :c2[0]]] or [""]
+        assert va == want, t
+        pick = va[int(rng.integers(0, len(va)))]
+        if pick:
+            assert env.is_valid_action(state, pl, pick)
+            assert not env.is_valid_action(state, (pl + 1) % 4, pick) or pick in env.valid_actions(state, (pl + 1) % 4)
+        state, players, rewards, terminal, winners = env.next_state(state, players, [pick])
+        r2, t2, w2 = orc.step(np.array([A.string_to_id(pick) if pick else -1], np.int32))
+        s2 = orc.state()
+        assert np.array_equal(state[0].board_contents, s2["board"][0].reshape(20, 20))
+        assert [p.player_score for p in state[2]] == s2["score"][0].tolist() and state[1] == s2["round"][0]
+        assert players == [int(s2["to_move"][0])] and rewards == [int(r2[0])] and terminal == bool(t2[0])
+        if terminal:
+            assert sum(1 << w for w in winners) == int(w2[0])
+            break
+    assert terminal and t > 50

@@ -326,11 +326,10 @@ def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
     """crl_tron_step_observe (one launch: [sample ->] next_state -> state_to_observation of all P players) equals
     crl_tron_sample + crl_tron_step + crl_tron_observe_all on a twin batch and the oracle stepped in lockstep: 64 and 16
     games per workgroup (LDS limit), ragged batches, auto-reset on and off, external and sampled actions, and the
-    boards / player counts that take the unfused path internally (N*N % 16 != 0, P = 8)."""
+    boards / player counts that run the one-game-per-workgroup kernel instead (N*N % 16 != 0, P = 8)."""
     import torch
     from colosseumrl_amd.batched import TronBatch
     seed, first = 77, 900
-    fused_path = (N * N) % 16 == 0 and P <= 7
     a, b = TronBatch(N, P, B, first_env_id=first), TronBatch(N, P, B, first_env_id=first)
     sh, sd = O.tron_start_positions(N, P)
     orc = OracleTron(N, P, B, sh, sd)
@@ -340,7 +339,7 @@ def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
     resets = 0
     for t in range(26):
         auto = (t % 5) != 4
-        sampled = fused_path and (t % 2 == 0)
+        sampled = (t % 2 == 0)            # also on the shapes that run the one-game-per-workgroup kernel (round 2 raised there)
         if sampled:
             act = b.sample(seed)                                     # advances b.tcount; the fused call advances a.tcount
             out = a.step_observe(None, seed=seed, auto_reset=auto, out=out)
@@ -365,10 +364,6 @@ def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
             assert np.array_equal(out["board"][p].reshape(B, -1).cpu().numpy(), ob) and np.array_equal(out["heads"][p].cpu().numpy(), oh)
             assert np.array_equal(out["directions"][p].cpu().numpy(), od) and np.array_equal(out["deaths"][p].cpu().numpy(), ok)
     assert resets > 0
-    if not fused_path:
-        from colosseumrl_amd import _native
-        with pytest.raises(_native.NativeError):
-            a.step_observe(None, seed=seed)                          # the unfused path needs explicit actions
 
 
 def test_step_observe_full_size_equals_rollout():
