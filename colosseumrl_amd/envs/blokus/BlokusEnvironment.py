@@ -164,7 +164,7 @@ class BlokusEnvironment(BaseEnvironment):
     def valid_actions(self, state: object, player: int) -> List[str]:
         """Every legal action string in the reference's order, or ``['']`` (reference :453-500)."""
         ids = self._legal_ids(state, player)
-        return [A.id_to_string(i) for i in ids] if len(ids) else [""]
+        return A.ids_to_strings(ids) if len(ids) else [""]
 
     def valid_actions_dict(self, state: object, player: int) -> Dict[str, Dict[Tuple[int, int], List[str]]]:
         """``{piece: {(x, y): [orientation+shift, ...]}}`` (reference :630-665, board.py:183-193)."""

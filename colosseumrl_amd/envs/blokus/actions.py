@@ -54,11 +54,28 @@ def decode(action_id: int) -> Tuple[int, int, int, int, int]:
     return action_id // 16000, cell % 20, cell // 20, orientation, shift
 
 
+_STRINGS = {}          # id -> string, filled as ids are seen (a valid_actions list is ~100-1,700 strings per call)
+
+
 def id_to_string(action_id: int) -> str:
-    if action_id < 0:
-        return ""
-    piece, x, y, orientation, shift = decode(int(action_id))
-    return "{};({}, {});{}{}".format(PIECE_NAMES[piece], x, y, ORIENTATIONS[orientation], shift)
+    action_id = int(action_id)
+    s = _STRINGS.get(action_id)
+    if s is None:
+        if action_id < 0:
+            return ""
+        piece, x, y, orientation, shift = decode(action_id)
+        s = _STRINGS[action_id] = "{};({}, {});{}{}".format(PIECE_NAMES[piece], x, y, ORIENTATIONS[orientation], shift)
+    return s
+
+
+def ids_to_strings(ids) -> list:
+    """Strings of a whole id list (ascending ids = the reference's valid_actions order)."""
+    get = _STRINGS.get
+    out = []
+    for i in ids.tolist() if hasattr(ids, "tolist") else ids:
+        s = get(i)
+        out.append(s if s is not None else id_to_string(i))
+    return out
 
 
 def string_to_id(action_str: str) -> int:

@@ -120,7 +120,7 @@ def test_dropin_results_are_cached_by_value_not_by_identity():
         assert all(np.array_equal(a[k], b[k]) for k in a)
     s[0][0, 0] = 3                                                       # caller scribbles on the returned board
     a, b = env.state_to_observation(s, 1), fresh.state_to_observation(s, 1)
-    assert a["board"][0, 0] == b["board"][0, 0] == 3 and np.array_equal(a["board"], b["board"])   # 3 seen by player 1 is 3
+    assert a["board"][0, 0] == b["board"][0, 0] == 2 and np.array_equal(a["board"], b["board"])   # player 2's cell, seen by player 1
     # TicTacToe
     env, fresh = get_environment("tictactoe_3p")(), get_environment("tictactoe_3p")()
     s, pl = env.new_state()
