@@ -123,8 +123,9 @@ def make_stepper(game, kw, batch, device, first_env_id):
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=True):
-    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample:
-    all threads (`value`) and one thread, with the visible core count; plus the reference's own Python figure."""
+    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample: every
+    hardware thread (`value`, `cores` = nproc), the 16 threads that are a 1-GPU box's share, and one thread; plus the
+    reference's own Python figure."""
     from oracle import oracle as O
     game, kw = WORKLOADS[workload][:2]
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -160,7 +161,7 @@ def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=Tr
         return run
 
     def timed(cores, seconds):
-        B = (64 * cores) if game == "blokus" else (65536 if cores > 1 else 8192)
+        B = (64 * cores) if game == "blokus" else (max(65536, 512 * cores) if cores > 1 else 8192)
         run = runner(B, cores)
         T = 4
         dt = run(T)                                # warms the thread pool
@@ -173,9 +174,11 @@ def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=Tr
         return {"value": B * T / dt, "threads": cores,
                 "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %.1f s" % (B, T, dt)}
 
-    allt = timed(threads_all, seconds_all)
-    out = {"value": allt["value"], "unit": "env-steps/s", "cores": threads_all, "kind": "port", "sample": allt["sample"],
+    allt = timed(nproc, seconds_all)                     # every hardware thread the box shows
+    out = {"value": allt["value"], "unit": "env-steps/s", "cores": nproc, "kind": "port", "sample": allt["sample"],
            "nproc": nproc, "threads_all": allt}
+    if threads_all != nproc:
+        out["threads_%d" % threads_all] = timed(threads_all, min(seconds_all, 5.0))     # a 1-GPU box's CPU share
     if with_one_thread:
         out["threads_1"] = timed(1, seconds_one)
     if workload in REFERENCE_PYTHON:
@@ -285,7 +288,7 @@ def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None)
     ev0.record()                                           # same stream the kernels are launched on
     launches = sr.rollout(steps, seed, chunk)
     ev1.record()
-    gathered = sr.gather(dst=dst)                          # the one collective: per-game results to rank `dst`
+    gathered = sr.gather(dst=dst, copy=False)              # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -316,7 +319,7 @@ def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
     for _ in range(n):
         st.rollout(chunk, seed)
     e1.record()
-    res = st.results()
+    res = st.results(copy=False)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     mean_len, n_ep = mean_episode_len(res)
@@ -432,6 +435,14 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     bb.rollout(24, 5)                                      # mid-game positions
     wall, gpu = rate(lambda: bb.valid(), 50)
     out["blokus_valid_count"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "games": Bb}
+    count, ids = bb.valid_list(2048)
+    wall, gpu = rate(lambda: bb.valid_list(2048, out=ids), 50)
+    out["blokus_valid_list"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "games": Bb,
+                                "mean_legal_actions": float(count.float().mean().item()), "max_legal_actions": int(count.max().item()),
+                                "what": "the ordered legal-action ids of every game, compacted [B][2048] (crl_blokus_valid_list)"}
+    rk = torch.zeros((Bb,), dtype=torch.int32, device=device)
+    wall, gpu = rate(lambda: bb.select(rk), 50)
+    out["blokus_select"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "what": "the r-th legal action for caller-chosen ranks"}
     act = bb.sample(5, advance=False)
     occ0, inv0, sc0, rd0, tm0 = bb.occ.clone(), bb.inv.clone(), bb.score.clone(), bb.round.clone(), bb.to_move.clone()
 
@@ -521,6 +532,84 @@ def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p",
     return out
 
 
+def world_of_one_gather_us(torch, dist, make, args, steps_per_launch):
+    """Cost of the end-of-rollout collective in a world of ONE rank, for runs that have no process group (the driver's
+    plain N = 1 run): a one-rank RCCL group is created here, AFTER the contract measurement, the timed region's launch
+    shape is run with and without `gather`, and the group is destroyed again.  {gather_us, region_us, region_no_gather_us}."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    from colosseumrl_amd.parallel import ShardedRollout
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        sr = ShardedRollout(make, WORKLOADS[args.workload][2] if args.batch <= 0 else args.batch)
+        def region(with_gather):
+            ts = []
+            for i in range(60):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sr.rollout(steps_per_launch, args.seed, steps_per_launch)
+                if with_gather:
+                    sr.gather(dst=0, copy=False)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+                if i % 20 == 19:
+                    sr.stepper.reset_stats()                # keep the 16-bit rows exact (what a 20-step region ships)
+            ts = sorted(ts[10:])
+            return ts[len(ts) // 2] * 1e6
+        region(True)
+        a, b = region(False), region(True)
+        row = sr.gather(dst=0, copy=False)
+        return {"gather_us": round(b - a, 2), "region_us": round(b, 2), "region_no_gather_us": round(a, 2),
+                "row_bytes": int(row.shape[1] * row.element_size()), "what": "median of 50 launch [+ gather] + synchronise "
+                "regions of the timed launch shape in a one-rank RCCL group created for this measurement"}
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def compact_summary(out):
+    """<= ~1.5 KB of scalars, emitted as the LAST key of the line so that a record that keeps only the tail of stdout
+    still carries every headline number: per workload env-steps/s (v), ms per launch (ms), HBM fraction of 8 TB/s
+    (hbm: measured traffic / launch time), VALU issue fraction of the measured peak (valu)."""
+    def sig(x, n=4):
+        return None if x is None else float("%.*g" % (n, x))
+
+    def wl(rec):
+        r = rec.get("roofline", {})
+        return {"v": sig(rec.get("value")), "ms": sig(r.get("launch_ms")), "hbm": sig(r.get("frac"), 3),
+                "valu": sig(r.get("valu_issue", {}).get("frac"), 3),
+                "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
+    sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig(out["kernel_ms"] * 1e3),
+                       "hbm": sig(out["roofline"].get("frac"), 3), "of_copy": sig(out["roofline"].get("frac_of_copy"), 3),
+                       "alg": sig(out["roofline"]["algorithmic"]["frac"], 3), "cold_v": sig(out.get("value_cold")),
+                       "cold_us": sig(out.get("cold_first_region_us")), "gather_us": (out.get("gather") or {}).get("gather_us")}}
+    if "steady_state" in out:
+        sm[out["config"]["workload"]] = wl(dict(out["steady_state"], cpu_baseline=out.get("cpu_baseline", {})))
+    for name, rec in out.get("others", {}).items():
+        sm[name] = wl(rec)
+    sa = out.get("step_api", {})
+    pick = {"tron_step": "tron_n20_step_auto_reset", "tron_step_lds": "tron_n20_step_staged", "tron_step_observe": "tron_n20_step_observe_fused",
+            "tron_observe_all": "tron_n20_observe_all", "ttt_step_observe": "ttt_3x5_step_observe_fused",
+            "blokus_step_observe": "blokus_step_observe_fused", "blokus_valid_list": "blokus_valid_list"}
+    sm["step_api_us"] = {k: sig(sa[v].get("gpu_us_per_call"), 3) for k, v in pick.items() if v in sa}
+    if "tron_n20_step_observe_fused" in sa:
+        sm["step_api_us"]["tron_step_observe_hbm"] = sig(sa["tron_n20_step_observe_fused"].get("frac_of_hbm_peak"), 3)
+    if "dropin" in out:
+        sm["dropin_us"] = {k: [v["next_state"], v["valid_actions"], v["state_to_observation"], v["new_state"],
+                               (v.get("reference_us") or {}).get("next_state")]
+                           for k, v in out["dropin"].items() if isinstance(v, dict)}
+        sm["dropin_cols"] = "next_state, valid_actions, state_to_observation, new_state, reference next_state"
+    cb = out.get("cpu_baseline", {})
+    if cb:
+        sm["cpu"] = {"nproc": cb.get("nproc"), "all": sig(cb.get("value"), 3), "t16": sig((cb.get("threads_16") or {}).get("value"), 3),
+                     "t1": sig((cb.get("threads_1") or {}).get("value"), 3), "ref_py": (cb.get("reference_python") or {}).get("value")}
+    return sm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -531,7 +620,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="env-steps fused into one kernel launch (default: the workload's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--only-headline", action="store_true", help="skip steady_state / seeds / others / step_api (profiling runs)")
+    ap.add_argument("--no-device-warmup", action="store_true",
+                    help="report the FIRST W + K region of the process as `value` (no device warm-up in between)")
+    ap.add_argument("--only-headline", action="store_true", help="skip steady_state / seeds / others / step_api / dropin (profiling runs)")
     ap.add_argument("--only-step-api", action="store_true", help="run just the per-step API section (profiling runs)")
     ap.add_argument("--only-dropin", action="store_true", help="run just the single-state drop-in latency section")
     args = ap.parse_args()
@@ -566,8 +657,11 @@ def main():
     if args.chunk <= 0:
         args.chunk = default_chunk
     from colosseumrl_amd.parallel import ShardedRollout
+
+    def make(batch, first_env_id):
+        return make_stepper(game, kw, batch, device, first_env_id)
     # weak scaling: every rank owns `batch` games; global ids rank*batch .. (rank+1)*batch - 1
-    sr = ShardedRollout(lambda batch, first_env_id: make_stepper(game, kw, batch, device, first_env_id), world * batch)
+    sr = ShardedRollout(make, world * batch)
 
     def barrier():
         torch.cuda.synchronize()
@@ -576,41 +670,51 @@ def main():
             torch.cuda.synchronize()
 
     steps_per_launch = min(args.chunk, args.steps)
-    # warm-up: W untimed steps and the rollout epilogue (gather), so lazily loaded code objects and the RCCL
-    # communicator are not set up inside the timed region
     # The W warm-up steps go through the very function that is timed afterwards (same events, launch path, gather and
-    # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record).
+    # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record,
+    # code objects are loaded at first launch, the RCCL communicator comes up at the first collective).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
-    # Device warm-up, before W and K and on a SCRATCH stepper (other memory, other games): ~30 ms of the same kind of
-    # launches, so that a 45-us timed region on a box that has just been handed over is not measured at idle clocks
-    # (first run on a fresh box: 62 us, every later one 41-45 us).  Not part of the W warm-up steps or the K timed steps.
-    # (launches of the timed region's own shape: the rocprof passes of tools/profile_bench.sh average over all dispatches)
-    # First ~60 ms of large device copies (the memory clocks follow sustained HBM traffic: after a quiet spell the first
-    # 20-step launch -- 65 MB in 20 us -- ran in 31 us, the ones behind the bandwidth measurement further down in 20),
-    # then ~30 ms of launches.
-    t_dev = time.perf_counter()
-    blob = torch.empty((256 << 20,), dtype=torch.uint8, device=device)
-    while time.perf_counter() - t_dev < 0.06:
-        blob[: 128 << 20].copy_(blob[128 << 20:])
-        torch.cuda.synchronize()
-    del blob
-    scratch = make_stepper(game, kw, batch, device, 0)
-    t_launch = time.perf_counter()
-    while time.perf_counter() - t_launch < 0.03:
-        scratch.rollout(steps_per_launch, args.seed)
-        torch.cuda.synchronize()
-    del scratch
-    device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
-    if args.warmup > 0:
-        timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events, dst)
+
+    def contract_region():
+        """W untimed + K timed steps, exactly as the contract says; returns the timed region's measurements."""
+        if args.warmup > 0:
+            timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events, dst)
+        else:
+            sr.gather(dst=dst, copy=False)
+        return timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, events, dst)
+
+    # (1) COLD: the first W + K region of this process, on a box that has just been handed over (memory clocks at idle).
+    cold = contract_region()
+    # (2) Device warm-up on a SCRATCH stepper (other memory, other games), then W + K again = `value`.  The memory clocks
+    # follow sustained HBM traffic, which 20-us launches with a synchronise between them are not: ~60 ms of large device
+    # copies, then ~30 ms of launches of the timed region's own shape.  Not part of W or K; `value_cold` / `cold_first_region_us`
+    # above is the same region without it, `--no-device-warmup` makes that one the headline.
+    device_warmup_ms = 0.0
+    if args.no_device_warmup:
+        elapsed, kernel_s, launches, gathered = cold
     else:
-        sr.gather(dst=dst)
-    elapsed, kernel_s, launches, gathered = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, events, dst)
+        t_dev = time.perf_counter()
+        blob = torch.empty((256 << 20,), dtype=torch.uint8, device=device)
+        while time.perf_counter() - t_dev < 0.06:
+            blob[: 128 << 20].copy_(blob[128 << 20:])
+            torch.cuda.synchronize()
+        del blob
+        scratch = make_stepper(game, kw, batch, device, 0)
+        t_launch = time.perf_counter()
+        while time.perf_counter() - t_launch < 0.03:
+            scratch.rollout(steps_per_launch, args.seed)
+            torch.cuda.synchronize()
+        del scratch
+        device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
+        sr.stepper.reset()
+        sr.stepper.reset_stats()
+        elapsed, kernel_s, launches, gathered = contract_region()
+    cold_elapsed = cold[0]
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed, cold_elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, cold_elapsed = float(tt[0].item()), float(tt[1].item())
     if rank == 0:
         mean_len, n_ep = mean_episode_len(gathered)
         copy_gbs, write_gbs = measure_copy_bandwidth(torch, device) if world == 1 else (None, None)
@@ -619,6 +723,7 @@ def main():
         # dominant (first) launch shape and uses the mean launch time only as an approximation -- flagged below
         equal = (args.steps % steps_per_launch) == 0
         launch_s = kernel_s / launches
+        row_bytes = int(gathered.shape[-1] * gathered.element_size())
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -628,26 +733,39 @@ def main():
                        "steps_per_launch": steps_per_launch, "launches": launches,
                        "agent": "uniform random (Philox-4x32-10), auto-reset",
                        "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
-                       "gather": "rccl gather to rank 0 (torch.distributed.gather)" if use_dist else "none (single process, no process group)"},
+                       "gather": ("rccl gather to rank 0 (torch.distributed.gather), %d-byte rows" % row_bytes) if use_dist
+                                 else "none (single process, no process group)",
+                       "device_warmup": ("none: `value` is the first W + K region of the process" if args.no_device_warmup else
+                                         "%.0f ms of device copies + launches on a scratch stepper between the cold region and W + K "
+                                         "(value_cold = the same region before it)" % device_warmup_ms)},
             "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
             "device_warmup_ms": round(device_warmup_ms, 1),
+            "value_cold": world * batch * args.steps / cold_elapsed, "cold_first_region_us": cold_elapsed * 1e6,
+            "cold_kernel_us": cold[1] * 1e6,
             "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),
         }
         if not equal:
             out["roofline"]["note"] = "launches of the timed region are not equal-sized; launch_ms is their mean"
         if world == 1 and not args.only_headline:
             seeds = {}
-            for s in (0, 1, 2):                             # seeds {0, 1, 2}, same timed region
+            for sd in (0, 1, 2):                            # seeds {0, 1, 2}, same timed region
                 sr.stepper.reset()
                 sr.stepper.reset_stats()
                 if args.warmup > 0:
-                    timed_rollout(torch, sr, args.warmup, s, args.chunk, barrier, events, dst)
-                e, _, _, g = timed_rollout(torch, sr, args.steps, s, args.chunk, barrier, events, dst)
-                seeds[str(s)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
+                    timed_rollout(torch, sr, args.warmup, sd, args.chunk, barrier, events, dst)
+                e, _, _, g = timed_rollout(torch, sr, args.steps, sd, args.chunk, barrier, events, dst)
+                seeds[str(sd)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
             vals = [v["value"] for v in seeds.values()]
             seeds["spread"] = (max(vals) - min(vals)) / (sum(vals) / len(vals))
             out["seeds"] = seeds
             out["steady_state"] = steady_state(torch, args.workload, device, args.seed, copy_gbs)
+            # the steady-state figures of the headline workload as scalars of `roofline` too (scalars there survive into
+            # records that keep only part of the line)
+            ssr = out["steady_state"]["roofline"]
+            out["roofline"].update({"steady_value": out["steady_state"]["value"], "steady_launch_ms": ssr["launch_ms"],
+                                    "steady_hbm_frac": ssr["frac"], "steady_valu_frac": ssr.get("valu_issue", {}).get("frac"),
+                                    "algorithmic_frac": out["roofline"]["algorithmic"]["frac"],
+                                    "steady_algorithmic_frac": ssr["algorithmic"]["frac"]})
             others = {}
             for wl in WORKLOADS:
                 if wl == args.workload:
@@ -657,6 +775,10 @@ def main():
             out["step_api"] = step_api_rates(torch, device, copy_gbs, write_gbs)
             out["stream_peaks"] = {"copy_GBs": copy_gbs, "write_GBs": write_gbs,
                                    "what": "measured in this run over 1 GiB: best read+write copy, pure write stream"}
+            try:
+                out["dropin"] = dropin_latencies()
+            except Exception as exc:                        # never fatal for the bench line
+                out["dropin"] = {"error": repr(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
             if "placement_tests_per_env_step" in out["cpu_baseline"]:
@@ -668,8 +790,31 @@ def main():
                         # reference-equivalent work: placements the reference's loops test per env-step (counted by the
                         # oracle on its sample) x the GPU's env-steps/s; the HIP kernel fits whole shapes instead
                         rec["placement_tests_per_s"] = rec["value"] * rec["cpu_baseline"]["placement_tests_per_env_step"]
+        # the collective's cost in a world of one rank, to read a multi-GPU record against
+        if world == 1 and game == "tron":
+            try:
+                if use_dist:
+                    ts = []
+                    for with_gather in (False, True, False, True):
+                        tt = []
+                        for _ in range(40):
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            sr.rollout(steps_per_launch, args.seed, steps_per_launch)
+                            if with_gather:
+                                sr.gather(dst=0, copy=False)
+                            torch.cuda.synchronize()
+                            tt.append(time.perf_counter() - t0)
+                        ts.append(sorted(tt)[20] * 1e6)
+                    out["gather"] = {"gather_us": round(min(ts[1], ts[3]) - min(ts[0], ts[2]), 2), "region_us": round(min(ts[1], ts[3]), 2),
+                                     "region_no_gather_us": round(min(ts[0], ts[2]), 2), "what": "this run's own one-rank RCCL group"}
+                elif not args.only_headline:
+                    out["gather"] = world_of_one_gather_us(torch, dist, make, args, steps_per_launch)
+            except Exception as exc:                        # never fatal for the bench line
+                out["gather"] = {"error": repr(exc)[:300]}
+        out["summary"] = compact_summary(out)               # LAST key: survives a record that keeps only the tail of stdout
         print(json.dumps(out))
-    if use_dist:
+    if use_dist and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

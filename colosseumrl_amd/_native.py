@@ -44,7 +44,8 @@ def build(force=False, verbose=False):
 
 class TronStats(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len", "results")]
+                ("tcount", "tstep", "n_episodes", "win_count", "len_sum", "ret_sum", "last_winners", "last_len", "results",
+                 "packed")]
 
 
 class TTTStats(C.Structure):

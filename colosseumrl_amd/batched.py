@@ -130,6 +130,9 @@ class TronBatch:
             self.last_winners = torch.zeros((B,), dtype=torch.uint8, device=dev)
             self.last_len = torch.zeros((B,), dtype=torch.int16, device=dev)
             self._results = torch.zeros((B, 3 + 2 * P), dtype=torch.int32, device=dev)   # packed by the rollout kernels
+            # the same row in 16-bit fields (include/colosseum_hip.h, crl_tron_stats.packed): 16 bytes per game at P = 4
+            self._packed = torch.zeros((B, (4 + P + 1) & ~1), dtype=torch.int16, device=dev)
+        self._stat_steps = 0                      # rollout steps the running totals span (since reset_stats)
         self._rollout_args = None
         self.reset()
 
@@ -143,8 +146,9 @@ class TronBatch:
 
     def reset_stats(self):
         for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.len_sum, self.ret_sum,
-                  self.last_winners, self.last_len, self._results):
+                  self.last_winners, self.last_len, self._results, self._packed):
             t.zero_()
+        self._stat_steps = 0
 
     # -- next_state for all games; actions int8 [P, B] in {0, +1, -1}
     def step(self, actions: torch.Tensor, auto_reset: bool = False):
@@ -159,7 +163,7 @@ class TronBatch:
     def _stats(self):
         return TronStats(*[t.data_ptr() for t in (self.tcount, self.tstep, self.n_episodes, self.win_count,
                                                    self.len_sum, self.ret_sum, self.last_winners, self.last_len,
-                                                   self._results)])
+                                                   self._results, self._packed)])
 
     # -- T fused random-agent steps with auto-reset
     def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto"):
@@ -175,6 +179,7 @@ class TronBatch:
                                             *self._rollout_args, flags, _stream())
         if rc:
             check(rc, "crl_tron_rollout")
+        self._stat_steps += int(steps)
 
     def check_state(self) -> int:
         """Number of games whose state breaks the invariant of every reset / step / rollout product that the LDS
@@ -263,18 +268,38 @@ class TronBatch:
                                              _stream()), "crl_tron_ranking")
         return out
 
-    def results(self):
+    def results(self, copy: bool = True):
         """Per-game episode results packed for the end-of-rollout gather: int32 [B, 3+2P] =
         n_episodes, len_sum, last_winners, win_count[P], ret_sum[P].  The rows are written by the rollout kernel
-        itself at the end of every launch (``crl_tron_stats.results``): this returns that buffer, no packing pass.
-        It is rewritten in place by the next rollout; ``clone()`` it to keep a snapshot."""
-        return self._results
+        itself at the end of every launch (``crl_tron_stats.results``): no packing pass.  By default a snapshot;
+        ``copy=False`` hands out the live buffer, which the next rollout rewrites in place."""
+        return self._results.clone() if copy else self._results
+
+    PACKED_EXACT_STEPS = 3276      # |ret_sum| <= 10 per step: the int16 fields hold the totals of this many steps
+
+    def packed_rows_exact(self) -> bool:
+        """True while the 16-bit row of ``results_packed`` cannot have wrapped: the running totals span at most
+        ``PACKED_EXACT_STEPS`` rollout steps since ``reset_stats`` (known on the host: it issues the launches)."""
+        return self._stat_steps <= self.PACKED_EXACT_STEPS
+
+    def results_packed(self, copy: bool = True):
+        """The gather row in 16-bit fields: int16 [B, (4+P+1)&~1] = n_episodes, len_sum, last_winners, tstep (steps into
+        the unfinished episode), ret_sum[P] -- the low 16 bits of the running totals, written by the rollout kernel
+        (``crl_tron_stats.packed``); 16 bytes per game at P = 4 instead of 44.  Exact while ``packed_rows_exact()``."""
+        return self._packed.clone() if copy else self._packed
 
     def results_from_columns(self):
         """The same rows assembled from the per-column statistics (what ``results()`` must equal; used by the tests)."""
         cols = [self.n_episodes, self.len_sum, self.last_winners.to(torch.int32)]
         cols += [self.win_count[p] for p in range(self.P)] + [self.ret_sum[p] for p in range(self.P)]
         return torch.stack(cols, dim=1).contiguous()
+
+    def results_packed_from_columns(self):
+        """The 16-bit rows assembled from the per-column statistics (what ``results_packed()`` must equal; tests)."""
+        cols = [self.n_episodes, self.len_sum, self.last_winners.to(torch.int32), self.tstep]
+        cols += [self.ret_sum[p] for p in range(self.P)]
+        cols += [torch.zeros_like(self.tstep)] * (self._packed.shape[1] - len(cols))
+        return torch.stack(cols, dim=1).to(torch.int16).contiguous()
 
 
 class TTTBatch:
@@ -398,9 +423,10 @@ class TTTBatch:
                                             _ptr(self.occ), _ptr(self.winner), _ptr(self.to_move), self._stats(),
                                             _stream()), "crl_ttt_rollout")
 
-    def results(self):
-        """int32 [B, 3+P] = n_episodes, len_sum, draw_count, win_count[P]; written by the rollout kernel (see TronBatch)."""
-        return self._results
+    def results(self, copy: bool = True):
+        """int32 [B, 3+P] = n_episodes, len_sum, draw_count, win_count[P]; written by the rollout kernel at the end of
+        every launch.  A snapshot by default; ``copy=False`` hands out the live buffer the next rollout rewrites."""
+        return self._results.clone() if copy else self._results
 
     def results_from_columns(self):
         cols = [self.n_episodes, self.len_sum, self.draw_count] + [self.win_count[p] for p in range(self.P)]
@@ -638,9 +664,10 @@ class BlokusBatch:
             check(self._lib.crl_blokus_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
                                                *self._state(), self._stats(), _stream()), "crl_blokus_rollout")
 
-    def results(self):
-        """int32 [B, 10] = n_episodes, len_sum, win_count[4], score_sum[4]; written by the rollout kernel (see TronBatch)."""
-        return self._results
+    def results(self, copy: bool = True):
+        """int32 [B, 10] = n_episodes, len_sum, win_count[4], score_sum[4]; written by the rollout kernel at the end of
+        every launch.  A snapshot by default; ``copy=False`` hands out the live buffer the next rollout rewrites."""
+        return self._results.clone() if copy else self._results
 
     def results_from_columns(self):
         cols = [self.n_episodes, self.len_sum] + [self.win_count[p] for p in range(4)] + [self.score_sum[p] for p in range(4)]

@@ -444,6 +444,10 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
     }
 }
 
+// u16 entries per game of the 16-bit gather row (crl_tron_stats.packed): n_episodes, len_sum, last_winners, tstep,
+// ret_sum[P], rounded up to a whole number of dwords
+template <int P> constexpr int kTronPackedRow = (4 + P + 1) & ~1;
+
 // per-lane rollout bookkeeping shared by the rollout kernels.  The running totals a launch adds to are read at kernel
 // entry (with every other global load of the prologue), not in the epilogue: a short launch otherwise ends on a chain
 // of exposed load -> add -> store round trips.
@@ -485,6 +489,7 @@ struct TronAcc {
     __device__ __forceinline__ void store(const crl_tron_stats &st, const int64_t B, const int64_t b) const
     {
         int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+        uint16_t *pk = st.packed ? st.packed + b * kTronPackedRow<P> : nullptr;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int r = old_ret[p] + ret[p];
@@ -492,6 +497,7 @@ struct TronAcc {
             st.ret_sum[p * B + b] = r;
             st.win_count[p * B + b] = w;
             if (row) { row[3 + p] = (int32_t)w; row[3 + P + p] = r; }
+            if (pk) pk[4 + p] = (uint16_t)r;
         }
         st.tcount[b] = tc;
         st.tstep[b] = ts;
@@ -506,6 +512,12 @@ struct TronAcc {
             row[0] = (int32_t)ne;
             row[1] = (int32_t)ls;
             row[2] = last_w >= 0 ? last_w : (int32_t)old_last_w;
+        }
+        if (pk) {
+            pk[0] = (uint16_t)ne;
+            pk[1] = (uint16_t)ls;
+            pk[2] = (uint16_t)(last_w >= 0 ? (uint32_t)last_w : old_last_w);
+            pk[3] = (uint16_t)ts;
         }
     }
 };
@@ -1365,6 +1377,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     lw |= tron_quad<0x4E>(lw);
     const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;   // alive +1, dead -1, alive at a terminal step +10
     int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    uint16_t *pk = st.packed ? st.packed + b * ((4 + P + 1) & ~1) : nullptr;        // kTronPackedRow, P a run-time value here
     if (pvalid) {
         const int rel = h - mine;
         const int rowi = rel / RS;                               // = y + 1
@@ -1376,6 +1389,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         st.ret_sum[p * B + b] = rs;
         st.win_count[p * B + b] = wc;
         if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+        if (pk) pk[4 + p] = (uint16_t)rs;
     }
     if (gvalid && p == 0) {
         const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + (ts_at_entry + (uint32_t)T - ts);
@@ -1388,6 +1402,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             st.last_len[b] = (uint16_t)last_len;
         }
         if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+        if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
     }
 }
 
@@ -2200,12 +2215,14 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     lw |= tron_quad<0x4E>(lw);
     const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;
     int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    uint16_t *pk = st.packed ? st.packed + b * kTronPackedRow<P> : nullptr;
     if (pvalid) {
         const int rs = old_ret + ret;
         const uint32_t wc = old_wins + wins;
         st.ret_sum[p * B + b] = rs;
         st.win_count[p * B + b] = wc;
         if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+        if (pk) pk[4 + p] = (uint16_t)rs;
     }
     if (p == 0) {
         r_tc[slot] = tc;
@@ -2222,6 +2239,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             st.last_len[b] = (uint16_t)last_len;
         }
         if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+        if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
     }
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
 

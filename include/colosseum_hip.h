@@ -126,7 +126,14 @@ typedef struct {
     int32_t  *results;      /* [B][3+2P] or NULL: the per-game row the end-of-rollout gather ships, rewritten by every
                              * launch from the running totals above: n_episodes, len_sum, last_winners, win_count[P],
                              * ret_sum[P] (no separate packing pass over the SoA arrays) */
+    uint16_t *packed;       /* [B][CRL_TRON_PACKED_ROW(P)] or NULL: the same row in 16-bit fields for a latency-bound
+                             * gather (winners mask + episode length + P int16 returns; 16 bytes per game at
+                             * P = 4 instead of 44): n_episodes, len_sum, last_winners, tstep (steps into the unfinished
+                             * episode), ret_sum[P] as int16 -- the LOW 16 bits of the running totals, hence exact while
+                             * the totals span at most 3,276 steps (|ret_sum| <= 10 per step); the host side ships this
+                             * row only then (colosseumrl_amd/parallel.py) and the int32 row otherwise */
 } crl_tron_stats;
+#define CRL_TRON_PACKED_ROW(P) ((4 + (P) + 1) & ~1)   /* u16 entries per game: a whole number of dwords */
 
 /* T fused env-steps per env with a uniform random agent and auto-reset (the benchmark loop of
  * BASELINE.md section 3; no reference counterpart -- the reference steps one env per Python call).

@@ -3,10 +3,25 @@
 tests/conftest.py starts this helper at session start, i.e. before the pytest process has initialised the GPU.  The helper
 never touches the GPU itself; it only forks + execs the commands it is sent.  That keeps every exec out of processes that
 hold a GPU context (on the GPU pool an exec from such a process is refused).  Protocol: one JSON object per line on stdin
-({"cmd": [...], "env": {...}, "cwd": ..., "timeout": s}), one per line on stdout ({"rc": int, "out": str})."""
+({"cmd": [...], "env": {...}, "cwd": ..., "timeout": s}), one per line on stdout ({"rc": int, "out": str}).
+The text "@FREE_PORT@" in an argument or an environment value is replaced by a TCP port that was free a moment ago (one
+port per request), so a leftover of an earlier session cannot make a rendezvous fail with EADDRINUSE.  A command runs in
+its own session; on timeout the WHOLE process group is killed (torch.distributed.run is an agent whose rank process would
+otherwise survive it, holding the GPU) and the reply carries rc = -9 and says "timeout"."""
 import json
+import os
+import signal
+import socket
 import subprocess
 import sys
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
 
 
 def main():
@@ -15,12 +30,24 @@ def main():
         if not line:
             continue
         req = json.loads(line)
+        port = free_port()
+        cmd = [a.replace("@FREE_PORT@", port) for a in req["cmd"]]
+        env = req.get("env")
+        if env is not None:
+            env = {k: v.replace("@FREE_PORT@", port) for k, v in env.items()}
         try:
-            p = subprocess.run(req["cmd"], env=req.get("env"), cwd=req.get("cwd"), stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, text=True, timeout=req.get("timeout", 600))
-            rep = {"rc": p.returncode, "out": p.stdout[-20000:]}
-        except subprocess.TimeoutExpired as e:
-            rep = {"rc": -9, "out": "timeout: %s" % (e.stdout[-4000:] if isinstance(e.stdout, str) else "")}
+            p = subprocess.Popen(cmd, env=env, cwd=req.get("cwd"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 text=True, start_new_session=True)
+            try:
+                out, _ = p.communicate(timeout=req.get("timeout", 600))
+                rep = {"rc": p.returncode, "out": out[-20000:]}
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                out, _ = p.communicate()
+                rep = {"rc": -9, "out": "timeout after %s s (process group killed): %s" % (req.get("timeout", 600), (out or "")[-4000:])}
         except Exception as e:  # noqa: BLE001
             rep = {"rc": -1, "out": repr(e)}
         sys.stdout.write(json.dumps(rep) + "\n")

@@ -27,16 +27,26 @@ assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
 B = 4096 + 7
 sr = ShardedRollout(lambda batch, first_env_id: TronBatch(20, 4, batch, device="cuda:0", first_env_id=first_env_id), B)
 sr.rollout(48, seed=3, chunk=20)
-got = sr.gather()                                                         # all_gather_into_tensor over RCCL
+got = sr.gather(packed=False)                                             # all_gather_into_tensor over RCCL, int32 rows
 want = sr.stepper.results_from_columns()
-assert got.data_ptr() != sr.stepper.results().data_ptr(), "gather() must have gone through the collective's receive buffer"
+assert got.data_ptr() != sr.stepper.results(copy=False).data_ptr(), "gather() must have gone through the collective's receive buffer"
 assert torch.equal(got, want), "gathered rows differ from the local rows"
 assert int(got[:, 0].sum()) > B
 ref = TronBatch(20, 4, B, device="cuda:0")
 ref.rollout(48, seed=3)
 assert torch.equal(ref.results(), got)
-rooted = sr.gather(dst=0)                                                 # torch.distributed.gather: what bench.py times
+narrow = sr.gather()                                                      # 48 steps: the 16-byte rows are exact and shipped
+assert narrow.dtype == torch.int16 and tuple(narrow.shape) == (B, 8)
+assert torch.equal(narrow, sr.stepper.results_packed_from_columns()) and torch.equal(narrow, ref.results_packed())
+assert torch.equal(narrow[:, :2].to(torch.int32), got[:, :2]) and torch.equal(narrow[:, 4:8].to(torch.int32), got[:, 7:11])
+live = sr.gather(copy=False)
+assert live.data_ptr() == sr.gather(copy=False).data_ptr() and live.data_ptr() != narrow.data_ptr()   # reused buffer vs snapshot
+rooted = sr.gather(dst=0, packed=False)                                   # torch.distributed.gather: what bench.py times
 assert rooted is not None and torch.equal(rooted, want)
+assert torch.equal(sr.gather(dst=0), narrow)
+sr.rollout(3300, seed=3, chunk=3300)                                      # beyond 3,276 steps the 16-bit totals may wrap: int32 rows
+assert not sr.stepper.packed_rows_exact() and sr.gather().dtype == torch.int32
+assert torch.equal(sr.gather(), sr.stepper.results_from_columns())
 st = ShardedRollout(lambda batch, first_env_id: TTTBatch((3, 5), 3, 3, batch, device="cuda:0", first_env_id=first_env_id), 1000)
 st.rollout(40, seed=1, chunk=40)
 assert torch.equal(st.gather(), st.stepper.results_from_columns())
@@ -50,7 +60,7 @@ print("rccl-world1-ok")
 
 
 def test_gather_through_rccl_world_of_one(run_fresh):
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531",
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="@FREE_PORT@",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     rc, out = run_fresh([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, timeout=300)
     assert rc == 0 and "rccl-world1-ok" in out, out[-3000:]
@@ -61,7 +71,7 @@ def test_bench_under_torchrun_world_of_one(run_fresh):
     process group is created, the timed region contains the RCCL gather, and the JSON line says so."""
     import json
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--master-port", "@FREE_PORT@", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
            "--only-headline", "--no-cpu-baseline"]
     rc, out = run_fresh(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, timeout=600)
     assert rc == 0, out[-3000:]

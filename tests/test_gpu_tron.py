@@ -83,6 +83,8 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
         assert np.array_equal(have, want), k
     import torch
     assert torch.equal(tb.results(), tb.results_from_columns())      # the row the kernel packs == the column statistics
+    assert torch.equal(tb.results_packed(), tb.results_packed_from_columns())   # and its 16-bit encoding (low 16 bits)
+    assert tb.packed_rows_exact() == (sum(chunks) <= 3276)
     return ost
 
 

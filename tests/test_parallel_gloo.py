@@ -35,10 +35,19 @@ class OracleTronStepper:
     def rollout(self, steps, seed):
         self.O.tron_rollout(self.st, seed, self.first, steps, self.sh, self.sd)
 
-    def results(self):
+    def results(self, copy=True):
         s = self.st
         cols = [s.n_episodes, s.len_sum, s.last_winners.astype(np.uint32)] + list(s.win_count) + [r.view(np.uint32) for r in s.ret_sum]
         return torch.from_numpy(np.stack([c.astype(np.uint32).view(np.int32) for c in cols], axis=1).copy())
+
+    # the 16-bit rows of TronBatch.results_packed: n_episodes, len_sum, last_winners, tstep, ret_sum[P] (low 16 bits)
+    def results_packed(self, copy=True):
+        s = self.st
+        cols = [s.n_episodes, s.len_sum, s.last_winners.astype(np.uint32), s.tstep] + [r.view(np.uint32) for r in s.ret_sum]
+        return torch.from_numpy(np.stack([c.astype(np.uint32).astype(np.uint16).view(np.int16) for c in cols], axis=1).copy())
+
+    def packed_rows_exact(self):
+        return int(self.st.tcount.max()) <= 3276
 
 
 def _worker(rank, world, port, total, out_dir):
@@ -52,14 +61,32 @@ def _worker(rank, world, port, total, out_dir):
         assert (sr.lo, sr.hi) == shard_bounds(total, rank, world)
         launches = sr.rollout(70, seed=5, chunk=32)
         assert launches == 3
-        allres = sr.gather().clone()                      # (the receive buffer is reused by the next gather)
-        assert allres.shape[0] == total
+        allres = sr.gather(packed=False)                  # a snapshot (copy=True): later gathers reuse the receive buffer
+        assert allres.shape[0] == total and allres.dtype == torch.int32
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), allres.numpy())
+        narrow = sr.gather()                              # 70 steps: the 16-bit rows are exact and are what "auto" ships
+        assert narrow.dtype == torch.int16 and narrow.shape == (total, 8)
+        np.save(os.path.join(out_dir, "rank%d_packed.npy" % rank), narrow.numpy())
         dst = world - 1                                   # the gather to ONE rank (what bench.py times)
-        rooted = sr.gather(dst=dst)
+        rooted = sr.gather(dst=dst, packed=False)
         assert (rooted is None) == (rank != dst)
         if rank == dst:
             assert torch.equal(rooted, allres)
+            assert torch.equal(sr.gather(dst=dst), narrow)
+        else:
+            assert sr.gather(dst=dst) is None
+        if world >= 3:                                    # a sub-group: `dst` names a rank OF THE GROUP (global rank differs)
+            sub = dist.new_group([1, 2])
+            if rank in (1, 2):
+                sg = ShardedRollout(lambda batch, first_env_id: OracleTronStepper(batch, first_env_id), 20, group=sub)
+                assert (sg.world, sg.rank) == (2, rank - 1)
+                sg.rollout(9, seed=2, chunk=9)
+                got = sg.gather(dst=1, packed=False)      # group rank 1 = global rank 2
+                assert (got is None) == (rank != 2)
+                if rank == 2:
+                    one = OracleTronStepper(20, 0)
+                    one.rollout(9, 2)
+                    assert torch.equal(got, one.results())
     finally:
         dist.destroy_process_group()
 
@@ -71,11 +98,13 @@ def test_sharded_rollout_matches_single_process(tmp_path, world, total):
     single.rollout(32, 5)
     single.rollout(32, 5)
     single.rollout(6, 5)
-    want = single.results().numpy()
+    want, want_packed = single.results().numpy(), single.results_packed().numpy()
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert np.array_equal(got, want), "rank %d gathered a different global result" % r
-    assert want[:, 0].sum() > 0
+        got = np.load(os.path.join(str(tmp_path), "rank%d_packed.npy" % r))
+        assert np.array_equal(got, want_packed), "rank %d gathered different 16-bit rows" % r
+    assert want[:, 0].sum() > 0 and np.array_equal(want_packed[:, :2], want[:, :2])
 
 
 def test_shard_bounds_cover_everything():
