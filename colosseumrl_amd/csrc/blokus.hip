@@ -127,6 +127,12 @@ void build_tables(BlkTables &t)
     }
 }
 
+// rows per shift of the pre-shifted table of the count pass: 28 are used; the stride decides which (shift, row) pairs
+// of a shape x row loop share an LDS bank (tools/sessions: 28 / 29 / 30 / 31 / 33 tried)
+#ifndef BLK_SH_ROWS
+#define BLK_SH_ROWS 28
+#endif
+
 // per-wave working set in LDS
 struct WaveLds {
     uint32_t occ[4][BN];     // board rows per colour, bit x = column x
@@ -136,7 +142,8 @@ struct WaveLds {
             uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
             uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
         } sel;
-        uint2 sh[9][28];     // the player being counted: sh[s][r] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell
+        uint2 sh[9][BLK_SH_ROWS];   // the player being counted: sh[s][r] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell;
+                                    // rows 0..27 are used, the row count sets the LDS bank offset between shifts
     } u;
     uint2 pad9[28];          // {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh`
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
@@ -364,70 +371,84 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const int piece = __builtin_ctzll(hit);
     r -= (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), piece);
     const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
-    // fit masks of the 8 orientations of that piece, all 20 origin rows; the rows outside the board are 0 (the table
+    // the anchors: my row's (lanes 0..19), the rows that have any (a scalar mask), and the origin rows a shape touching
+    // one can have (as blk_row_range)
+    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
+    uint32_t rows_mask = (uint32_t)__ballot(crow != 0u);
+    const int lo = __builtin_ctz(rows_mask), hi = 31 - __builtin_clz(rows_mask);
+    const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4, n_rows = y1 - y0 + 1;
+    // fit masks of the 8 orientations of that piece for those origin rows (no other row is ever asked for: an anchor
+    // row minus a cell's row offset lies inside them or outside the board); the rows outside the board are 0 (the table
     // shares its LDS with the count pass's shifted rows, so they are rewritten every time)
     for (int i = lane; i < 8 * 12; i += 64) {
         const int o = i / 12, k = i - o * 12;
         L.u.sel.fit[o][k < 4 ? k : k + BN] = 0u;         // index 0..3 and 24..31
     }
-    for (int i = lane; i < 8 * BN; i += 64) {
-        const int o = i / BN, y = i - o * BN;
+    auto fit_row = [&](const int o, const int y) {
         const ShapeRegs s = blk_load_shape(T, piece, o);
         uint32_t F = 0xffffffffu;
 #pragma unroll
         for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
         L.u.sel.fit[o][y + 4] = F;                       // bit x+4
-    }
-    // level 2: the anchors in row-major order.  Row lanes scatter their set bits into a list ...
-    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
-    const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
-    const int n_anchor = __builtin_amdgcn_readlane((int)rinc, BN - 1);
-    {
-        uint32_t m = crow;
-        int pos = (int)rinc - __popc(crow);
-        while (m) {
-            const int x = __builtin_ctz(m);
-            m &= m - 1;
-            L.u.sel.alist[pos++] = (uint16_t)((lane << 8) | x);
+    };
+    // (consecutive lanes take consecutive rows of one orientation: distinct LDS banks; the row count is rounded up to a
+    //  power of two so that the split needs no division -- one or two trips of 64 lanes instead of three)
+    if (n_rows <= 16) {
+        const int sh = n_rows <= 8 ? 3 : 4;
+        for (int i = lane; i < (8 << sh); i += 64) {
+            const int yy = i & ((1 << sh) - 1);
+            if (yy < n_rows) fit_row(i >> sh, y0 + yy);
+        }
+    } else {
+        for (int i = lane; i < 8 * BN; i += 64) {
+            const int o = i / BN;
+            fit_row(o, i - o * BN);
         }
     }
     wave_sync();
-    // ... and the wave walks them in order with one lane per (orientation, shift) pair: lane o*n + j asks whether
-    // the piece fits with its cell j on the anchor (origin = anchor - s_j: one bit of the fit table; origin row and
-    // column are always inside the padded table).  The ballot of those answers is the anchor's legal set in
-    // reference order, its popcount the anchor's action count; both stay in scalar registers.
+    // level 2: the anchors in row-major order, one lane per (orientation, shift) pair: lane o*n + j asks whether the piece
+    // fits with its cell j on the anchor (origin = anchor - s_j: one bit of the fit table; origin row and column are
+    // always inside the padded table).  The ballot of those answers is the anchor's legal set in reference order, its
+    // popcount the anchor's action count; both stay in scalar registers.  The anchors themselves are walked on the scalar
+    // unit too -- rows with anchors from `rows_mask`, a row's anchors from its bits (v_readlane of the row lane's mask),
+    // lowest set bit first: no anchor list in LDS, and the fit row is read once per ROW, not per anchor (round 2 listed
+    // the anchors in LDS and paid a dependent LDS round trip per anchor).
+    // lane / n without a division: n is 1..5 and lane < 64 (floor(2^32 / n) + 1 is exact there)
+    const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
     const bool pair = lane < 8 * n;
-    const int po = pair ? lane / n : 0, pj = pair ? lane - po * n : 0;
+    const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
     const uint32_t cb = T.cells[piece * 8 + po][pj];
     const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
     const uint32_t *frow = &L.u.sel.fit[po][8 - dy4];            // frow[ay] = fit[po][ay - dy + 4]
     const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
     BlkMove mv = {piece, 0, 0, 0, 0};
-#ifdef BLK_DIAG_FULLWALK     /* diagnostic builds only: one extra walk over ALL anchors, to price the walk (tools/sessions) */
-    {
-        uint32_t dummy = 0;
-        for (int a = 0; a < n_anchor; ++a) {
-            const int packed = __builtin_amdgcn_readfirstlane((int)L.u.sel.alist[a]);
-            const int ay = packed >> 8, ax = packed & 0xff;
-            dummy += (uint32_t)__builtin_popcountll(__ballot(pair && ((frow[ay] >> (ax + shbase)) & 1u)));
+    // The walk starts from whichever end of the anchor order is nearer in rank: the piece's total is known (pcnt), so an
+    // action in the upper half of the piece's range is counted down from the last anchor -- a quarter of the anchors per
+    // select on average instead of half.
+    const uint32_t ptotal = (uint32_t)__builtin_amdgcn_readlane((int)mine, piece);
+    const bool back = r >= ((ptotal + 1u) >> 1);
+    uint32_t rr = back ? ptotal - 1u - r : r;
+    while (rows_mask) {
+        const int ay = back ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
+        rows_mask &= ~(1u << ay);
+        uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
+        const uint32_t fr = pair ? frow[ay] >> shbase : 0u;      // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
+        while (cr) {
+            const int ax = back ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
+            const uint32_t bit = 1u << ax;
+            cr &= ~bit;
+            const unsigned long long legal = __ballot((fr & bit) != 0u);
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
+            if (rr < cnt) {                                      // level 3: the chosen legal pair at this anchor
+                const int lane_sel = nth_set_bit64(legal, (int)(back ? cnt - 1u - rr : rr));
+                mv.x = ax;
+                mv.y = ay;
+                mv.orient = n == 1 ? lane_sel : (int)__umulhi((uint32_t)lane_sel, inv_n);
+                mv.shift = lane_sel - mv.orient * n;
+                return mv;
+            }
+            rr -= cnt;
         }
-        if (dummy == 0xffffffffu) mv.x = 1;
-    }
-#endif
-    for (int a = 0; a < n_anchor; ++a) {
-        const int packed = __builtin_amdgcn_readfirstlane((int)L.u.sel.alist[a]);
-        const int ay = packed >> 8, ax = packed & 0xff;
-        const unsigned long long legal = __ballot(pair && ((frow[ay] >> (ax + shbase)) & 1u));
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
-        if (r < cnt) {                                           // level 3: the r-th legal pair at this anchor
-            const int lane_sel = nth_set_bit64(legal, (int)r);
-            mv.x = ax;
-            mv.y = ay;
-            mv.orient = lane_sel / n;
-            mv.shift = lane_sel - mv.orient * n;
-            return mv;
-        }
-        r -= cnt;
     }
     return mv;   // unreachable when r < total
 }

@@ -988,20 +988,38 @@ __device__ __forceinline__ void tron_quad_actions(const uint32_t gid, const uint
     a_hi = s16[2] | s16[3] << 16;
 }
 
+// ---- diagnostic build only (-DCRL_QUAD_STAMPS): when each wave of the lane-per-player byte kernel passes its phases
+// (100 MHz wall clock: entry, boards in LDS, steps done, kernel end).  Leaves the kernel through g_quad_stamps alone; the
+// shipped build compiles none of it (tools/debug/quad_phases.py).
+#ifdef CRL_QUAD_STAMPS
+__device__ unsigned long long g_quad_stamps[4096 * 4];
+#define QUAD_STAMP(i)                                                                                          \
+    do {                                                                                                       \
+        const unsigned wid_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                             \
+        if ((threadIdx.x & 63) == 0 && wid_ < 4096u) g_quad_stamps[wid_ * 4u + (i)] = wall_clock64();           \
+    } while (0)
+#else
+#define QUAD_STAMP(i) do { } while (0)
+#endif
+
+#ifndef CRL_QUAD_WG
+#define CRL_QUAD_WG 256          /* threads per workgroup (diagnostic builds: 512 / 1024, tools/sessions) */
+#endif
 template <int RS>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(CRL_QUAD_WG, 1024 / CRL_QUAD_WG)
 tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
                          const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
                          int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
                          int8_t *__restrict__ deaths, const crl_tron_stats st)
 {
-    constexpr int kGames = 64, kWaveGames = 16;
+    constexpr int kGames = CRL_QUAD_WG / 4, kWaveGames = 16;
     constexpr int kRowDwords = RS / 4;
     constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
     constexpr int OB = 3;                                       // P <= 4: owners 1..4, 5 tag bits
     constexpr uint32_t kTags = (1u << (8 - OB)) - 1u;           // the all-ones tag is never used: 0xff stays "wall"
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint8_t act_lut[84];
+    QUAD_STAMP(0);
     tron_fill_action_lut(act_lut);
     const int N = g.N, NN = g.NN, P = cfg.P;
     const int lane = threadIdx.x & (CRL_WAVE - 1);
@@ -1143,6 +1161,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     if (!gvalid) k = 1;
     const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
     __syncthreads();                                            // action table; (non-wide) slabs written by other lanes
+    QUAD_STAMP(1);
     uint32_t a_lo = 0, a_hi = 0;                                // my player's actions of steps 0-15 / 16-31 of the group
     auto refill = [&](const uint32_t group) { tron_quad_actions(gid, group, p, seed_lo, seed_hi, act_lut, a_lo, a_hi); };
     refill(tc >> 5);
@@ -1297,6 +1316,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     } else {
         for (int t = 0; t < T; ++t) one_step(std::false_type{});
     }
+    QUAD_STAMP(2);
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
     tc = tc_in + (uint32_t)T;
@@ -1404,6 +1424,10 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
         if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
     }
+#ifdef CRL_QUAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the stores of this wave have left
+#endif
+    QUAD_STAMP(3);
 }
 
 // ---- replay of unfinished episodes on byte slabs (epilogue of both bitboard kernels) --------------------------------
@@ -3024,7 +3048,17 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
         //  which is the same rollout -- the state and the step counters carry over)
         constexpr int kQuadMaxT = 16383;
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
-            hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, 64)), dim3(256), (size_t)64 * pad.stride, s,
+#if CRL_QUAD_WG > 256
+            {
+                static thread_local int opted = 0;
+                if (!opted) {
+                    CRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tron_rollout_quad_kernel<kRowBytesSmall>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDynamic));
+                    opted = 1;
+                }
+            }
+#endif
+            hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, CRL_QUAD_WG / 4)), dim3(CRL_QUAD_WG), (size_t)(CRL_QUAD_WG / 4) * pad.stride, s,
                                cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0),
                                board, heads, dirs, deaths, st);
             CRL_LAUNCH_CHECK();
@@ -3072,6 +3106,15 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }
+
+#ifdef CRL_QUAD_STAMPS
+int crl_diag_quad_stamps(uint64_t *out, int n)      /* diagnostic builds only: copies n stamps (4 per wave) to the host */
+{
+    CRL_HIP(hipDeviceSynchronize());
+    CRL_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_stamps), (size_t)n * sizeof(uint64_t)));
+    return CRL_OK;
+}
+#endif
 
 int crl_tron_check_state(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads, int32_t *n_bad,
                          void *stream)
