@@ -428,16 +428,22 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const uint32_t ptotal = (uint32_t)__builtin_amdgcn_readlane((int)mine, piece);
     const bool back = r >= ((ptotal + 1u) >> 1);
     uint32_t rr = back ? ptotal - 1u - r : r;
+    // A row at a time: every pair lane counts its legal anchors of the row (one AND, one popcount), a wave sum gives the
+    // row's action count, and rows before the rank's are skipped whole; only inside the rank's row are the anchors looked
+    // at one by one (a ballot, a popcount and a compare each on the scalar unit).
     while (rows_mask) {
         const int ay = back ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
         rows_mask &= ~(1u << ay);
         uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
         const uint32_t fr = pair ? frow[ay] >> shbase : 0u;      // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
-        while (cr) {
+        const uint32_t m = fr & cr;
+        const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
+        if (rr >= row_total) { rr -= row_total; continue; }
+        for (;;) {                                               // rr < row_total: the anchor is in this row
             const int ax = back ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
             const uint32_t bit = 1u << ax;
             cr &= ~bit;
-            const unsigned long long legal = __ballot((fr & bit) != 0u);
+            const unsigned long long legal = __ballot((m & bit) != 0u);
             const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
             if (rr < cnt) {                                      // level 3: the chosen legal pair at this anchor
                 const int lane_sel = nth_set_bit64(legal, (int)(back ? cnt - 1u - rr : rr));
@@ -448,6 +454,7 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
                 return mv;
             }
             rr -= cnt;
+            if (cr == 0u) return mv;                             // (unreachable: the row's counts add up to row_total)
         }
     }
     return mv;   // unreachable when r < total

@@ -84,6 +84,29 @@ def test_rollout_full_size_vs_oracle():
     test_rollout_vs_oracle(16384, (5, 2))
 
 
+def test_full_games_full_size_vs_oracle():
+    """BASELINE config 4 at FULL size, WHOLE games: B = 16,384 games x 84 plies against the oracle on the host's threads.
+    A random game lasts 62-74 plies, so every game ends at least once inside the launch: passes, the one-step terminal
+    lag, the +15 / +20 last-piece bonuses, ties and the auto-reset are all compared at the full batch, every state array
+    and every statistic bit for bit (round 2 compared the opening plies only at this size)."""
+    import os
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    B, seed, first = 16384, 0x5EED, 7 * 16384
+    threads = max(8, min(32, os.cpu_count() or 8))
+    bb = BlokusBatch(B, first_env_id=first)
+    ost = O.BlokusState(B)
+    for T in (60, 24):
+        bb.rollout(T, seed)
+        O.blokus_rollout(ost, seed, first, T, n_threads=threads)
+    for k in ("occ", "inv", "score", "round", "to_move", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum"):
+        want = getattr(ost, k)
+        assert np.array_equal(getattr(bb, k).cpu().numpy().view(want.dtype), want), k
+    assert int(ost.n_episodes.min()) >= 1                                 # every game ended inside the launches
+    assert int(ost.win_count.sum()) >= int(ost.n_episodes.sum())          # ties: more winners than games
+    assert torch.equal(bb.results(), bb.results_from_columns())
+
+
 def test_rollout_full_size_properties():
     """BASELINE config 4 size (B=16384): conservation laws of the fused rollout + shard invariance."""
     import torch

@@ -89,3 +89,46 @@ def test_ttt_long_rollout(dims, K, P):
     for k in ("occ", "winner", "to_move", "tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
         want = getattr(ost, k)
         assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), k
+
+
+def test_ttt_and_blokus_random_configurations():
+    """The differential fuzz of tools/debug/ttt_blokus_fuzz.py as part of the suite (as was done for Tron in round 2): 600
+    random TicTacToe configurations (1-3 dimensions, up to 32 cells, K 1-6, 2-8 players, ragged batches, split launches)
+    and 60 Blokus ones, every state array and statistic against the oracle."""
+    from colosseumrl_amd.batched import BlokusBatch, TTTBatch
+    rng = np.random.default_rng(20261004)
+    done = 0
+    for case in range(600):
+        nd = int(rng.integers(1, 4))
+        while True:
+            dims = tuple(int(rng.integers(1, 9)) for _ in range(nd))
+            if 1 <= int(np.prod(dims)) <= 32:
+                break
+        K, P, B = int(rng.integers(1, 7)), int(rng.integers(2, 9)), int(rng.integers(1, 3000))
+        chunks = [int(rng.integers(1, 500)) for _ in range(int(rng.integers(1, 4)))]
+        seed, first = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+        try:
+            ost = O.TTTState(dims, K, P, B)
+            tb = TTTBatch(dims, K, P, B, first_env_id=first)
+        except Exception:                                   # shapes the library rejects (too many win lines, K out of range)
+            continue
+        for T in chunks:
+            O.ttt_rollout(ost, seed, first, T, n_threads=16)
+            tb.rollout(T, seed)
+        for k in ("occ", "winner", "to_move", "tcount", "tstep", "n_episodes", "win_count", "draw_count", "len_sum"):
+            want = getattr(ost, k)
+            assert np.array_equal(getattr(tb, k).cpu().numpy().view(want.dtype), want), (case, dims, K, P, B, chunks, k)
+        done += 1
+    assert done > 450
+    for case in range(60):
+        B = int(rng.integers(1, 400))
+        chunks = [int(rng.integers(1, 100)) for _ in range(int(rng.integers(1, 4)))]
+        seed, first = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+        bb = BlokusBatch(B, first_env_id=first)
+        ost = O.BlokusState(B)
+        for T in chunks:
+            bb.rollout(T, seed)
+            O.blokus_rollout(ost, seed, first, T, n_threads=16)
+        for k in ("occ", "inv", "score", "round", "to_move", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum"):
+            want = getattr(ost, k)
+            assert np.array_equal(getattr(bb, k).cpu().numpy().view(want.dtype), want), (case, B, chunks, k)

@@ -1,9 +1,8 @@
 #!/bin/bash
-# Diagnostic (GPU box): build blokus.hip with -DBLK_STAMPS, run a rollout, print per-phase cycle shares.
-# The instrumented library is built into a scratch directory and loaded through CRL_LIB_PATH: the in-tree objects and
-# the shipped libcolosseum_hip.so are never touched.
+# Diagnostic (GPU box): per-phase cycle shares of a Blokus rollout step from a -DBLK_STAMPS build.
+# Build the variant in the build container first (it travels with the snapshot):  tools/lib_variant.sh blkstamps blokus -DBLK_STAMPS
 set -euo pipefail
-export CRL_LIB_PATH=$(tools/diag_build.sh stamps -DBLK_STAMPS)
+export CRL_LIB_PATH=${CRL_LIB_PATH:-build/ab_blkstamps/libcolosseum_hip.so}
 python3 - <<'PY'
 import ctypes as C, torch
 from colosseumrl_amd import _native
