@@ -128,7 +128,7 @@ void build_tables(BlkTables &t)
 }
 
 // rows per shift of the pre-shifted table of the count pass: 28 are used; the stride decides which (shift, row) pairs
-// of a shape x row loop share an LDS bank (tools/sessions: 28 / 29 / 30 / 31 / 33 tried)
+// of a shape x row loop share an LDS bank (28 / 29 / 30 / 31 / 33 tried with tools/lib_variant.sh + lib_ab.py: 28 is the fastest)
 #ifndef BLK_SH_ROWS
 #define BLK_SH_ROWS 28
 #endif

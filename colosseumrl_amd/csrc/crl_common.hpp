@@ -63,7 +63,7 @@ void crl_set_error(const char *fmt, ...);
 // a 64-bit product of zero-extended operands into that very pair, hence inline asm).  Measured on gfx950 a v_mad_u64_u32
 // costs what ONE of the pair does (4.4 cycles per wave and SIMD with >= 2 waves, against 2.2 for plain integer VALU:
 // profiles/r2_valu_issue_calibration.json) but has the longer latency, and a Philox round waits for its products: in an
-// A/B on one box (tools/sessions/gpu_session_v.sh) WIDE gained 3 % on the TicTacToe rollouts and 0.5 % on the
+// A/B on one box (tools/README.md) WIDE gained 3 % on the TicTacToe rollouts and 0.5 % on the
 // lane-per-player Tron kernel (>= 4 waves per SIMD cover the latency) and LOST 1-4 % on the lone-wave Tron kernels and
 // 5 % on Blokus.  So it is a per-kernel choice.
 struct philox_out { uint32_t w[4]; };

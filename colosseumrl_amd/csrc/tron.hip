@@ -279,7 +279,7 @@ struct TronRng {
         }
         advance(g, c, k0, k1);
     }
-    // (Tried in round 2, tools/sessions/gpu_session_n.sh: select-based rotation and an out-of-line `unlikely` refill, to save
+    // (Tried in round 2, tools/README.md: select-based rotation and an out-of-line `unlikely` refill, to save
     // the lone wave its taken branches -- +0.9 % on the byte kernel, -1 % on the bitboard kernel: placement noise.)
     __device__ __forceinline__ void advance(const uint32_t g, const uint32_t c, const uint32_t k0, const uint32_t k1)
     {
@@ -1003,7 +1003,7 @@ __device__ unsigned long long g_quad_stamps[4096 * 4];
 #endif
 
 #ifndef CRL_QUAD_WG
-#define CRL_QUAD_WG 256          /* threads per workgroup (diagnostic builds: 512 / 1024, tools/sessions) */
+#define CRL_QUAD_WG 256          /* threads per workgroup (diagnostic builds: 512 / 1024, tools/README.md) */
 #endif
 template <int RS>
 __global__ void __launch_bounds__(CRL_QUAD_WG, 1024 / CRL_QUAD_WG)
@@ -2079,7 +2079,9 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     // loop and its reset branches; one compare per step turns it into one)
     int a = (pvalid && k_in == 0) ? 1 : 0;
     auto store_group = [&](const int grp) {                     // my 16 bytes of group grp of the spare slab
+#ifndef CRL_DIAG_NO_REWRITE     /* diagnostic builds only (WRONG results): what the rolling rewrite of the spare slab costs */
         *(lds_u128 *)(uintptr_t)(uint32_t)(spare_p + 64 * grp) = fresh[grp];
+#endif
     };
     // When every game of the wave enters with its step counter a multiple of four (launches of 4 k steps keep it so),
     // `acts` can only run dry at the end of a four-step trip: the countdown is then kept per trip, not per step.
@@ -2113,7 +2115,11 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         const int pos_was = pos;
         d8 = run ? dir8 : d8;                                   // :44 the direction is committed even if the move dies
         pos = moved ? tgt : pos;
+#ifdef CRL_DIAG_PLAIN_OR           /* diagnostic builds only (WRONG when two players set bits of one word in one step) */
+        *(lds_u32 *)(uintptr_t)(uint32_t)(moved ? wa : jaddr) = word | bit;
+#else
         atomicOr((unsigned int *)(lds + ((moved ? wa : jaddr) - lds0)), bit);
+#endif
         bool alive_now = moved;
 #if defined(CRL_DIAG_NO_SLOW)      /* diagnostic builds only (WRONG results): what the interaction path costs the common one */
         if (false && near == 0u) {
@@ -3017,7 +3023,7 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
     const bool use_quad = quad_ok && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QBITS));
     // the same on bitboards (+ replay): boards above 20x20, where byte slabs would leave a CU with one wave per SIMD.
     // Launches of any length: at 40x40 even a 16-step launch takes 0.15 ms against 0.25 ms on byte slabs (the replay is
-    // cheaper than moving 1,852-byte slabs through a lone wave per SIMD); tools/sessions/gpu_session_z.sh
+    // cheaper than moving 1,852-byte slabs through a lone wave per SIMD); tools/README.md
     const bool qbits_ok = lds_ok && cfg.P <= 4;
     const bool use_qbits = qbits_ok && !use_quad &&
                            ((flags & CRL_ROLLOUT_QBITS) || (!small && !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS))));
@@ -3026,7 +3032,10 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
         // games) at a time: a game stride of 16 dwords mod 32 banks keeps the two games on different banks (the
         // lane-per-game kernel's 4 mod 32 would overlap them)
         TronBits qb = bits;
-        qb.stride = bits.stride - 16 + 64;
+#ifndef CRL_QBITS_PAD
+#define CRL_QBITS_PAD 64            /* bytes behind a game's two slabs: the four junk words + bank padding (tools/lib_variant.sh) */
+#endif
+        qb.stride = bits.stride - 16 + CRL_QBITS_PAD;
         const size_t lds_q = std::max((size_t)64 * qb.stride, (size_t)16 * pad.stride);
         constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, see below)
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
