@@ -281,18 +281,34 @@ def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None)
     """The contract's timed region: exactly `steps` env-steps + the gather of the per-game results, bracketed by
     barrier + synchronize on both sides.  The clock stops when THIS rank's work (incl. the collective, which itself waits
     for the other ranks' shards) has completed on the device; the closing barrier follows, and the caller takes the MAX of
-    the per-rank times -- the time of the slowest rank, without the latency of the closing barrier itself."""
-    ev0, ev1 = events or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    the per-rank times -- the time of the slowest rank, without the latency of the closing barrier itself.
+    `events` = (ev0, ev1) brackets the launches with HIP events on the launch stream (kernel time for the roofline); None
+    leaves them out: next to a collective two timing events cost ~10 us of a ~40 us region (tools/debug/gather_latency.py:
+    39.5 -> 49.0 us in a one-rank RCCL group; 3.6 us without a process group), so runs under a process group measure the
+    launches in a separate pass (`launch_time_pass`)."""
     barrier()
     t0 = time.perf_counter()
-    ev0.record()                                           # same stream the kernels are launched on
+    if events:
+        events[0].record()                                 # same stream the kernels are launched on
     launches = sr.rollout(steps, seed, chunk)
-    ev1.record()
+    if events:
+        events[1].record()
     gathered = sr.gather(dst=dst, copy=False)              # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    return elapsed, ev0.elapsed_time(ev1) * 1e-3, launches, gathered
+    return elapsed, (events[0].elapsed_time(events[1]) * 1e-3 if events else None), launches, gathered
+
+
+def launch_time_pass(torch, sr, steps, seed, chunk, events):
+    """HIP-event time of the launches of one more region of the same shape (no gather), for runs whose contract region
+    carries no events."""
+    torch.cuda.synchronize()
+    events[0].record()
+    sr.rollout(steps, seed, chunk)
+    events[1].record()
+    torch.cuda.synchronize()
+    return events[0].elapsed_time(events[1]) * 1e-3
 
 
 def mean_episode_len(gathered):
@@ -674,15 +690,19 @@ def main():
     # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record,
     # code objects are loaded at first launch, the RCCL communicator comes up at the first collective).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    region_events = None if use_dist else events           # (see timed_rollout: no timing events next to a collective)
     dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
 
     def contract_region():
         """W untimed + K timed steps, exactly as the contract says; returns the timed region's measurements."""
         if args.warmup > 0:
-            timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, events, dst)
+            timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, region_events, dst)
         else:
             sr.gather(dst=dst, copy=False)
-        return timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, events, dst)
+        e, k, n, g = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, region_events, dst)
+        if k is None:
+            k = launch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events)
+        return e, k, n, g
 
     # (1) COLD: the first W + K region of this process, on a box that has just been handed over (memory clocks at idle).
     cold = contract_region()
@@ -739,6 +759,9 @@ def main():
                                          "%.0f ms of device copies + launches on a scratch stepper between the cold region and W + K "
                                          "(value_cold = the same region before it)" % device_warmup_ms)},
             "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
+            "kernel_ms_source": ("HIP events around the launches of the timed region" if region_events else
+                                 "HIP events around the launches of one more region of the same shape (timing events next to a "
+                                 "collective cost ~10 us of the region: not recorded inside it)"),
             "device_warmup_ms": round(device_warmup_ms, 1),
             "value_cold": world * batch * args.steps / cold_elapsed, "cold_first_region_us": cold_elapsed * 1e6,
             "cold_kernel_us": cold[1] * 1e6,
@@ -752,8 +775,8 @@ def main():
                 sr.stepper.reset()
                 sr.stepper.reset_stats()
                 if args.warmup > 0:
-                    timed_rollout(torch, sr, args.warmup, sd, args.chunk, barrier, events, dst)
-                e, _, _, g = timed_rollout(torch, sr, args.steps, sd, args.chunk, barrier, events, dst)
+                    timed_rollout(torch, sr, args.warmup, sd, args.chunk, barrier, region_events, dst)
+                e, _, _, g = timed_rollout(torch, sr, args.steps, sd, args.chunk, barrier, region_events, dst)
                 seeds[str(sd)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
             vals = [v["value"] for v in seeds.values()]
             seeds["spread"] = (max(vals) - min(vals)) / (sum(vals) / len(vals))

@@ -24,7 +24,7 @@
 namespace {
 
 // waves per SIMD the register allocator must leave room for.  Left alone it takes 256 VGPRs (1 wave/SIMD, the
-// 16,384 one-wave games of BASELINE config 4 then run in 16 rounds).  Measured on MI355X (tools/blokus_occ_sweep.sh):
+// 16,384 one-wave games of BASELINE config 4 then run in 16 rounds).  Measured on MI355X (-DBLK_WAVES_PER_SIMD=n variants, tools/lib_variant.sh):
 // 4/5/6/8 waves per SIMD -> 244/237/256/265 M env-steps/s; 8 (64 VGPRs + 96 B of spills) wins.
 #ifndef BLK_WAVES_PER_SIMD
 #define BLK_WAVES_PER_SIMD 8

@@ -50,4 +50,54 @@ for name, payload in (("wide 44 B/game", wide), ("packed 16 B/game", narrow)):
             ts.append(time.perf_counter() - t0)
         ts.sort()
         print("%-18s %-24s median %.1f us  p10 %.1f  min %.1f" % (name, label, ts[150] * 1e6, ts[30] * 1e6, ts[0] * 1e6), flush=True)
+
+# what precedes the region matters: bench.py's contract region comes right after barrier + synchronise
+from colosseumrl_amd.parallel import ShardedRollout  # noqa: E402
+sr = ShardedRollout(lambda batch, first_env_id: TronBatch(20, 4, batch, first_env_id=first_env_id), B)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def region(before, events):
+    ts, ks = [], []
+    for i in range(120):
+        torch.cuda.synchronize()
+        before()
+        t0 = time.perf_counter()
+        if events:
+            e0.record()
+        sr.rollout(20, 0, 20)
+        if events:
+            e1.record()
+        sr.gather(dst=0, copy=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        if events:
+            ks.append(e0.elapsed_time(e1))
+        if i % 40 == 39:
+            sr.stepper.reset_stats()
+    ts.sort(); ks.sort()
+    return ts[60] * 1e6, (ks[60] * 1e3 if ks else 0.0)
+
+
+def nothing():
+    pass
+
+
+def barrier():
+    dist.barrier()
+    torch.cuda.synchronize()
+
+
+def sleep200():
+    time.sleep(200e-6)
+
+
+def sleep1ms():
+    time.sleep(1e-3)
+
+
+for label, before in (("nothing", nothing), ("dist.barrier + sync", barrier), ("sleep 200 us", sleep200), ("sleep 1 ms", sleep1ms)):
+    for ev in (False, True):
+        r, k = region(before, ev)
+        print("before the region: %-20s events %-5s region median %.1f us  kernel (events) %.1f us" % (label, ev, r, k), flush=True)
 dist.destroy_process_group()
