@@ -377,6 +377,20 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     wall, gpu = rate(eager, 1000)
     out["tron_n20_step_auto_reset"] = {"env_steps_per_s": B / wall, "us_per_call": wall * 1e6, "gpu_us_per_call": gpu * 1e6,
                                        "algorithmic_GBs": (12 * P + 2) * B / gpu / 1e9, "games": B}
+    # what the call really moves: rocprofv3 PMC 2 x FETCH_SIZE + WRITE_SIZE per dispatch (profiles/traffic_step_api.json).
+    # crl_tron_step probes and writes single bytes, each a 64-byte sector: ~10x its algorithmic 50 B / game -- and still LESS
+    # than streaming the boards through LDS would (N*N in + the touched sectors out: (N*N + 50) x B = 29.5 MB one way)
+    tj = (_load_json(os.path.join(ROOT, "profiles", "traffic_step_api.json")) or {}).get("kernels", {})
+
+    def pmc_bytes(kernel):
+        return (tj.get(kernel) or {}).get("hbm_bytes_per_call")
+    if pmc_bytes("tron_step_kernel<4>"):
+        nb = pmc_bytes("tron_step_kernel<4>")
+        out["tron_n20_step_auto_reset"].update({"hbm_bytes_per_call_pmc": nb, "sector_GBs": nb / gpu / 1e9,
+                                                "sector_frac_of_hbm_peak": nb / gpu / 1e9 / HBM_PEAK_GBS,
+                                                "board_streaming_bytes": (N * N + 12 * P + 2) * B,
+                                                "note": "byte probes / trail writes move whole 64-byte sectors; for a step that also "
+                                                        "needs observations use step_observe (one coalesced read of every board)"})
     # the same 16 calls recorded once into a HIP graph and replayed: what a caller that steps in a loop should do about the
     # launch boundary (the call is launch- / latency-bound: 3.3 MB of traffic)
     try:
@@ -421,7 +435,7 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
                                               "GBs": nbytes / gpu / 1e9, "frac_of_hbm_peak": nbytes / gpu / 1e9 / HBM_PEAK_GBS,
                                               "frac_of_copy": nbytes / gpu / 1e9 / copy_gbs if copy_gbs else None,
                                               "frac_of_stream": nbytes / gpu / 1e9 / stream_gbs if stream_gbs else None,
-                                              "bytes_per_call": nbytes,
+                                              "bytes_per_call": nbytes, "hbm_bytes_per_call_pmc": pmc_bytes("tron_step_observe_kernel<4, 64>"),
                                               "what": "ONE launch: sample -> next_state (auto-reset) -> state_to_observation of all P observers; "
                                                       "bytes counted = N*N in + P*N*N out per game"}
     wall, gpu = rate(lambda: tb.ranking(), 200)

@@ -18,6 +18,20 @@ shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, prefix + "_rocp
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:                                       # gpurun merges runs into the same directory: take the newest
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, prefix + "_kernel_stats.csv"))
+if len(sys.argv) == 3 and prefix.endswith("step_api"):
+    # the per-step API pass: HBM bytes per CALL of every kernel that has both PMC passes -> profiles/traffic_step_api.json
+    summ = json.load(open(os.path.join(src, "summary.json")))
+    rec = {}
+    for name, vals in summ.get("pmc", {}).items():
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and "namespace" in name:
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
+            rec[short] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+                          "hbm_bytes_per_call": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)}
+    json.dump({"note": "bench.py --only-step-api under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): per-dispatch averages; "
+                       "hbm_bytes_per_call = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction of MI355X_MICROARCH.md)",
+               "source": "profiles/%s_rocprofv3_summary.json" % prefix, "kernels": rec},
+              open(os.path.join(dst, "traffic_step_api.json"), "w"), indent=1)
+    print(json.dumps({k: v["hbm_bytes_per_call"] for k, v in rec.items()}))
 if len(sys.argv) > 3:
     workload, kern, spl = sys.argv[3], sys.argv[4], int(sys.argv[5])
     summ = json.load(open(os.path.join(src, "summary.json")))
