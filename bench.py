@@ -282,7 +282,10 @@ def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None)
     barrier + synchronize on both sides.  The clock stops when THIS rank's work (incl. the collective, which itself waits
     for the other ranks' shards) has completed on the device; the closing barrier follows, and the caller takes the MAX of
     the per-rank times -- the time of the slowest rank, without the latency of the closing barrier itself.
-    `events` = (ev0, ev1) brackets the launches with HIP events on the launch stream (kernel time for the roofline); None
+    `events` = (ev0, ev1) brackets the launches with HIP events on the launch stream (kernel time for the roofline; two
+    hipEventRecord calls = 3.6 us of the region.  Events ATTACHED to the dispatch -- crl_tron_rollout_timed -- give the
+    kernel's own duration, 16.7 us against the 19.7 us between two recorded markers, but that launch path costs the host
+    5 us more: it is used by `dispatch_time_pass`, not here); None
     leaves them out: next to a collective two timing events cost ~10 us of a ~40 us region (tools/debug/gather_latency.py:
     39.5 -> 49.0 us in a one-rank RCCL group; 3.6 us without a process group), so runs under a process group measure the
     launches in a separate pass (`launch_time_pass`)."""
@@ -298,6 +301,20 @@ def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None)
     elapsed = time.perf_counter() - t0
     barrier()
     return elapsed, (events[0].elapsed_time(events[1]) * 1e-3 if events else None), launches, gathered
+
+
+def dispatch_time_pass(torch, sr, steps, seed, chunk, events, reps=20):
+    """The launches' own duration: HIP events attached to the first / last dispatch (crl_tron_rollout_timed; Tron only),
+    median over `reps` isolated regions of the timed shape.  None for steppers without that entry point."""
+    if not getattr(sr.stepper, "rollout_takes_events", False):
+        return None
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        sr.rollout(steps, seed, chunk, events=events)
+        torch.cuda.synchronize()
+        ts.append(events[0].elapsed_time(events[1]) * 1e-3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def launch_time_pass(torch, sr, steps, seed, chunk, events):
@@ -614,6 +631,7 @@ def compact_summary(out):
                 "valu": sig(r.get("valu_issue", {}).get("frac"), 3),
                 "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
     sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig(out["kernel_ms"] * 1e3),
+                       "kernel_dispatch_us": sig((out.get("kernel_ms_dispatch") or 0) * 1e3) or None,
                        "hbm": sig(out["roofline"].get("frac"), 3), "of_copy": sig(out["roofline"].get("frac_of_copy"), 3),
                        "alg": sig(out["roofline"]["algorithmic"]["frac"], 3), "cold_v": sig(out.get("value_cold")),
                        "cold_us": sig(out.get("cold_first_region_us")), "gather_us": (out.get("gather") or {}).get("gather_us")}}
@@ -704,6 +722,9 @@ def main():
     # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record,
     # code objects are loaded at first launch, the RCCL communicator comes up at the first collective).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in events:
+        e.record()                                         # creates the HIP events (torch does so lazily)
+    torch.cuda.synchronize()
     region_events = None if use_dist else events           # (see timed_rollout: no timing events next to a collective)
     dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
 
@@ -745,6 +766,7 @@ def main():
         sr.stepper.reset_stats()
         elapsed, kernel_s, launches, gathered = contract_region()
     cold_elapsed = cold[0]
+    kernel_dispatch_s = dispatch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events) if args.steps <= 4096 else None
     if use_dist:
         tt = torch.tensor([elapsed, cold_elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -777,6 +799,7 @@ def main():
                                  "HIP events around the launches of one more region of the same shape (timing events next to a "
                                  "collective cost ~10 us of the region: not recorded inside it)"),
             "device_warmup_ms": round(device_warmup_ms, 1),
+            "kernel_ms_dispatch": kernel_dispatch_s * 1e3 if kernel_dispatch_s else None,
             "value_cold": world * batch * args.steps / cold_elapsed, "cold_first_region_us": cold_elapsed * 1e6,
             "cold_kernel_us": cold[1] * 1e6,
             "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),

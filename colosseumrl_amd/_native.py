@@ -74,6 +74,7 @@ PROTOTYPES = {
     "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_step": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "crl_tron_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, TronStats, _U32, _VP]),
+    "crl_tron_rollout_timed": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, _VP, TronStats, _U32, _VP, _VP, _VP]),
     "crl_tron_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_observe_all": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_ranking": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),

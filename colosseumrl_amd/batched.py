@@ -166,17 +166,29 @@ class TronBatch:
                                                    self._results, self._packed)])
 
     # -- T fused random-agent steps with auto-reset
-    def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto"):
+    def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto", events=None):
         """``kernel``: "auto" (library's choice), "quad" / "qbits" / "bits" / "bytes" (pin one of the LDS kernels) or "global";
-        ``use_lds=False`` is the older spelling of "global".  All kernels give identical results."""
+        ``use_lds=False`` is the older spelling of "global".  All kernels give identical results.
+        ``events``: an optional pair (start, stop) of ``torch.cuda.Event(enable_timing=True)`` -- either may be None -- that
+        have been recorded at least once (torch creates the HIP event at the first record): the launch carries them in
+        its dispatch (``crl_tron_rollout_timed``), so ``start.elapsed_time(stop)`` after a synchronise is the rollout's
+        kernel time without marker packets around it."""
         flags = _ROLLOUT_KERNEL_FLAGS[kernel]
         if not use_lds:
             flags = _native.CRL_ROLLOUT_NO_LDS
         if self._rollout_args is None:       # the state / statistics tensors are never reallocated: bind them once
             self._rollout_args = (_ptr(self.board), _ptr(self.heads), _ptr(self.dirs), _ptr(self.deaths), self._stats())
         with _DevGuard(self.device):
-            rc = self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
-                                            *self._rollout_args, flags, _stream())
+            if events is None:
+                rc = self._lib.crl_tron_rollout(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id, int(steps),
+                                                *self._rollout_args, flags, _stream())
+            else:
+                handles = [C.c_void_p(e.cuda_event) if e is not None else None for e in events]
+                if any(e is not None and not e.cuda_event for e in events):
+                    raise ValueError("rollout(events=...): record() each event once before passing it (torch creates the "
+                                     "HIP event lazily)")
+                rc = self._lib.crl_tron_rollout_timed(self._ctx.handle, self.B, seed & (2 ** 64 - 1), self.first_env_id,
+                                                      int(steps), *self._rollout_args, flags, _stream(), handles[0], handles[1])
         if rc:
             check(rc, "crl_tron_rollout")
         self._stat_steps += int(steps)
@@ -274,6 +286,8 @@ class TronBatch:
         itself at the end of every launch (``crl_tron_stats.results``): no packing pass.  By default a snapshot;
         ``copy=False`` hands out the live buffer, which the next rollout rewrites in place."""
         return self._results.clone() if copy else self._results
+
+    rollout_takes_events = True    # rollout(events=(start, stop)): HIP events attached to the dispatches
 
     PACKED_EXACT_STEPS = 3276      # |ret_sum| <= 10 per step: the int16 fields hold the totals of this many steps
 

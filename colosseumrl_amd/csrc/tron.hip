@@ -29,6 +29,7 @@
 //     in place at the end.
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <algorithm>
 
@@ -2984,10 +2985,19 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
     return CRL_OK;
 }
 
-int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
-                     int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
-                     crl_tron_stats st, uint32_t flags, void *stream)
+static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                             int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                             crl_tron_stats st, uint32_t flags, void *stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    // every launch of the rollout goes through here: with events, the FIRST launch carries the start event and the LAST one
+    // the stop event in the dispatch itself (hipExtLaunchKernelGGL) -- no marker packets around the kernels
+    bool first_launch = true;
+    auto launch = [&](auto kernel, const dim3 grid, const dim3 block, const size_t lds_bytes, const bool last, auto... args) {
+        hipEvent_t e0 = first_launch ? ev_start : nullptr, e1 = last ? ev_stop : nullptr;
+        first_launch = false;
+        if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds_bytes, (hipStream_t)stream, e0, e1, 0u, args...);
+        else hipLaunchKernelGGL(kernel, grid, block, lds_bytes, (hipStream_t)stream, args...);
+    };
     TRON_CTX_CHECK("crl_tron_rollout");
     CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_rollout: NULL state pointer");
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
@@ -3041,12 +3051,13 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
             const int tt = std::min(kQuadMaxT, T - t0);
             TRON_DISPATCH_P4(cfg.P, {
+                const bool last = t0 + kQuadMaxT >= T;
                 if (small)
-                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, false>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, qb, B,
-                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                    launch(tron_rollout_qbits_kernel<PP, false>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last, cfg, g, pad, qb, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
                 else
-                    hipLaunchKernelGGL((tron_rollout_qbits_kernel<PP, true>), dim3(blocks_for(B, 64)), dim3(256), lds_q, s, cfg, g, pad, qb, B,
-                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                    launch(tron_rollout_qbits_kernel<PP, true>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last, cfg, g, pad, qb, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
             });
             CRL_LAUNCH_CHECK();
         }
@@ -3067,9 +3078,9 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
                 }
             }
 #endif
-            hipLaunchKernelGGL((tron_rollout_quad_kernel<kRowBytesSmall>), dim3(blocks_for(B, CRL_QUAD_WG / 4)), dim3(CRL_QUAD_WG), (size_t)(CRL_QUAD_WG / 4) * pad.stride, s,
-                               cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0),
-                               board, heads, dirs, deaths, st);
+            launch(tron_rollout_quad_kernel<kRowBytesSmall>, dim3(blocks_for(B, CRL_QUAD_WG / 4)), dim3(CRL_QUAD_WG), (size_t)(CRL_QUAD_WG / 4) * pad.stride,
+                   t0 + kQuadMaxT >= T, cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0),
+                   board, heads, dirs, deaths, st);
             CRL_LAUNCH_CHECK();
         }
         return CRL_OK;
@@ -3096,24 +3107,40 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
             const dim3 grid(blocks_for(B, threads));
             const dim3 block(threads);
             if (use_bits && small)
-                hipLaunchKernelGGL((tron_rollout_bits_kernel<PP, false>), grid, block, lds_bytes, s, cfg, g, pad, bits, B,
-                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+                launch(tron_rollout_bits_kernel<PP, false>, grid, block, lds_bytes, true, cfg, g, pad, bits, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
             else if (use_bits)
-                hipLaunchKernelGGL((tron_rollout_bits_kernel<PP, true>), grid, block, lds_bytes, s, cfg, g, pad, bits, B,
-                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+                launch(tron_rollout_bits_kernel<PP, true>, grid, block, lds_bytes, true, cfg, g, pad, bits, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
             else if (small)
-                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesSmall>), grid, block, lds_bytes, s, cfg, g, pad, B,
-                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+                launch(tron_rollout_lds_kernel<PP, kRowBytesSmall>, grid, block, lds_bytes, true, cfg, g, pad, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
             else
-                hipLaunchKernelGGL((tron_rollout_lds_kernel<PP, kRowBytesLarge>), grid, block, lds_bytes, s, cfg, g, pad, B,
-                                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+                launch(tron_rollout_lds_kernel<PP, kRowBytesLarge>, grid, block, lds_bytes, true, cfg, g, pad, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         } else {
-            hipLaunchKernelGGL((tron_rollout_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
+            launch(tron_rollout_kernel<PP>, dim3(blocks_for(B, 256)), dim3(256), (size_t)0, true, cfg, g, B,
+                   (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, board, heads, dirs, deaths, st);
         }
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
+}
+
+int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                     int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                     crl_tron_stats st, uint32_t flags, void *stream)
+{
+    return tron_rollout_impl(ctx, B, seed, first_env_id, T, board, heads, dirs, deaths, st, flags, stream, nullptr, nullptr);
+}
+
+int crl_tron_rollout_timed(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                           int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                           crl_tron_stats st, uint32_t flags, void *stream, void *start_event, void *stop_event)
+{
+    CRL_REQUIRE(T > 0 || (!start_event && !stop_event), "crl_tron_rollout_timed: no launch to attach the events to (T = 0)");
+    return tron_rollout_impl(ctx, B, seed, first_env_id, T, board, heads, dirs, deaths, st, flags, stream,
+                             (hipEvent_t)start_event, (hipEvent_t)stop_event);
 }
 
 #ifdef CRL_QUAD_STAMPS

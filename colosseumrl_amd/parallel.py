@@ -99,12 +99,16 @@ class ShardedRollout:
         self._equal = self.total % self.world == 0          # equal shards: the local rows go into the collective as they are
         self._recv = {}                                     # (dtype, row shape) -> (receive buffer, its per-rank pieces)
 
-    def rollout(self, steps: int, seed: int = 0, chunk: int = 512) -> int:
-        """Exactly `steps` env-steps for every local game, as fused launches of <= chunk steps."""
+    def rollout(self, steps: int, seed: int = 0, chunk: int = 512, events=None) -> int:
+        """Exactly `steps` env-steps for every local game, as fused launches of <= chunk steps.  ``events`` = (start, stop)
+        torch events a stepper that supports it (``TronBatch.rollout(events=...)``) carries in the first / last launch."""
         launches, left = 0, int(steps)
         while left > 0:
             t = min(int(chunk), left)
-            self.stepper.rollout(t, seed)
+            if events is None:
+                self.stepper.rollout(t, seed)
+            else:
+                self.stepper.rollout(t, seed, events=(events[0] if launches == 0 else None, events[1] if left == t else None))
             left -= t
             launches += 1
         return launches

@@ -154,6 +154,15 @@ int crl_tron_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t firs
                      int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                      crl_tron_stats stats, uint32_t flags, void *stream);
 
+/* crl_tron_rollout with HIP events ATTACHED TO THE DISPATCHES: start_event (hipEvent_t as void*, may be NULL) is updated
+ * with the start of the rollout's first kernel, stop_event (may be NULL) with the end of its last one
+ * (hipExtLaunchKernelGGL) -- the kernel time of a short launch without the marker packets and the ~3.6 us of host time
+ * two hipEventRecord calls around it cost.  The events must have been created (and, for hipEventElapsedTime, are complete
+ * once the stream is synchronised).  No reference counterpart. */
+int crl_tron_rollout_timed(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
+                           int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
+                           crl_tron_stats stats, uint32_t flags, void *stream, void *start_event, void *stop_event);
+
 /* Counts (adds to *n_bad, a device int32 the caller zeroes) the games whose state breaks what every state produced by
  * crl_tron_reset / _step / _rollout satisfies and the LDS rollout kernels rely on: every head inside the board and
  * board[heads[p]] == p + 1.  For callers that upload hand-made states before a rollout.  No reference counterpart. */

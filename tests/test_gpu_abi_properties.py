@@ -172,3 +172,30 @@ def test_observe_with_out_of_range_player_ids():
     got = tb.observe(pl)
     for k in ("board", "heads", "directions", "deaths"):
         assert torch.equal(ref[k], got[k]), k
+
+
+@pytest.mark.parametrize("N,P,T,kernel", [(20, 4, 20, "auto"), (20, 4, 16383 + 40, "auto"), (40, 4, 64, "auto"), (12, 6, 50, "auto"),
+                                         (20, 4, 30, "global")])
+def test_rollout_with_events_attached_to_the_dispatches(N, P, T, kernel):
+    """crl_tron_rollout_timed: the start / stop events ride in the first / last dispatch of the rollout
+    (hipExtLaunchKernelGGL).  Same results as the plain call, a plausible elapsed time, either event optional."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    B = 4096 + 3
+    a, b = TronBatch(N, P, B), TronBatch(N, P, B)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with pytest.raises(ValueError):
+        a.rollout(T, 5, kernel=kernel, events=(e0, e1))          # never recorded: torch has not created the HIP events
+    e0.record(); e1.record()
+    torch.cuda.synchronize()
+    a.rollout(T, 5, kernel=kernel, events=(e0, e1))
+    b.rollout(T, 5, kernel=kernel)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert 0.0 < ms < 50.0, ms
+    for k in ("board", "heads", "dirs", "deaths", "tcount", "ret_sum", "n_episodes"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    a.rollout(7, 5, kernel=kernel, events=(None, e1))
+    a.rollout(7, 5, kernel=kernel, events=(e0, None))
+    b.rollout(14, 5, kernel=kernel)
+    assert torch.equal(a.board, b.board) and torch.equal(a.results(), b.results())
