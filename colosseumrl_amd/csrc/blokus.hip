@@ -251,6 +251,9 @@ __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const
 
 // actions contributed by one oriented shape when its origin lies in rows [y0, y1]; any_only: stop at the first hit.
 // blk_build_shifted(q) must have run.
+// (Tried in round 3: cell 0 of every shape is its origin, i.e. the same table row in all 64 lanes, so with wave-uniform
+//  rows it can come out of a register by v_readlane instead of out of the LDS -- four reads per row instead of five.
+//  7 % SLOWER: the pass is bound by instruction issue, not by the LDS, and a v_readlane with a scalar index stalls.)
 template <bool ANY_ONLY>
 __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const ShapeRegs &s, const bool active,
                                                     const int y0, const int y1)
@@ -261,8 +264,7 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Shap
 #pragma unroll
     for (int j = 0; j < 5; ++j) cellrow[j] = (j < s.n) ? &L.u.sh[s.sh(j)][s.ro(j)] : &L.pad9[s.ro(j)];
     uint32_t cnt = 0;
-#pragma nounroll
-    for (int y = y0; y <= y1; ++y) {
+    auto one_row = [&](const int y) {
         uint2 v[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) v[j] = cellrow[j][y];
@@ -270,8 +272,29 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Shap
         // bit x+4 of v[j].y: cell j of the shape at origin (x, y) is an anchor.  (v_bcnt_u32_b32 adds its second operand:
         // accumulate in the instruction itself; left to the compiler the five counts go through a tree of v_add3)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & v[j].y));
-        if (ANY_ONLY && __ballot(active && cnt > 0)) break;
+        for (int j = 0; j < 5; ++j) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & v[j].y));
+    };
+#ifndef BLK_COUNT_UNROLL
+#define BLK_COUNT_UNROLL 4
+#endif
+    if (ANY_ONLY) {
+#pragma nounroll
+        for (int y = y0; y <= y1; ++y) {
+            one_row(y);
+            if (__ballot(active && cnt > 0)) break;
+        }
+    } else {
+        // BLK_COUNT_UNROLL rows per trip, one after the other through the same registers: the row offset is an immediate of
+        // the LDS reads, so the five table pointers move once per trip instead of once per row (5 of a row's 17 VALU) and the
+        // loop control is shared
+        int y = y0;
+#pragma nounroll
+        for (; y + BLK_COUNT_UNROLL - 1 <= y1; y += BLK_COUNT_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < BLK_COUNT_UNROLL; ++u) one_row(y + u);
+        }
+#pragma nounroll
+        for (; y <= y1; ++y) one_row(y);
     }
     return active ? cnt : 0u;
 }

@@ -3008,7 +3008,6 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
     if (T == 0) return CRL_OK;
-    hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
     // LDS-resident kernels.  Byte slabs: 256 games per workgroup on boards up to 20x20, 64 (one wave) up to 40x40.
     // Bitboards (T >= 256): 256 games per workgroup either way; the replay takes the byte slabs one wave at a time
