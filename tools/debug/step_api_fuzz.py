@@ -18,8 +18,8 @@ for case in range(n_cases):
     T, seed, first = int(rng.integers(1, 40)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
     a, b, c = (TronBatch(N, P, B, first_env_id=first) for _ in range(3))
     for t in range(T):
-        fusable = (N * N) % 16 == 0 and P < 8            # else the library takes three launches and wants explicit actions
-        oa = a.step_observe(None if fusable else a.sample(seed), seed=seed)
+        # (shapes the 16-byte fused kernel cannot take -- N*N % 16 != 0, P = 8 -- run the one-game-per-workgroup kernel)
+        oa = a.step_observe(None, seed=seed)
         b.step(b.sample(seed), auto_reset=True)
         ob = b.observe_all()
         for k in ("board", "heads", "directions", "deaths"):
