@@ -60,7 +60,7 @@ class BlokusVectorEnv:
     """B turn-based Blokus games (4 players, 20x20).  ``step`` takes int32 dense action ids [B] for the player to move
     (``envs.blokus.actions``: ``((piece*400 + y*20 + x)*8 + orientation)*5 + shift``; -1 = pass, the reference's '').
     Like the reference's ``next_state`` it does not validate actions (``match_server`` does, via ``is_valid_action``):
-    pick them from ``sample_valid`` / ``valid_mask``."""
+    pick them from ``valid_list`` / ``select`` / ``sample_valid`` (or test them with ``is_valid``)."""
 
     def __init__(self, batch: int = 1024, device="cuda"):
         self.batch = BlokusBatch(batch, device=device)
@@ -78,6 +78,21 @@ class BlokusVectorEnv:
     def valid_mask(self) -> torch.Tensor:
         """Dense legal-action bitmap int32 [B, 10500] of the player to move (42 KB per game: meant for small B)."""
         return self.batch.valid(want_mask=True)[1]
+
+    def valid_list(self, cap: int = 2048, out=None):
+        """(count int32 [B], ids int32 [B, cap]): the ORDERED legal action ids of the player to move, compacted -- what the
+        reference's ``valid_actions`` returns (BlokusEnvironment.py:453-500), for every game; ``ids[b, :count[b]]`` ascending
+        = reference order, -1 beyond.  1,693 is the longest list seen in reference-played games."""
+        return self.batch.valid_list(cap, out=out)
+
+    def select(self, rank: torch.Tensor) -> torch.Tensor:
+        """Dense id of the rank[b]-th legal action (reference order) of the player to move, -1 where rank is outside
+        [0, count): lets a policy that emits an index into the legal list act without materialising the list."""
+        return self.batch.select(rank)[0]
+
+    def is_valid(self, action: torch.Tensor) -> torch.Tensor:
+        """uint8 [B]: 1 iff action[b] is a legal action of the player to move (``is_valid_action`` for all games)."""
+        return self.batch.is_valid(action)
 
     def sample_valid(self, seed: int = 0) -> torch.Tensor:
         """A uniformly drawn legal action id per game (-1 where the mover must pass)."""
