@@ -138,3 +138,40 @@ def test_tictactoe_current_rewards_golden(golden, name, env_name):
         assert got == want.tolist() and all(isinstance(r, int) for r in got)
         seen.add(int(winner))
     assert seen == set(range(-1, env.max_players))          # undecided states and every possible winner are covered
+
+
+def test_single_state_path_makes_no_copies():
+    """The drop-in classes and their stepper (colosseumrl_amd/single.py) stage states in host-mapped memory: no torch
+    tensors, no hipMemcpy -- one launch chain and ONE blocking call (crl_stream_synchronize) per GPU call.  Static check
+    of the sources (the GPU suite checks the behaviour)."""
+    import re
+    pkg = os.path.join(ROOT, "colosseumrl_amd")
+    files = [os.path.join(pkg, "single.py")]
+    for sub in ("tron", "tictactoe", "blokus"):
+        d = os.path.join(pkg, "envs", sub)
+        files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".py")]
+    for path in files:
+        src = open(path).read()
+        code = re.sub(r'""".*?"""', "", src, flags=re.S)
+        code = re.sub(r"#.*", "", code)
+        assert "torch" not in code, path + " touches torch: the single-state path must not go through device tensors"
+        assert ".cpu()" not in code and "copy_(" not in code, path
+    single = open(files[0]).read()
+    # every public GPU call of a stepper ends in exactly one synchronise
+    for name in ("step_observe", "observe", "ranking", "reset", "step", "valid", "legal_ids", "is_valid"):
+        bodies = re.findall(r"    def %s\(self.*?(?=\n    def |\nclass |\Z)" % name, single, flags=re.S)
+        assert bodies, name
+        for body in bodies:
+            assert body.count("self.sync()") == 1, (name, body.count("self.sync()"))
+
+
+def test_without_a_gpu_the_single_state_steppers_raise():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from colosseumrl_amd import get_environment
+    for name, args in (("tictactoe", ()), ("blokus", ())):
+        env = get_environment(name)(*args)
+        state, players = env.new_state()                 # host objects only
+        with pytest.raises(_native.NativeError):
+            env.valid_actions(state, players[0])
