@@ -264,3 +264,37 @@ def test_blokus_dropin_vs_oracle_full_game():
             assert sum(1 << w for w in winners) == int(w2[0])
             break
     assert terminal and t > 50
+
+
+def test_dropin_instances_are_independent_across_threads():
+    """Several env instances live in one process under the GIL (MatchmakingServer.py:128-135): each owns its context, its
+    host-mapped staging block and its stream, so four threads playing four games at once reproduce what each game gives
+    when played alone."""
+    import threading
+    from colosseumrl_amd import get_environment
+    names = {0: "forward", 1: "right", -1: "left"}
+
+    def play(seed, out):
+        env = get_environment("tron")("20;4")
+        rng = np.random.default_rng(seed)
+        state, players = env.new_state()
+        trace = []
+        for _ in range(60):
+            acts = [names[int(x)] for x in rng.integers(-1, 2, size=4)]
+            state, players, rewards, terminal, winners = env.next_state(state, [0, 1, 2, 3], acts)
+            obs = env.state_to_observation(state, int(rng.integers(0, 4)))
+            trace.append((state[1].tolist(), state[3].tolist(), rewards.tolist(), int(obs["board"].sum())))
+            if terminal:
+                state, players = env.new_state()
+        out[seed] = trace
+
+    alone = {}
+    for seed in range(4):
+        play(seed, alone)
+    together = {}
+    threads = [threading.Thread(target=play, args=(seed, together)) for seed in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert together == alone
