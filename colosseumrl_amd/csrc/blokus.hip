@@ -241,10 +241,14 @@ __device__ __forceinline__ ShapeRegs blk_load_shape(const BlkTables &T, const in
 // offset, a cell test is one 8-byte LDS read and two ANDs instead of a read, two variable shifts and two ANDs.
 __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const int lane)
 {
-    for (int i = lane; i < 9 * 28; i += 64) {
-        const int sft = i / 28, r = i - sft * 28;
+    // one trip: lanes 0..27 take a row each and its shifts 0..4, lanes 32..59 the same rows' shifts 5..8 (one read, five /
+    // four 8-byte writes per lane; as 252 (shift, row) items over 64 lanes it was four trips with a division each)
+    const int r = lane & 31, s0 = lane < 32 ? 0 : 5;
+    if (r < 28) {
         const uint2 v = L.ac[q][r];
-        L.u.sh[sft][r] = make_uint2(v.x >> sft, v.y >> sft);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (s0 + k < 9) L.u.sh[s0 + k][r] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
     }
     wave_sync();
 }
@@ -347,12 +351,14 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
 }
 
 // legal-action count per piece of player q into L.pcnt[], returns the total (valid_actions length)
-__device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane)
+// *piece_incl (lane p: the inclusive prefix of the per-piece counts up to piece p) is what level 1 of blk_select needs
+__device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
+                                              uint32_t *piece_incl = nullptr)
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
     if (lane < 32) L.pcnt[lane] = 0;
-    if (y1 < y0) { wave_sync(); return 0; }
+    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; return 0; }
     const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
     blk_build_shifted(L, q, lane);
     // 64 lanes per batch of shapes.  A batch with at most 32 (16) shapes left gives each shape two (four) lanes, each with
@@ -379,17 +385,21 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     wave_sync();
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
     const uint32_t total = wave_scan_incl(mine, lane);
+    if (piece_incl) *piece_incl = total;
     return (uint32_t)__builtin_amdgcn_readlane((int)total, 63);
 }
 
 struct BlkMove { int piece, x, y, orient, shift; };
 
 // the r-th (0-based) legal action of player q in reference order; blk_count() must have filled L.pcnt
-__device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, uint32_t r, const int lane)
+// HAVE_INCL: `piece_incl` is the scan blk_count handed out (the rollout keeps it in a register); else it is redone here
+template <bool HAVE_INCL = false>
+__device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, uint32_t r, const int lane,
+                                              const uint32_t piece_incl = 0u)
 {
     // level 1: the piece (pcnt is indexed by piece id; pieces not held count 0)
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
-    const uint32_t incl = wave_scan_incl(mine, lane);
+    const uint32_t incl = HAVE_INCL ? piece_incl : wave_scan_incl(mine, lane);
     const unsigned long long hit = __ballot(r < incl);
     const int piece = __builtin_ctzll(hit);
     r -= (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), piece);
@@ -401,12 +411,8 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     const int lo = __builtin_ctz(rows_mask), hi = 31 - __builtin_clz(rows_mask);
     const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4, n_rows = y1 - y0 + 1;
     // fit masks of the 8 orientations of that piece for those origin rows (no other row is ever asked for: an anchor
-    // row minus a cell's row offset lies inside them or outside the board); the rows outside the board are 0 (the table
-    // shares its LDS with the count pass's shifted rows, so they are rewritten every time)
-    for (int i = lane; i < 8 * 12; i += 64) {
-        const int o = i / 12, k = i - o * 12;
-        L.u.sel.fit[o][k < 4 ? k : k + BN] = 0u;         // index 0..3 and 24..31
-    }
+    // row minus a cell's row offset lies inside them or outside the board, and a row outside the board is answered by a
+    // predicate at the read -- round 2 zeroed twelve padding rows per orientation in LDS on every select)
     auto fit_row = [&](const int o, const int y) {
         const ShapeRegs s = blk_load_shape(T, piece, o);
         uint32_t F = 0xffffffffu;
@@ -458,7 +464,8 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         const int ay = back ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
         rows_mask &= ~(1u << ay);
         uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
-        const uint32_t fr = pair ? frow[ay] >> shbase : 0u;      // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
+        // bit x: my (orientation, shift) pair is legal on anchor (x, ay); the origin row ay - dy must be on the board
+        const uint32_t fr = (pair && (unsigned)(ay + 4 - dy4) < (unsigned)BN) ? frow[ay] >> shbase : 0u;
         const uint32_t m = fr & cr;
         const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
         if (rr >= row_total) { rr -= row_total; continue; }
@@ -490,14 +497,15 @@ template <bool LEGAL = false>
 __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv,
                                           uint32_t (&inv)[4], int (&score)[4], const int lane)
 {
-    const ShapeRegs s = blk_load_shape(T, mv.piece, mv.orient);
-    int ox = 0, oy = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh(j) : ox; oy = (j == mv.shift) ? s.ro(j) : oy; }
-    if (lane < s.n) {
-        int cx = 0, cy = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { cx = (j == lane) ? s.sh(j) : cx; cy = (j == lane) ? s.ro(j) : cy; }
+    // the cell bytes straight out of the table: lane j its own cell, everybody the anchored one (round 2 picked both out
+    // of the packed shape registers with two chains of five selects)
+    const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[mv.piece]);
+    const uint8_t *cells = &T.cells[mv.piece * 8 + mv.orient][0];
+    const uint32_t oc = cells[mv.shift];
+    const int ox = (int)(oc & 15u), oy = (int)(oc >> 4);
+    if (lane < n) {
+        const uint32_t cc = cells[lane];
+        const int cx = (int)(cc & 15u), cy = (int)(cc >> 4);
         const int x = mv.x + cx - ox, y = mv.y + cy - oy;
         if (x >= 0 && x < BN && y >= 0 && y < BN) {
             if (LEGAL) {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
     for (int c = 0; c < 4; ++c) {
         if (c == q) {
             inv[c] &= ~(1u << mv.piece);
-            score[c] += s.n + ((inv[c] == 0) ? (mv.piece == 0 ? 20 : 15) : 0);
+            score[c] += n + ((inv[c] == 0) ? (mv.piece == 0 ? 20 : 15) : 0);
         }
     }
     wave_sync();
@@ -887,7 +895,8 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         uint32_t ip = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
-        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane);   // len(valid_actions) of the mover
+        uint32_t piece_incl = 0u;
+        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl);   // len(valid_actions) of the mover
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
         // one Philox call serves 4 plies (everything here is wave-uniform: the ten rounds run on the scalar unit, ~100
@@ -903,7 +912,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BlkMove mv = {0, 0, 0, 0, 0};
         if (total > 0) {
             const uint32_t r = __umulhi(word, total);
-            mv = blk_select(T, L, pl, ip, r, lane);
+            mv = blk_select<true>(T, L, pl, ip, r, lane, piece_incl);
             BLK_STAMP(3);
             // the mover keeps a move iff some OTHER piece of its inventory had one (new inventory, old board)
             any_move = total > (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[mv.piece]);
