@@ -71,6 +71,12 @@ struct BlkTables {
     uint8_t uniq[NPIECE][8];    // k-th distinct orientation: orient | multiplicity << 4.  Orientations that give the
                                 // same cell set (symmetric pieces) yield the same NUMBER of legal actions, so the
                                 // count pass fits each distinct shape once and multiplies.
+    // The 91 distinct oriented shapes as the count / existence passes want them (round 3): per cell the byte offset of its
+    // row 0 in the wave's pre-shifted table (WaveLds::u.sh[dx+4][dy+4], or the {all ones, 0} row WaveLds::pad9[4] for the
+    // slots behind the shape's cells) relative to the start of WaveLds, the multiplicity and the piece -- one 16-byte read
+    // per work item where round 2 went item -> uniq -> cells / ncell and then computed five addresses (~45 VALU per batch).
+    struct alignas(16) Distinct { uint16_t off[5]; uint8_t mult, piece; uint32_t unused; } distinct[92];
+    uint8_t first[24];          // index of a piece's first distinct shape in `distinct`
 };
 
 // orientation o of offset (dx,dy): ORIENTATIONS order of board.py:47, maps of computation.py:54-86
@@ -147,8 +153,29 @@ struct WaveLds {
     } u;
     uint2 pad9[28];          // {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh`
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
-    uint8_t items[NSHAPE];   // work list of a count / existence pass: piece << 3 | k  (k-th distinct orientation)
+    uint8_t items[NSHAPE];   // work list of a count / existence pass: indices into BlkTables::distinct
 };
+
+// the `distinct` / `first` part of the tables (needs the layout of WaveLds)
+void build_distinct(BlkTables &t)
+{
+    int d = 0;
+    for (int p = 0; p < NPIECE; ++p) {
+        t.first[p] = (uint8_t)d;
+        for (int k = 0; k < t.nuniq[p]; ++k, ++d) {
+            const int o = t.uniq[p][k] & 7;
+            BlkTables::Distinct &e = t.distinct[d];
+            for (int j = 0; j < 5; ++j) {
+                const int c = t.cells[p * 8 + o][j], sx = c & 15, ro = c >> 4;
+                const size_t off = j < t.ncell[p] ? offsetof(WaveLds, u) + (size_t)(sx * BLK_SH_ROWS + ro) * sizeof(uint2)
+                                                  : offsetof(WaveLds, pad9) + (size_t)ro * sizeof(uint2);
+                e.off[j] = (uint16_t)off;
+            }
+            e.mult = (uint8_t)(t.uniq[p][k] >> 4);
+            e.piece = (uint8_t)p;
+        }
+    }
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -258,15 +285,24 @@ __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const
 // (Tried in round 3: cell 0 of every shape is its origin, i.e. the same table row in all 64 lanes, so with wave-uniform
 //  rows it can come out of a register by v_readlane instead of out of the LDS -- four reads per row instead of five.
 //  7 % SLOWER: the pass is bound by instruction issue, not by the LDS, and a v_readlane with a scalar index stalls.)
+struct DistinctRegs { uint32_t o01, o23, o4mp; };    // BlkTables::Distinct as loaded: off[0..4], mult, piece
+
+__device__ __forceinline__ DistinctRegs blk_load_distinct(const BlkTables &T, const int d)
+{
+    const uint4 raw = *reinterpret_cast<const uint4 *>(&T.distinct[d]);
+    return DistinctRegs{raw.x, raw.y, raw.z};
+}
+
 template <bool ANY_ONLY>
-__device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const ShapeRegs &s, const bool active,
+__device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const DistinctRegs &e, const bool active,
                                                     const int y0, const int y1)
 {
-    // per cell: the table row of origin row 0 (cell j at column offset sh(j), row offset ro(j)); slots beyond the shape's
-    // cells read {all ones, 0}: no constraint on the fit, no anchor
-    const uint2 *cellrow[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) cellrow[j] = (j < s.n) ? &L.u.sh[s.sh(j)][s.ro(j)] : &L.pad9[s.ro(j)];
+    // per cell: the table row of origin row 0 (cell j at column offset dx + 4, row offset dy + 4); slots beyond the shape's
+    // cells read {all ones, 0}: no constraint on the fit, no anchor -- the five addresses come ready-made out of the table
+    const char *base = reinterpret_cast<const char *>(&L);
+    const uint2 *cellrow[5] = {reinterpret_cast<const uint2 *>(base + (e.o01 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o01 >> 16)),
+                               reinterpret_cast<const uint2 *>(base + (e.o23 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o23 >> 16)),
+                               reinterpret_cast<const uint2 *>(base + (e.o4mp & 0xffffu))};
     uint32_t cnt = 0;
     auto one_row = [&](const int y) {
         uint2 v[5];
@@ -323,8 +359,9 @@ __device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, c
     const int pos = (int)(incl - nu);
     // plain byte stores, one per distinct orientation (<= 8 trips): left to itself the compiler vectorises this into
     // 16-byte stores fed by a register-resident {0..7} table that it then SPILLS to scratch in the rollout kernel
+    const uint32_t d0 = lane < NPIECE ? T.first[lane] : 0u;
 #pragma clang loop vectorize(disable) unroll(disable)
-    for (uint32_t k = 0; k < nu; ++k) L.items[pos + (int)k] = (uint8_t)((lane << 3) | (int)k);
+    for (uint32_t k = 0; k < nu; ++k) L.items[pos + (int)k] = (uint8_t)(d0 + k);   // index into T.distinct
     wave_sync();
     return __builtin_amdgcn_readlane((int)incl, NPIECE - 1);
 }
@@ -341,10 +378,8 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
         const bool active = i < items;
-        const int it = active ? L.items[i] : 0;
-        const int piece = it >> 3;
-        const ShapeRegs s = blk_load_shape(T, piece, T.uniq[piece][it & 7] & 7);
-        const uint32_t c = blk_shape_count<true>(L, s, active, y0, y1);
+        const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
+        const uint32_t c = blk_shape_count<true>(L, e, active, y0, y1);
         if (__ballot(c > 0)) return true;
     }
     return false;
@@ -372,14 +407,11 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
         const int share = (n_rows + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up
         const int ya = y0 + part * share, yb = min(ya + share - 1, y1);
         const bool active = i < items;
-        const int it = active ? L.items[i] : 0;
-        const int piece = it >> 3;
-        const int om = T.uniq[piece][it & 7];
-        const ShapeRegs s = blk_load_shape(T, piece, om & 7);
-        // (a full batch keeps the wave-uniform row range: scalar loop control, rows read in pairs)
-        const uint32_t c = (split_log == 0 ? blk_shape_count<false>(L, s, active, y0, y1)
-                                           : blk_shape_count<false>(L, s, active, ya, yb)) * (uint32_t)(om >> 4);
-        if (c) atomicAdd(&L.pcnt[piece], c);
+        const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
+        // (a full batch keeps the wave-uniform row range: scalar loop control)
+        const uint32_t c = (split_log == 0 ? blk_shape_count<false>(L, e, active, y0, y1)
+                                           : blk_shape_count<false>(L, e, active, ya, yb)) * ((e.o4mp >> 16) & 0xffu);
+        if (c) atomicAdd(&L.pcnt[e.o4mp >> 24], c);
         base += 64 >> split_log;
     }
     wave_sync();
@@ -1234,6 +1266,7 @@ int crl_blokus_create(crl_ctx **out)
     CRL_REQUIRE(out != nullptr, "crl_blokus_create: out is NULL");
     BlkTables host;
     build_tables(host);
+    build_distinct(host);
     void *dev = nullptr;
     CRL_HIP(hipMalloc(&dev, sizeof(BlkTables)));
     hipError_t e = hipMemcpy(dev, &host, sizeof(BlkTables), hipMemcpyHostToDevice);
