@@ -326,7 +326,8 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
     } else {
         // BLK_COUNT_UNROLL rows per trip, one after the other through the same registers: the row offset is an immediate of
         // the LDS reads, so the five table pointers move once per trip instead of once per row (5 of a row's 17 VALU) and the
-        // loop control is shared
+        // loop control is shared.  (Two register sets with the next row's reads in flight behind the current row's
+        // counting -- a software pipeline -- were 7 % SLOWER: 64 VGPRs, and the eight waves of a SIMD hide the latency.)
         int y = y0;
 #pragma nounroll
         for (; y + BLK_COUNT_UNROLL - 1 <= y1; y += BLK_COUNT_UNROLL) {
