@@ -389,12 +389,12 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
 // legal-action count per piece of player q into L.pcnt[], returns the total (valid_actions length)
 // *piece_incl (lane p: the inclusive prefix of the per-piece counts up to piece p) is what level 1 of blk_select needs
 __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
-                                              uint32_t *piece_incl = nullptr)
+                                              uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr)
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
     if (lane < 32) L.pcnt[lane] = 0;
-    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; return 0; }
+    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
     const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
     blk_build_shifted(L, q, lane);
     // 64 lanes per batch of shapes.  A batch with at most 32 (16) shapes left gives each shape two (four) lanes, each with
@@ -419,6 +419,7 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
     const uint32_t total = wave_scan_incl(mine, lane);
     if (piece_incl) *piece_incl = total;
+    if (piece_cnt) *piece_cnt = mine;
     return (uint32_t)__builtin_amdgcn_readlane((int)total, 63);
 }
 
@@ -428,21 +429,29 @@ struct BlkMove { int piece, x, y, orient, shift; };
 // HAVE_INCL: `piece_incl` is the scan blk_count handed out (the rollout keeps it in a register); else it is redone here
 template <bool HAVE_INCL = false>
 __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, uint32_t r, const int lane,
-                                              const uint32_t piece_incl = 0u)
+                                              const uint32_t piece_incl = 0u, const uint32_t piece_cnt = 0u, const uint32_t piece_cells = 0u)
 {
-    // level 1: the piece (pcnt is indexed by piece id; pieces not held count 0)
-    const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
+    // level 1: the piece (pcnt is indexed by piece id; pieces not held count 0).  With HAVE_INCL everything comes out of
+    // registers -- the scan and the per-piece counts as blk_count left them, the cell counts as loaded once per launch --
+    // else out of LDS: each dependent LDS round trip of this serial pass is ~150 cycles of a ~6,000-cycle select.
+    const uint32_t mine = HAVE_INCL ? piece_cnt : (lane < 32 ? L.pcnt[lane] : 0u);
     const uint32_t incl = HAVE_INCL ? piece_incl : wave_scan_incl(mine, lane);
     const unsigned long long hit = __ballot(r < incl);
     const int piece = __builtin_ctzll(hit);
     r -= (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine), piece);
-    const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
+    const int n = HAVE_INCL ? __builtin_amdgcn_readlane((int)piece_cells, piece) : __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
     // the anchors: my row's (lanes 0..19), the rows that have any (a scalar mask), and the origin rows a shape touching
     // one can have (as blk_row_range)
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
     uint32_t rows_mask = (uint32_t)__ballot(crow != 0u);
     const int lo = __builtin_ctz(rows_mask), hi = 31 - __builtin_clz(rows_mask);
     const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4, n_rows = y1 - y0 + 1;
+    // lane / n without a division: n is 1..5 and lane < 64 (floor(2^32 / n) + 1 is exact there).  My (orientation, shift)
+    // pair's cell byte is fetched here, ahead of the fit table: its LDS round trip runs behind the build
+    const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
+    const bool pair = lane < 8 * n;
+    const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
+    const uint32_t cb = T.cells[piece * 8 + po][pj];
     // fit masks of the 8 orientations of that piece for those origin rows (no other row is ever asked for: an anchor
     // row minus a cell's row offset lies inside them or outside the board, and a row outside the board is answered by a
     // predicate at the read -- round 2 zeroed twelve padding rows per orientation in LDS on every select)
@@ -475,11 +484,6 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     // unit too -- rows with anchors from `rows_mask`, a row's anchors from its bits (v_readlane of the row lane's mask),
     // lowest set bit first: no anchor list in LDS, and the fit row is read once per ROW, not per anchor (round 2 listed
     // the anchors in LDS and paid a dependent LDS round trip per anchor).
-    // lane / n without a division: n is 1..5 and lane < 64 (floor(2^32 / n) + 1 is exact there)
-    const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
-    const bool pair = lane < 8 * n;
-    const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
-    const uint32_t cb = T.cells[piece * 8 + po][pj];
     const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
     const uint32_t *frow = &L.u.sel.fit[po][8 - dy4];            // frow[ay] = fit[po][ay - dy + 4]
     const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
@@ -917,6 +921,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     // the condition is permanent (round 0 is excluded: its single-corner anchor rule is not).  Purely a cache of
     // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
     uint32_t dead = 0;
+    const uint32_t piece_cells = lane < 24 ? T.ncell[lane] : 0u;   // lane p: cells of piece p, for the whole launch
     philox_out rnd = {{0u, 0u, 0u, 0u}};
 #ifdef BLK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
@@ -928,8 +933,8 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         uint32_t ip = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
-        uint32_t piece_incl = 0u;
-        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl);   // len(valid_actions) of the mover
+        uint32_t piece_incl = 0u, piece_cnt = 0u;
+        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt);   // len(valid_actions) of the mover
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
         // one Philox call serves 4 plies (everything here is wave-uniform: the ten rounds run on the scalar unit, ~100
@@ -945,10 +950,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BlkMove mv = {0, 0, 0, 0, 0};
         if (total > 0) {
             const uint32_t r = __umulhi(word, total);
-            mv = blk_select<true>(T, L, pl, ip, r, lane, piece_incl);
+            mv = blk_select<true>(T, L, pl, ip, r, lane, piece_incl, piece_cnt, piece_cells);
             BLK_STAMP(3);
             // the mover keeps a move iff some OTHER piece of its inventory had one (new inventory, old board)
-            any_move = total > (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[mv.piece]);
+            any_move = total > (uint32_t)__builtin_amdgcn_readlane((int)piece_cnt, mv.piece);
         }
         // Does anybody else have a move?  The reference asks that of the PRE-move board (:424), so it is asked here before
         // the move is placed -- which lets the other players' rows be derived only now, when they are needed (late game).
