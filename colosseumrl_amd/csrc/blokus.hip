@@ -444,49 +444,40 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     // one can have (as blk_row_range)
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
     uint32_t rows_mask = (uint32_t)__ballot(crow != 0u);
-    const int lo = __builtin_ctz(rows_mask), hi = 31 - __builtin_clz(rows_mask);
-    const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4, n_rows = y1 - y0 + 1;
-    // lane / n without a division: n is 1..5 and lane < 64 (floor(2^32 / n) + 1 is exact there).  My (orientation, shift)
-    // pair's cell byte is fetched here, ahead of the fit table: its LDS round trip runs behind the build
+    // level 2: the anchors in row-major order, one lane per (orientation, shift) pair: lane o*n + j asks whether the piece
+    // fits with its cell j on the anchor.  The ballot of those answers is the anchor's legal set in reference order, its
+    // popcount the anchor's action count; both stay in scalar registers.  The anchors themselves are walked on the scalar
+    // unit too -- rows with anchors from `rows_mask`, a row's anchors from its bits (v_readlane of the row lane's mask),
+    // lowest set bit first: no anchor list in LDS (round 2 listed the anchors in LDS and paid a dependent LDS round trip
+    // per anchor).
+    // lane / n without a division: n is 1..5 and lane < 64 (floor(2^32 / n) + 1 is exact there)
     const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
     const bool pair = lane < 8 * n;
     const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
-    const uint32_t cb = T.cells[piece * 8 + po][pj];
-    // fit masks of the 8 orientations of that piece for those origin rows (no other row is ever asked for: an anchor
-    // row minus a cell's row offset lies inside them or outside the board, and a row outside the board is answered by a
-    // predicate at the read -- round 2 zeroed twelve padding rows per orientation in LDS on every select)
-    auto fit_row = [&](const int o, const int y) {
-        const ShapeRegs s = blk_load_shape(T, piece, o);
-        uint32_t F = 0xffffffffu;
+    // NO fit table (round 2 / early round 3 built the fit masks of all 8 orientations x up to 20 origin rows in LDS on
+    // every select: 41 % of the select's time, for a walk that visits two or three rows).  The pair lane fits its own
+    // orientation with its own cell on the anchors of a row when the walk gets there: cell k of the shape then lies
+    // (dy_k - dy_j) rows and (dx_k - dx_j) columns from the anchor, so
+    //     legal anchors of row ay = AND_k  allowed[ay + dy_k - dy_j] >> (dx_k - dx_j)
+    // -- five reads of the padded `ac` rows (rows outside the board are 0; the masks are stored << 8, which keeps every
+    // shift a right shift), five shifts, two three-way ANDs per visited row, no table, no wave barrier.  Slots behind the
+    // shape's cells repeat cell 0 (the same test twice).
+    const uint2 cw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + po][0]);
+    int rowoff[5];                                               // byte offset of cell k's row relative to ac[q][ay + 4]
+    uint32_t colsh[5];                                           // right shift that brings cell k's column onto the anchor's
+    {
+        const uint32_t c[5] = {cw.x & 0xffu, (cw.x >> 8) & 0xffu, (cw.x >> 16) & 0xffu, cw.x >> 24, cw.y & 0xffu};
+        uint32_t mineb = c[0];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
-        L.u.sel.fit[o][y + 4] = F;                       // bit x+4
-    };
-    // (consecutive lanes take consecutive rows of one orientation: distinct LDS banks; the row count is rounded up to a
-    //  power of two so that the split needs no division -- one or two trips of 64 lanes instead of three)
-    if (n_rows <= 16) {
-        const int sh = n_rows <= 8 ? 3 : 4;
-        for (int i = lane; i < (8 << sh); i += 64) {
-            const int yy = i & ((1 << sh) - 1);
-            if (yy < n_rows) fit_row(i >> sh, y0 + yy);
-        }
-    } else {
-        for (int i = lane; i < 8 * BN; i += 64) {
-            const int o = i / BN;
-            fit_row(o, i - o * BN);
+        for (int k = 1; k < 5; ++k) mineb = (pj == k) ? c[k] : mineb;
+        const int dxj = (int)(mineb & 15u), dyj = (int)(mineb >> 4);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            rowoff[k] = ((int)(c[k] >> 4) - dyj) * (int)sizeof(uint2);
+            colsh[k] = (uint32_t)(8 + (int)(c[k] & 15u) - dxj);
         }
     }
-    wave_sync();
-    // level 2: the anchors in row-major order, one lane per (orientation, shift) pair: lane o*n + j asks whether the piece
-    // fits with its cell j on the anchor (origin = anchor - s_j: one bit of the fit table; origin row and column are
-    // always inside the padded table).  The ballot of those answers is the anchor's legal set in reference order, its
-    // popcount the anchor's action count; both stay in scalar registers.  The anchors themselves are walked on the scalar
-    // unit too -- rows with anchors from `rows_mask`, a row's anchors from its bits (v_readlane of the row lane's mask),
-    // lowest set bit first: no anchor list in LDS, and the fit row is read once per ROW, not per anchor (round 2 listed
-    // the anchors in LDS and paid a dependent LDS round trip per anchor).
-    const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
-    const uint32_t *frow = &L.u.sel.fit[po][8 - dy4];            // frow[ay] = fit[po][ay - dy + 4]
-    const int shbase = 8 - dx4;                                  // (ax + shbase) = ax - dx + 4
+    const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]);
     BlkMove mv = {piece, 0, 0, 0, 0};
     // The walk starts from whichever end of the anchor order is nearer in rank: the piece's total is known (pcnt), so an
     // action in the upper half of the piece's range is counted down from the last anchor -- a quarter of the anchors per
@@ -501,8 +492,11 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         const int ay = back ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
         rows_mask &= ~(1u << ay);
         uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
-        // bit x: my (orientation, shift) pair is legal on anchor (x, ay); the origin row ay - dy must be on the board
-        const uint32_t fr = (pair && (unsigned)(ay + 4 - dy4) < (unsigned)BN) ? frow[ay] >> shbase : 0u;
+        // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
+        uint32_t fr = pair ? 0xffffffffu : 0u;
+        const char *rowp = acq + ay * (int)sizeof(uint2);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
         const uint32_t m = fr & cr;
         const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
         if (rr >= row_total) { rr -= row_total; continue; }
