@@ -914,7 +914,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     // a round >= 1 it can only pass, so its own cells and inventory stay fixed while `allowed` only shrinks:
     // the condition is permanent (round 0 is excluded: its single-corner anchor rule is not).  Purely a cache of
     // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
-    uint32_t dead = 0;
+    uint32_t dead = 0, can_move = 0;
     const uint32_t piece_cells = lane < 24 ? T.ncell[lane] : 0u;   // lane p: cells of piece p, for the whole launch
     philox_out rnd = {{0u, 0u, 0u, 0u}};
 #ifdef BLK_STAMPS
@@ -951,6 +951,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         }
         // Does anybody else have a move?  The reference asks that of the PRE-move board (:424), so it is asked here before
         // the move is placed -- which lets the other players' rows be derived only now, when they are needed (late game).
+        // `can_move` remembers who was found to have one on the board as it stands: while movers pass, the board and the
+        // others' inventories stay what they were, so the answer does too (late in a game two or three players pass in a
+        // row, and every one of those plies asked the same question of the same board).
+        if (!any_move && (can_move & ~(1u << pl))) any_move = true;
         for (int q = 0; q < 4 && !any_move; ++q) {
             if (q == pl || ((dead >> q) & 1u)) continue;
             blk_prep(L, lane, round, q);
@@ -958,19 +962,22 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
 #pragma unroll
             for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
             any_move = blk_exists(T, L, q, iq, lane);
+            if (any_move) can_move |= 1u << q;
             if (!any_move && round >= 1) dead |= 1u << q;
         }
         BLK_STAMP(5);
         if (total > 0) {
             blk_apply<true>(T, L, pl, mv, inv, score, lane);
+            can_move = 0;                                       // the board changed
             BLK_STAMP(4);
         }
+        if (pl == 3) can_move = 0;                              // ... and so does the round (round 0 has its own anchor rule)
         const BlkOutcome out = blk_outcome(any_move, pl, score);
         round += (pl == 3) ? 1 : 0;
         pl = (pl + 1) & 3;
         ts += 1;
         if (out.terminal) {
-            dead = 0;
+            dead = 0; can_move = 0;
             if (lane == 0) {        // episode statistics go straight to memory (this wave owns game b): nothing to carry
                 st.n_episodes[b] += 1;
                 st.len_sum[b] += ts;
