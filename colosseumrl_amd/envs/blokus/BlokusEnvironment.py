@@ -38,6 +38,7 @@ class BlokusEnvironment(BaseEnvironment):
         self._device = device
         self._stepper = None
         self._seen = None      # (state key, mover, ordered legal ids, observation) of the state the last next_state returned
+        self._staged = None    # key of the state the staging block holds
 
     @property
     def min_players(self) -> int:
@@ -79,11 +80,18 @@ class BlokusEnvironment(BaseEnvironment):
         return (np.asarray(board.board_contents).tobytes(), int(round_count),
                 tuple((int(ai.player_score), tuple(ai.current_pieces)) for ai in players))
 
-    def _load(self, state, mover: int):
+    def _load(self, state, mover: int, key=None):
+        """The stepper with `state` and `mover` staged.  A state that is already in the staging block -- what the last
+        ``next_state`` produced -- is not written (and its row bitboards not rebuilt) again; compared by value."""
         board, round_count, players = state
         st = self._single()
-        inv = [sum(1 << PIECE_NAME_TO_INDEX[p] for p in ai.current_pieces) for ai in players]
-        st.load(board.board_contents, inv, [ai.player_score for ai in players], int(round_count), int(mover))
+        key = self._key(state) if key is None else key
+        if key != self._staged:
+            inv = [sum(1 << PIECE_NAME_TO_INDEX[p] for p in ai.current_pieces) for ai in players]
+            st.load(board.board_contents, inv, [ai.player_score for ai in players], int(round_count), int(mover))
+            self._staged = key
+        else:
+            st.v["to_move"][0] = int(mover)
         return st
 
     def _unload(self, st):
@@ -104,10 +112,10 @@ class BlokusEnvironment(BaseEnvironment):
         """Dense ids of every legal action of `player`, ascending (= reference order): the compacted list the GPU
         writes (``crl_blokus_valid_list``); for the state and mover the last ``next_state`` returned it is already
         there."""
-        seen = self._seen
-        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+        seen, key = self._seen, self._key(state)
+        if seen is not None and seen[1] == player and seen[0] == key:
             return seen[2]
-        return self._load(state, player).legal_ids(player)
+        return self._load(state, player, key).legal_ids(player)
 
     # ---- dynamics ---------------------------------------------------------------------------
     def new_state(self, num_players: int = 4) -> State:
@@ -152,13 +160,14 @@ class BlokusEnvironment(BaseEnvironment):
         st.step(action_id)
         v = st.v
         new_state = self._unload(st)
+        self._staged = self._key(new_state)
         mover = int(v["to_move"][0])
         term = bool(v["terminal"][0])
         wmask = int(v["winners"][0])
         win = [p for p in range(4) if (wmask >> p) & 1] if term else None
         obs = {"board": v["obs_board"].astype(np.int64).reshape(20, 20), "pieces": v["obs_pieces"].copy().reshape(4, 21),
                "score": v["obs_score"].astype(np.int64), "player": np.array([mover])}
-        self._seen = (self._key(new_state), mover, st.ids(), obs)
+        self._seen = (self._staged, mover, st.ids(), obs)
         return new_state, [mover], [int(v["reward"][0])], term, win
 
     def valid_actions(self, state: object, player: int) -> List[str]:
@@ -215,21 +224,21 @@ class BlokusEnvironment(BaseEnvironment):
         if not (0 <= index[0] < 20 and 0 <= index[1] < 20 and 0 <= shift < 5):
             return False
         wanted = A.encode(piece, index[0], index[1], o, shift)
-        seen = self._seen
-        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+        seen, key = self._seen, self._key(state)
+        if seen is not None and seen[1] == player and seen[0] == key:
             ids = seen[2]
             k = int(np.searchsorted(ids, wanted))
             return bool(k < len(ids) and ids[k] == wanted)
-        return self._load(state, player).is_valid(player, wanted)
+        return self._load(state, player, key).is_valid(player, wanted)
 
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
         """Relative player ids (-1 empty), board rotated into the observer's viewpoint, inventories as a
         (4, 21) uint8 matrix in relative player order, scores rolled (reference :721-768); evaluated by
         ``crl_blokus_observe`` (already done by the fused step for the state and mover ``next_state`` returned)."""
-        seen = self._seen
-        if seen is not None and seen[1] == player and seen[0] == self._key(state):
+        seen, key = self._seen, self._key(state)
+        if seen is not None and seen[1] == player and seen[0] == key:
             return {k: a.copy() for k, a in seen[3].items()}
-        st = self._load(state, player)
+        st = self._load(state, player, key)
         st.observe(player)
         v = st.v
         return {"board": v["obs_board"].astype(np.int64).reshape(20, 20), "pieces": v["obs_pieces"].copy().reshape(4, 21),

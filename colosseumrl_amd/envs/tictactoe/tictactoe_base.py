@@ -44,6 +44,7 @@ class TicTacToeEnvBase(BaseEnvironment):
         self._device = device
         self._stepper = None
         self._seen = None      # (state key, empties mask, mover, observation) of the state the last next_state returned
+        self._staged = None    # key of the state the staging block holds
         self._n_cells = int(np.prod(self.SHAPE))
         self._cell_strings = [action_to_string(np.unravel_index(c, self.SHAPE)) for c in range(self._n_cells)]
 
@@ -79,15 +80,25 @@ class TicTacToeEnvBase(BaseEnvironment):
         except AttributeError:
             return None
 
+    def _stage(self, state, mover: int):
+        """The stepper with `state` (and `mover`) in its staging block; a state that is already there -- what the last
+        ``next_state`` produced -- is not written again (compared by value)."""
+        st = self._single()
+        key = self._key(state)
+        if key is None or key != self._staged:
+            st.load(state[0], state[1], mover)
+            self._staged = key
+        else:
+            st.v["to_move"][0] = mover
+        return st
+
     def _valid_mask(self, state) -> int:
         """Empties bit mask of ``state`` (computed on the GPU; for the state the last ``next_state`` returned the fused
         launch has already produced it)."""
         seen = self._seen
         if seen is not None and seen[0] == self._key(state):
             return seen[1]
-        st = self._single()
-        st.load(state[0], state[1], 0)
-        return st.valid()
+        return self._stage(state, 0).valid()
 
     def _cell_of(self, index) -> int:
         """Flat cell of an index tuple with Python indexing rules (negative wraps, out of range raises)."""
@@ -134,14 +145,14 @@ class TicTacToeEnvBase(BaseEnvironment):
         cell = -1
         if len(action) > 0:
             cell = self._cell_of(string_to_action(action))     # same exceptions as the reference's board[index]
-        st = self._single()
-        st.load(state[0], state[1], player_num)
+        st = self._stage(state, player_num)
         st.step(cell)
         v = st.v
         board = v["board"].copy().reshape(self.SHAPE)
         w, ws, mover = int(v["winner"][0]), int(v["winners"][0]), int(v["to_move"][0])
         new_state = (board, None if w < 0 else w)
-        self._seen = (self._key(new_state), int(v["valid"][0]), mover, v["obs_board"].copy())
+        self._staged = self._key(new_state)
+        self._seen = (self._staged, int(v["valid"][0]), mover, v["obs_board"].copy())
         return (new_state, [mover], [int(v["reward"][0])], bool(v["terminal"][0]), None if ws < 0 else [ws])
 
     def valid_actions(self, state: object, player: int) -> List[str]:
@@ -162,7 +173,6 @@ class TicTacToeEnvBase(BaseEnvironment):
         seen = self._seen
         if seen is not None and seen[2] == player and seen[0] == self._key(state):
             return {"board": seen[3].copy().reshape(self.SHAPE)}
-        st = self._single()
-        st.load(state[0], state[1], 0)
+        st = self._stage(state, 0)
         st.observe(player)
         return {"board": st.v["obs_board"].copy().reshape(self.SHAPE)}

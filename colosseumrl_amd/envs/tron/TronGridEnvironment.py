@@ -70,6 +70,7 @@ class TronGridEnvironment(BaseEnvironment):
         self._stepper = None
         self._start_boards = {}                      # spawn layout -> start board (new_state)
         self._observed = None                        # (state key, observations of all players) of the last next_state
+        self._staged = None                          # key of the state the staging block holds
 
     def __repr__(self):
         return ("Tron Finite Grid Environment\n" + "=" * 50 + "\n"
@@ -107,6 +108,16 @@ class TronGridEnvironment(BaseEnvironment):
             # (the context's spawn layout only matters to auto-reset, which the single-state calls never ask for)
             self._stepper = SingleTron(self.N, self.num_players, list(range(self.num_players)), [0] * self.num_players)
         return self._stepper
+
+    def _stage(self, state):
+        """The stepper with `state` in its staging block.  A state that is already there -- the one the last
+        ``next_state`` produced, the usual case in a game loop -- is not written again (compared by value)."""
+        st = self._single()
+        key = self._key(state)
+        if key is None or key != self._staged:
+            st.load(*state)
+            self._staged = key
+        return st
 
     @staticmethod
     def _key(state):
@@ -153,13 +164,12 @@ class TronGridEnvironment(BaseEnvironment):
         without another GPU call), no copies, one synchronise."""
         for player, action in zip(players, actions):
             self._moves[player] = self.STRING_TO_ACTION[action]      # KeyError on an unknown string, like the reference
-        st = self._single()
-        st.load(*state)
+        st = self._stage(state)
         st.step_observe(self._moves)
         new_state = st.state64()
         v = st.v
-        P, NN = self.num_players, self.N * self.N
-        self._observed = (self._key(new_state), v["obs_board"].copy(), v["obs_heads"].copy(), v["obs_dirs"].copy(),
+        self._staged = self._key(new_state)           # the staging block now holds the new state
+        self._observed = (self._staged, v["obs_board"].copy(), v["obs_heads"].copy(), v["obs_dirs"].copy(),
                           v["obs_deaths"].copy())
         new_players = np.where(new_state[3] == 0)[0]
         rewards = v["rewards"].astype(np.int64)
@@ -186,8 +196,7 @@ class TronGridEnvironment(BaseEnvironment):
             directions = seen[3][pl * P:(pl + 1) * P].astype(np.int64)
             deaths = seen[4][pl * P:(pl + 1) * P].astype(np.int64)
         else:
-            st = self._single()
-            st.load(*state)
+            st = self._stage(state)
             st.observe(player)
             v = st.v
             board = v["obs_board"][:NN].astype(np.int64).reshape(N, N)
@@ -228,8 +237,7 @@ class TronGridEnvironment(BaseEnvironment):
     def compute_ranking(self, state: object, players: List[int], winners: List[int]) -> Dict[int, int]:
         """Competition ranking by trail length with the mutual-kill tie rule (reference :483-508), on the GPU
         (``crl_tron_ranking``).  Keys are numpy integers ordered by rank like the reference's ``most_common()`` walk."""
-        st = self._single()
-        st.load(*state)
+        st = self._stage(state)
         ranks = st.ranking().copy()
         order = sorted(range(len(ranks)), key=lambda p: (int(ranks[p]), p))
         return {np.int64(p): int(ranks[p]) for p in order}
