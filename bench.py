@@ -536,14 +536,14 @@ def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p",
     from colosseumrl_amd.config import get_environment
     rng = random.Random(0)
     out = {}
-    for name in names:
+    def one_pass(name):
         env = get_environment(name)() if name != "tron" else get_environment(name)("20;4")
-        n_next, n_other = (300, 300) if name == "blokus" else (3000, 1000)
+        n_next, n_other = (300, 300) if name == "blokus" else (2000, 1000)
         state, players = env.new_state()
         for _ in range(3):                                  # lazy set-up (context, staging, code objects) outside the timing
             va = env.valid_actions(state, players[0])
             env.state_to_observation(state, players[0])
-            acts = [rng.choice(va) for _ in players] if name != "tron" else [rng.choice(va) for _ in players]
+            acts = [rng.choice(va) for _ in players]
             state, players, _, term, _ = env.next_state(state, players, acts)
             if term:
                 state, players = env.new_state()
@@ -570,12 +570,20 @@ def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p",
                 state, players = env.new_state()
                 t["new_state"] += time.perf_counter() - t0
                 k["new_state"] += 1
-        rec = {m: round(t[m] / max(k[m], 1) * 1e6, 1) for m in t}
+        return {m: t[m] / max(k[m], 1) * 1e6 for m in t}, k["next_state"]
+
+    for name in names:
+        # two passes, the lower figure per method: whole passes of these ~20-us calls come out at twice the time now and
+        # then (seen for whichever env runs first after a different one; per-stream latencies are uniform,
+        # tools/debug/stream_latency.py), and a latency is what the call CAN do
+        (a, calls), (b, _) = one_pass(name), one_pass(name)
+        rec = {m: round(min(a[m], b[m]), 1) for m in a}
         rec["reference_us"] = REFERENCE_DROPIN_US.get(name)
-        rec["calls"] = k["next_state"]
+        rec["calls"] = calls
         out[name] = rec
-    out["what"] = ("us per call of the BaseEnvironment single-state API on one state (B = 1), random play; reference_us = the "
-                   "reference's own Python path, one core, build container (it cannot travel to the GPU box)")
+    out["what"] = ("us per call of the BaseEnvironment single-state API on one state (B = 1), random play, mean over a pass, the lower "
+                   "of two passes; reference_us = the reference's own Python path, one core, build container (it cannot "
+                   "travel to the GPU box)")
     return out
 
 
