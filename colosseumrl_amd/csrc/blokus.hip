@@ -933,12 +933,19 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BLK_STAMP(2);
         // one Philox call serves 4 plies (everything here is wave-uniform: the ten rounds run on the scalar unit, ~100
         // instructions -- worth keeping the four words across plies)
+        // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lane k (k < 4)
+        // computes block (tc >> 4) * 4 + k, a ply takes its word out of lane (tc >> 2) & 3 with a v_readlane.  (Round 2 ran
+        // the ten rounds on the scalar unit, everything being wave-uniform: ~110 scalar instructions every fourth ply.
+        // But this kernel is bound by the SCALAR unit -- it issues one instruction per ~4.2 cycles per SIMD whatever the
+        // occupancy, half the rate of the vector unit (tools/ubench/valu_rate.hip, mix "salu"), and a ply has 408 scalar
+        // against 529 vector instructions -- so uniform work is cheaper on the vector side.)
+        if ((tc & 15u) == 0u || t == 0) rnd = philox4x32_10(g, ((tc >> 4) << 2) + (uint32_t)(lane & 3), 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
         const uint32_t sel = tc & 3u;
-        if (sel == 0u || t == 0) rnd = philox4x32_10(g, tc >> 2, 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
-        uint32_t word = rnd.w[0];
-        word = (sel == 1) ? rnd.w[1] : word;
-        word = (sel == 2) ? rnd.w[2] : word;
-        word = (sel == 3) ? rnd.w[3] : word;
+        uint32_t wsel = rnd.w[0];
+        wsel = (sel == 1) ? rnd.w[1] : wsel;
+        wsel = (sel == 2) ? rnd.w[2] : wsel;
+        wsel = (sel == 3) ? rnd.w[3] : wsel;
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)wsel, (int)((tc >> 2) & 3u));
         tc += 1;
         bool any_move = false;
         BlkMove mv = {0, 0, 0, 0, 0};

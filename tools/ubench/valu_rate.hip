@@ -119,6 +119,45 @@ __global__ void __launch_bounds__(256) tron_mix_kernel(uint32_t *out, uint64_t *
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// Scalar issue rate (round 3: the Blokus rollout issues 408 SALU next to 529 VALU instructions per wave-step -- is the
+// scalar unit a bound?).  `with_valu` = 0: 64 independent s_add_u32 / s_xor_b32 per iteration on 8 chains;
+// 1: the same 64 SALU interleaved one to one with 64 independent VALU instructions (do the two pipes issue side by side?).
+__global__ void __launch_bounds__(256) salu_kernel(uint32_t *out, uint64_t *clk, int iters, int with_valu)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    const uint32_t c = blockIdx.x | 1u;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, s4 = s0 + 4, s5 = s0 + 5, s6 = s0 + 6, s7 = s0 + 7;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (with_valu) {
+        for (int i = 0; i < iters; ++i) {
+            asm volatile(
+                ".rept 8\n"
+                "s_add_u32 %4, %4, %12\n v_add_u32 %0, %0, %13\n s_xor_b32 %5, %5, %12\n v_xor_b32 %1, %1, %13\n"
+                "s_add_u32 %6, %6, %12\n v_add_u32 %2, %2, %13\n s_xor_b32 %7, %7, %12\n v_xor_b32 %3, %3, %13\n"
+                "s_add_u32 %8, %8, %12\n v_xor_b32 %0, %0, %13\n s_xor_b32 %9, %9, %12\n v_add_u32 %1, %1, %13\n"
+                "s_add_u32 %10, %10, %12\n v_xor_b32 %2, %2, %13\n s_xor_b32 %11, %11, %12\n v_add_u32 %3, %3, %13\n"
+                ".endr\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7)
+                : "s"(c), "v"(c) : "scc");
+        }
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            asm volatile(
+                ".rept 8\n"
+                "s_add_u32 %0, %0, %8\n s_xor_b32 %1, %1, %8\n s_add_u32 %2, %2, %8\n s_xor_b32 %3, %3, %8\n"
+                "s_add_u32 %4, %4, %8\n s_xor_b32 %5, %5, %8\n s_add_u32 %6, %6, %8\n s_xor_b32 %7, %7, %8\n"
+                ".endr\n"
+                : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "s"(c) : "scc");
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;
+}
+
 int main()
 {
     uint32_t *out;
@@ -131,8 +170,8 @@ int main()
     const int iters = 40000;
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"note\": \"wave64 instructions per second, whole chip; "
            "cycles = shader cycles per instruction per SIMD at the in-kernel clock\", \"mixes\": {", prop.gcnArchName, cus, cus * 4);
-    for (int mix = 0; mix < 5; ++mix) {
-        static const char *const names[5] = {"valu", "tron", "valu_half_exec", "mul_lo_hi_pairs", "mad_u64_u32"};
+    for (int mix = 0; mix < 7; ++mix) {
+        static const char *const names[7] = {"valu", "tron", "valu_half_exec", "mul_lo_hi_pairs", "mad_u64_u32", "salu", "salu_valu_1to1"};
         printf("%s\"%s\": [", mix ? ", " : "", names[mix]);
         for (int wps = 1; wps <= 8; wps *= 2) {
             const int blocks = cus * wps;                          // wps blocks of 4 waves per CU = wps waves per SIMD
@@ -140,7 +179,8 @@ int main()
             CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; ++rep) {                    // rep 0 warms up (clock ramp), rep 1 is timed
                 CHECK(hipEventRecord(e0));
-                if (mix >= 3) hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 4, mix == 4);
+                if (mix >= 5) hipLaunchKernelGGL(salu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 6);
+                else if (mix >= 3) hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 4, mix == 4);
                 else if (mix != 1) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 2);
                 else hipLaunchKernelGGL(tron_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
                 CHECK(hipEventRecord(e1));
@@ -152,15 +192,17 @@ int main()
             CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
             const double ghz = (double)h[0] / (double)h[1] * 0.1;
             // (mul mixes: iters / 4 iterations of 64 multiplies, or of 32 v_mad_u64_u32 = the same 32 full products)
-            const double valu_per_wave = mix >= 3 ? (double)(iters / 4) * (mix == 4 ? 32 : 64)
+            // (salu mixes: 64 SALU per iteration, plus 64 VALU in the 1:1 mix; "valu" columns then count the VALU part only)
+            const double valu_per_wave = mix == 5 ? 0.0 : mix == 6 ? (double)iters * 64 : mix >= 3 ? (double)(iters / 4) * (mix == 4 ? 32 : 64)
                                                   : (double)iters * (mix == 1 ? kBlocksPerIter * 11 : kValuPerIter);
-            const double all_per_wave = mix >= 3 ? valu_per_wave : (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
+            const double all_per_wave = mix == 5 ? (double)iters * 64 : mix == 6 ? (double)iters * 128 : mix >= 3 ? valu_per_wave
+                                                  : (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
             const double waves = (double)blocks * 4;
             const double s = ms * 1e-3;
             printf("%s{\"waves_per_simd\": %d, \"ms\": %.3f, \"clock_ghz\": %.3f, \"valu_wave_insts_per_s\": %.4e, "
                    "\"all_wave_insts_per_s\": %.4e, \"cycles_per_valu_per_simd\": %.3f, \"cycles_per_inst_per_simd\": %.3f}",
                    wps > 1 ? ", " : "", wps, ms, ghz, valu_per_wave * waves / s, all_per_wave * waves / s,
-                   s * ghz * 1e9 / (valu_per_wave * wps), s * ghz * 1e9 / (all_per_wave * wps));
+                   valu_per_wave > 0 ? s * ghz * 1e9 / (valu_per_wave * wps) : 0.0, s * ghz * 1e9 / (all_per_wave * wps));
         }
         printf("]");
     }
