@@ -20,6 +20,7 @@
 // that piece, one lane per anchor, wave prefix scan -> the r-th (orientation, shift) bit of that anchor).
 // The 168 oriented shapes (21 pieces x 8 orientations, 5 packed cell bytes each) sit in LDS.
 #include "crl_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -487,38 +488,48 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     uint32_t rr = back ? ptotal - 1u - r : r;
     // A row at a time: every pair lane counts its legal anchors of the row (one AND, one popcount), a wave sum gives the
     // row's action count, and rows before the rank's are skipped whole; only inside the rank's row are the anchors looked
-    // at one by one (a ballot, a popcount and a compare each on the scalar unit).
-    while (rows_mask) {
-        const int ay = back ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
-        rows_mask &= ~(1u << ay);
-        uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
-        // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
-        uint32_t fr = pair ? 0xffffffffu : 0u;
-        const char *rowp = acq + ay * (int)sizeof(uint2);
+    // at one by one (a ballot, a popcount and a compare each on the scalar unit).  The two walking directions are two
+    // instances of the loop (BACK a compile-time constant): selecting ctz / clz per row and per anchor cost a handful of
+    // scalar instructions each time, and the scalar unit is what bounds this kernel.
+    auto walk = [&](auto back_tag) -> BlkMove {
+        constexpr bool BACK = decltype(back_tag)::value;
+        while (rows_mask) {
+            const int ay = BACK ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
+            rows_mask &= ~(1u << ay);
+            uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
+            // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
+            uint32_t fr = pair ? 0xffffffffu : 0u;
+            const char *rowp = acq + ay * (int)sizeof(uint2);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
-        const uint32_t m = fr & cr;
-        const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
-        if (rr >= row_total) { rr -= row_total; continue; }
-        for (;;) {                                               // rr < row_total: the anchor is in this row
-            const int ax = back ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
-            const uint32_t bit = 1u << ax;
-            cr &= ~bit;
-            const unsigned long long legal = __ballot((m & bit) != 0u);
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
-            if (rr < cnt) {                                      // level 3: the chosen legal pair at this anchor
-                const int lane_sel = nth_set_bit64(legal, (int)(back ? cnt - 1u - rr : rr));
-                mv.x = ax;
-                mv.y = ay;
-                mv.orient = n == 1 ? lane_sel : (int)__umulhi((uint32_t)lane_sel, inv_n);
-                mv.shift = lane_sel - mv.orient * n;
-                return mv;
+            for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
+            const uint32_t m = fr & cr;
+            const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
+            if (rr >= row_total) { rr -= row_total; continue; }
+            for (;;) {                                           // rr < row_total: the anchor is in this row
+                const int ax = BACK ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
+                const uint32_t bit = 1u << ax;
+                cr &= ~bit;
+                const bool mine_legal = (m & bit) != 0u;
+                const unsigned long long legal = __ballot(mine_legal);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
+                if (rr < cnt) {                                  // level 3: the chosen legal pair at this anchor
+                    // its lane: the legal lane with exactly `want` legal lanes below it (v_mbcnt: no scalar bit search)
+                    const uint32_t want = BACK ? cnt - 1u - rr : rr;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(legal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)legal, 0u));
+                    const int lane_sel = __builtin_ctzll(__ballot(mine_legal && below == want));
+                    mv.x = ax;
+                    mv.y = ay;
+                    mv.orient = n == 1 ? lane_sel : (int)__umulhi((uint32_t)lane_sel, inv_n);
+                    mv.shift = lane_sel - mv.orient * n;
+                    return mv;
+                }
+                rr -= cnt;
+                if (cr == 0u) return mv;                         // (unreachable: the row's counts add up to row_total)
             }
-            rr -= cnt;
-            if (cr == 0u) return mv;                             // (unreachable: the row's counts add up to row_total)
         }
-    }
-    return mv;   // unreachable when r < total
+        return mv;                                               // unreachable when r < total
+    };
+    return back ? walk(std::true_type{}) : walk(std::false_type{});
 }
 
 // place the piece (board.py:87-103; no legality check there) and update inventory / score (ai.py:44-54)
