@@ -570,6 +570,21 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
     wave_sync();
 }
 
+// the board part of blk_apply for a move known to be legal (its cells are empty: only the mover's colour changes)
+__device__ __forceinline__ void blk_place_legal(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv, const int lane)
+{
+    const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[mv.piece]);
+    const uint8_t *cells = &T.cells[mv.piece * 8 + mv.orient][0];
+    const uint32_t oc = cells[mv.shift];
+    const int ox = (int)(oc & 15u), oy = (int)(oc >> 4);
+    if (lane < n) {
+        const uint32_t cc = cells[lane];
+        const int x = mv.x + (int)(cc & 15u) - ox, y = mv.y + (int)(cc >> 4) - oy;
+        if (x >= 0 && x < BN && y >= 0 && y < BN) atomicOr(&L.occ[q][y], 1u << x);
+    }
+    wave_sync();
+}
+
 struct BlkOutcome { int reward, terminal, winners; };
 
 // BlokusEnvironment.py:424-447 once `any_move` is known
@@ -914,9 +929,14 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
                       const crl_blokus_stats st)
 {
     BLK_SHARED_SETUP();
-    uint32_t inv[4];
-    int score[4];
-    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    // Inventories and scores live in VECTOR registers, one player per lane (lane & 3; replicated over the wave): this
+    // kernel is bound by the scalar unit (one instruction per ~4.2 cycles per SIMD, tools/ubench/valu_rate.hip), and as
+    // four-entry arrays of scalar registers every "inventory of player pl" is a chain of three s_cselect and every update
+    // eight of them (round 2 / early round 3: ~50 scalar instructions per ply in blk_apply alone).
+    for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = occ[b * 4 * BN + i];
+    uint32_t vinv = inv_g[b * 4 + (lane & 3)];
+    int vscore = score_g[b * 4 + (lane & 3)];
+    wave_sync();
     int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
     uint32_t tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tcount[b]);
     uint32_t ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.tstep[b]);
@@ -935,15 +955,11 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BLK_STAMP(0);
         blk_prep(L, lane, round, pl);                            // the mover's rows; another player's only when the game may end
         BLK_STAMP(1);
-        uint32_t ip = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ip = (c == pl) ? inv[c] : ip;
+        const uint32_t ip = (uint32_t)__builtin_amdgcn_readlane((int)vinv, pl);
         uint32_t piece_incl = 0u, piece_cnt = 0u;
         const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt);   // len(valid_actions) of the mover
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
-        // one Philox call serves 4 plies (everything here is wave-uniform: the ten rounds run on the scalar unit, ~100
-        // instructions -- worth keeping the four words across plies)
         // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lane k (k < 4)
         // computes block (tc >> 4) * 4 + k, a ply takes its word out of lane (tc >> 2) & 3 with a v_readlane.  (Round 2 ran
         // the ten rounds on the scalar unit, everything being wave-uniform: ~110 scalar instructions every fourth ply.
@@ -976,25 +992,33 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         for (int q = 0; q < 4 && !any_move; ++q) {
             if (q == pl || ((dead >> q) & 1u)) continue;
             blk_prep(L, lane, round, q);
-            uint32_t iq = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+            const uint32_t iq = (uint32_t)__builtin_amdgcn_readlane((int)vinv, q);
             any_move = blk_exists(T, L, q, iq, lane);
             if (any_move) can_move |= 1u << q;
             if (!any_move && round >= 1) dead |= 1u << q;
         }
         BLK_STAMP(5);
         if (total > 0) {
-            blk_apply<true>(T, L, pl, mv, inv, score, lane);
+            blk_place_legal(T, L, pl, mv, lane);
+            {                                                   // ai.py:44-54 for the mover's lane(s)
+                const int n = __builtin_amdgcn_readlane((int)piece_cells, mv.piece);
+                const uint32_t left = vinv & ~(1u << mv.piece);
+                const bool me = (lane & 3) == pl;
+                vscore += me ? n + (left == 0u ? (mv.piece == 0 ? 20 : 15) : 0) : 0;
+                vinv = me ? left : vinv;
+            }
             can_move = 0;                                       // the board changed
             BLK_STAMP(4);
         }
         if (pl == 3) can_move = 0;                              // ... and so does the round (round 0 has its own anchor rule)
-        const BlkOutcome out = blk_outcome(any_move, pl, score);
+        const int mover = pl;
         round += (pl == 3) ? 1 : 0;
         pl = (pl + 1) & 3;
         ts += 1;
-        if (out.terminal) {
+        if (!any_move) {                                        // terminal (BlokusEnvironment.py:424-440): the scores become scalars
+            const int score[4] = {__builtin_amdgcn_readlane(vscore, 0), __builtin_amdgcn_readlane(vscore, 1),
+                                  __builtin_amdgcn_readlane(vscore, 2), __builtin_amdgcn_readlane(vscore, 3)};
+            const BlkOutcome out = blk_outcome(false, mover, score);
             dead = 0; can_move = 0;
             if (lane == 0) {        // episode statistics go straight to memory (this wave owns game b): nothing to carry
                 st.n_episodes[b] += 1;
@@ -1005,7 +1029,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
                     st.score_sum[c * B + b] += score[c];
                 }
             }
-            blk_fresh(L, lane, inv, score);
+            for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = 0u;
+            vinv = (1u << NPIECE) - 1u;
+            vscore = 0;
+            wave_sync();
             round = 0; pl = 0; ts = 0;
         }
     }
@@ -1014,7 +1041,9 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_blk_stamps[i], stamp_acc[i]);
 #endif
-    blk_store_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    wave_sync();
+    for (int i = lane; i < 4 * BN; i += 64) occ[b * 4 * BN + i] = L.occ[i / BN][i % BN];
+    if (lane < 4) { inv_g[b * 4 + lane] = vinv; score_g[b * 4 + lane] = vscore; }
     if (lane == 0) {
         round_g[b] = round; to_move_g[b] = pl;
         st.tcount[b] = tc; st.tstep[b] = ts;
