@@ -947,7 +947,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
     uint32_t dead = 0, can_move = 0;
     const uint32_t piece_cells = lane < 24 ? T.ncell[lane] : 0u;   // lane p: cells of piece p, for the whole launch
-    philox_out rnd = {{0u, 0u, 0u, 0u}};
+    uint32_t rnd_word = 0u;
 #ifdef BLK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -960,19 +960,24 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt);   // len(valid_actions) of the mover
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
-        // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lane k (k < 4)
-        // computes block (tc >> 4) * 4 + k, a ply takes its word out of lane (tc >> 2) & 3 with a v_readlane.  (Round 2 ran
+        // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lanes 4k .. 4k+3
+        // compute block (tc >> 4) * 4 + k and keep one of its words each, a ply takes its word out of lane tc & 15 with a
+        // v_readlane.  (Round 2 ran
         // the ten rounds on the scalar unit, everything being wave-uniform: ~110 scalar instructions every fourth ply.
         // But this kernel is bound by the SCALAR unit -- it issues one instruction per ~4.2 cycles per SIMD whatever the
         // occupancy, half the rate of the vector unit (tools/ubench/valu_rate.hip, mix "salu"), and a ply has 408 scalar
         // against 529 vector instructions -- so uniform work is cheaper on the vector side.)
-        if ((tc & 15u) == 0u || t == 0) rnd = philox4x32_10(g, ((tc >> 4) << 2) + (uint32_t)(lane & 3), 0u, CRL_TAG_BLOKUS, seed_lo, seed_hi);
-        const uint32_t sel = tc & 3u;
-        uint32_t wsel = rnd.w[0];
-        wsel = (sel == 1) ? rnd.w[1] : wsel;
-        wsel = (sel == 2) ? rnd.w[2] : wsel;
-        wsel = (sel == 3) ? rnd.w[3] : wsel;
-        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)wsel, (int)((tc >> 2) & 3u));
+        if ((tc & 15u) == 0u || t == 0) {
+            // lane j (j < 16) ends up with the word of ply (tc & ~15) + j: block j >> 2, word j & 3.  (The seed goes through
+            // an opaque copy: the ten rounds' keys are then derived here, every 16 plies, instead of living in 20 scalar
+            // registers across the whole step loop -- which had the compiler shuffle a dozen s_mov around the select walk.)
+            uint32_t k0 = seed_lo, k1 = seed_hi;
+            asm volatile("" : "+s"(k0), "+s"(k1));
+            const philox_out r4 = philox4x32_10(g, ((tc >> 4) << 2) + (uint32_t)((lane >> 2) & 3), 0u, CRL_TAG_BLOKUS, k0, k1);
+            const int ws = lane & 3;
+            rnd_word = ws == 0 ? r4.w[0] : ws == 1 ? r4.w[1] : ws == 2 ? r4.w[2] : r4.w[3];
+        }
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)rnd_word, (int)(tc & 15u));
         tc += 1;
         bool any_move = false;
         BlkMove mv = {0, 0, 0, 0, 0};
