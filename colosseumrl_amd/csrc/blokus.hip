@@ -479,7 +479,6 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
         }
     }
     const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]);
-    BlkMove mv = {piece, 0, 0, 0, 0};
     // The walk starts from whichever end of the anchor order is nearer in rank: the piece's total is known (pcnt), so an
     // action in the upper half of the piece's range is counted down from the last anchor -- a quarter of the anchors per
     // select on average instead of half.
@@ -491,43 +490,51 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     // at one by one (a ballot, a popcount and a compare each on the scalar unit).  The two walking directions are two
     // instances of the loop (BACK a compile-time constant): selecting ctz / clz per row and per anchor cost a handful of
     // scalar instructions each time, and the scalar unit is what bounds this kernel.
+    // Two plain loops with one exit each -- first the row, then the anchor in it (as nested loops with a `return` in the
+    // middle the compiler built a maze of flag registers and branches: ~15 scalar instructions per anchor).  Both end by
+    // themselves because r < total (the row counts add up to the piece's total, an anchor's counts to its row's); running
+    // out of rows / anchors ends them too, so that an inconsistent state could give a wrong move but not a hang.
     auto walk = [&](auto back_tag) -> BlkMove {
         constexpr bool BACK = decltype(back_tag)::value;
-        while (rows_mask) {
-            const int ay = BACK ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
+        int ay;
+        uint32_t cr, m, row_total;
+        do {
+            ay = BACK ? 31 - __builtin_clz(rows_mask) : __builtin_ctz(rows_mask);
             rows_mask &= ~(1u << ay);
-            uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);     // this row's anchors, bit x
+            cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);              // this row's anchors, bit x
             // bit x: my (orientation, shift) pair is legal on anchor (x, ay)
             uint32_t fr = pair ? 0xffffffffu : 0u;
             const char *rowp = acq + ay * (int)sizeof(uint2);
 #pragma unroll
             for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
-            const uint32_t m = fr & cr;
-            const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
-            if (rr >= row_total) { rr -= row_total; continue; }
-            for (;;) {                                           // rr < row_total: the anchor is in this row
-                const int ax = BACK ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
-                const uint32_t bit = 1u << ax;
-                cr &= ~bit;
-                const bool mine_legal = (m & bit) != 0u;
-                const unsigned long long legal = __ballot(mine_legal);
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(legal);
-                if (rr < cnt) {                                  // level 3: the chosen legal pair at this anchor
-                    // its lane: the legal lane with exactly `want` legal lanes below it (v_mbcnt: no scalar bit search)
-                    const uint32_t want = BACK ? cnt - 1u - rr : rr;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(legal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)legal, 0u));
-                    const int lane_sel = __builtin_ctzll(__ballot(mine_legal && below == want));
-                    mv.x = ax;
-                    mv.y = ay;
-                    mv.orient = n == 1 ? lane_sel : (int)__umulhi((uint32_t)lane_sel, inv_n);
-                    mv.shift = lane_sel - mv.orient * n;
-                    return mv;
-                }
-                rr -= cnt;
-                if (cr == 0u) return mv;                         // (unreachable: the row's counts add up to row_total)
-            }
-        }
-        return mv;                                               // unreachable when r < total
+            m = fr & cr;
+            row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
+            if (rr < row_total) break;
+            rr -= row_total;
+        } while (rows_mask);
+        int ax;
+        uint32_t cnt;
+        unsigned long long legal;
+        bool mine_legal;
+        do {                                                     // rr < row_total: the anchor is in this row
+            ax = BACK ? 31 - __builtin_clz(cr) : __builtin_ctz(cr);
+            const uint32_t bit = 1u << ax;
+            cr &= ~bit;
+            mine_legal = (m & bit) != 0u;
+            legal = __ballot(mine_legal);
+            cnt = (uint32_t)__builtin_popcountll(legal);
+            if (rr < cnt) break;
+            rr -= cnt;
+        } while (cr);
+        // level 3: the chosen legal pair at this anchor: the legal lane with exactly `want` legal lanes below it
+        // (v_mbcnt: no scalar bit search)
+        const uint32_t want = BACK ? cnt - 1u - rr : rr;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(legal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)legal, 0u));
+        const int lane_sel = __builtin_ctzll(__ballot(mine_legal && below == want) | (1ull << 63));
+        BlkMove out = {piece, ax, ay, 0, 0};
+        out.orient = n == 1 ? lane_sel : (int)__umulhi((uint32_t)lane_sel, inv_n);
+        out.shift = lane_sel - out.orient * n;
+        return out;
     };
     return back ? walk(std::true_type{}) : walk(std::false_type{});
 }
