@@ -15,12 +15,14 @@ also runs in a world of one rank when a process group exists, e.g. under `torchr
 rank stops when its own work incl. the collective is complete; the value uses the MAX over ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --only-headline):
-  roofline      measured HBM bytes per launch (rocprofv3 PMC of the SAME launch shape, profiles/traffic_*.json; a
-                documented per-launch traffic model when no PMC pass exists for the shape) / launch time vs the 8 TB/s
-                spec and vs the device-copy bandwidth measured in this run; `algorithmic` = SURVEY 8(d)'s per-step bytes
-                x env-steps per launch / launch time (what a step-at-a-time stepper would have to move -- the fused
-                kernels keep state in LDS, so this exceeds the physical traffic on long launches); `valu_issue` = PMC
-                SQ_INSTS_VALU of that launch shape / launch time against the MEASURED issue peak
+  roofline      the contract's formula: `achieved` = SURVEY 8(d)'s algorithmic bytes per env-step x the env-steps of one
+                launch / the launch's duration (HIP events attached to the dispatch; the marker-event figure beside it),
+                `frac` = / 8 TB/s; `traffic` = the HBM bytes the launch really moved (rocprofv3 PMC of the SAME launch
+                shape, profiles/traffic_*.json; a documented model when no PMC pass exists for the shape) with
+                `physical_achieved` / `physical_frac` / `frac_of_copy` (vs the device-copy bandwidth measured in this
+                run) from it.  The fused kernels keep state in LDS across a launch, so on LONG launches the algorithmic
+                figure exceeds the physical one and 1.0 (noted in the object): their roof is instruction issue --
+                `valu_issue` = PMC SQ_INSTS_VALU of that launch shape / launch time against the MEASURED issue peak
                 (tools/ubench/valu_rate.hip -> profiles/r2_valu_issue_calibration.json)
   steady_state  the same workload in long launches (the regime a rollout worker lives in)
   seeds         the headline region repeated for seeds {0, 1, 2}
@@ -221,7 +223,12 @@ def valu_peaks(waves_per_simd):
     return peak, rows[w]["valu_wave_insts_per_s"], "measured: profiles/r2_valu_issue_calibration.json (tools/ubench/valu_rate.hip)"
 
 
-def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs):
+def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source=None):
+    """The contract's roofline object.  `achieved` / `frac` follow the task's formula: ALGORITHMIC bytes of one launch
+    (SURVEY 8(d)'s per-env-step figure x the env-steps the launch processes) / the launch's duration, against 8 TB/s;
+    `traffic` = the HBM bytes the launch really moved (PMC); `physical_*` = that traffic / the same duration.  A fused
+    launch keeps its state in LDS / registers across its steps, so for long launches the algorithmic figure exceeds the
+    physical one by about the number of fused steps (and 1.0): HBM is then not the kernel's roof, `valu_issue` is."""
     game, kw = WORKLOADS[workload][:2]
     wps = WORKLOADS[workload][4]
     alg_bps = algorithmic_bytes_per_step(game, kw, mean_len)
@@ -231,16 +238,20 @@ def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs):
         traffic, source = int(pmc["hbm_bytes_per_launch"]) * batch // int(pmc.get("games", batch)), "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), same launch shape: profiles/traffic_%s.json" % workload
     else:
         traffic, source = int(launch_traffic_model(game, kw) * batch), "model: state in + out once per launch + statistics (no PMC pass for %d-step launches)" % steps_per_launch
-    achieved = traffic / launch_s / 1e9
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    phys = traffic / launch_s / 1e9
+    r = {"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
          "traffic": traffic, "traffic_source": source, "kernel": kernel_name(game, kw, steps_per_launch),
          "steps_per_launch": int(steps_per_launch), "launch_ms": launch_s * 1e3,
-         "algorithmic": {"bytes_per_env_step": round(alg_bps, 2), "achieved": alg_gbs, "frac": alg_gbs / HBM_PEAK_GBS,
-                         "note": "SURVEY 8(d) bytes of a step-at-a-time stepper x env-steps per launch / launch time; the fused "
-                                 "kernel keeps state in LDS/registers across the launch, so this is not physical traffic"}}
+         "launch_ms_source": launch_source or "HIP events around back-to-back launches on the launch stream",
+         "bytes_per_env_step": round(alg_bps, 2),
+         "formula": "achieved = bytes_per_env_step (SURVEY 8(d): 12P+2 + (N*N+4P)/mean_episode_len for Tron) x games x steps_per_launch / launch_ms",
+         "physical_achieved": phys, "physical_frac": phys / HBM_PEAK_GBS}
+    if r["frac"] > 1.0:
+        r["note"] = ("frac > 1: the fused launch keeps boards in LDS / registers across its %d steps, so the algorithmic bytes of a "
+                     "step-at-a-time stepper are never moved; HBM is not this launch shape's roof -- see valu_issue and physical_frac" % steps_per_launch)
     if copy_gbs:
         r["copy_peak"] = copy_gbs
-        r["frac_of_copy"] = achieved / copy_gbs
+        r["frac_of_copy"] = phys / copy_gbs               # physical traffic against the device-copy ceiling of this run
     if pmc and pmc.get("valu_insts_per_launch"):
         peak, peak_occ, src = valu_peaks(wps)
         v = pmc["valu_insts_per_launch"] / launch_s
@@ -629,19 +640,20 @@ def world_of_one_gather_us(torch, dist, make, args, steps_per_launch):
 def compact_summary(out):
     """<= ~1.5 KB of scalars, emitted as the LAST key of the line so that a record that keeps only the tail of stdout
     still carries every headline number: per workload env-steps/s (v), ms per launch (ms), HBM fraction of 8 TB/s
-    (hbm: measured traffic / launch time), VALU issue fraction of the measured peak (valu)."""
+    by the contract's formula (alg: algorithmic bytes / launch time; above 1 for long fused launches) and physical (hbm:
+    measured PMC traffic / launch time), VALU issue fraction of the measured peak (valu)."""
     def sig(x, n=4):
         return None if x is None else float("%.*g" % (n, x))
 
     def wl(rec):
         r = rec.get("roofline", {})
-        return {"v": sig(rec.get("value")), "ms": sig(r.get("launch_ms")), "hbm": sig(r.get("frac"), 3),
+        return {"v": sig(rec.get("value")), "ms": sig(r.get("launch_ms")), "alg": sig(r.get("frac"), 3), "hbm": sig(r.get("physical_frac"), 3),
                 "valu": sig(r.get("valu_issue", {}).get("frac"), 3),
                 "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
     sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig(out["kernel_ms"] * 1e3),
                        "kernel_dispatch_us": sig((out.get("kernel_ms_dispatch") or 0) * 1e3) or None,
-                       "hbm": sig(out["roofline"].get("frac"), 3), "of_copy": sig(out["roofline"].get("frac_of_copy"), 3),
-                       "alg": sig(out["roofline"]["algorithmic"]["frac"], 3), "cold_v": sig(out.get("value_cold")),
+                       "alg": sig(out["roofline"].get("frac"), 3), "hbm": sig(out["roofline"].get("physical_frac"), 3),
+                       "of_copy": sig(out["roofline"].get("frac_of_copy"), 3), "cold_v": sig(out.get("value_cold")),
                        "cold_us": sig(out.get("cold_first_region_us")), "gather_us": (out.get("gather") or {}).get("gather_us")}}
     if "steady_state" in out:
         sm[out["config"]["workload"]] = wl(dict(out["steady_state"], cpu_baseline=out.get("cpu_baseline", {})))
@@ -733,7 +745,12 @@ def main():
     for e in events:
         e.record()                                         # creates the HIP events (torch does so lazily)
     torch.cuda.synchronize()
-    region_events = None if use_dist else events           # (see timed_rollout: no timing events next to a collective)
+    # The contract region carries NO timing events at any world size: two hipEventRecord calls are 3.6 us of a 36-us region
+    # in a single process and ~10 us next to a collective (see timed_rollout), and a per-N value that is instrumented at
+    # N = 1 only would skew the scaling curve the driver derives from these lines.  The launches are timed in further
+    # regions of the same shape right after (`launch_time_pass`: recorded markers; `dispatch_time_pass`: events attached
+    # to the dispatch).  CRL_BENCH_REGION_EVENTS=1 puts the markers back into the region (single process only).
+    region_events = events if (not use_dist and os.environ.get("CRL_BENCH_REGION_EVENTS") == "1") else None
     dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
 
     def contract_region():
@@ -786,7 +803,17 @@ def main():
         # launches of the timed region are equal-sized when steps % chunk == 0; otherwise the roofline describes the
         # dominant (first) launch shape and uses the mean launch time only as an approximation -- flagged below
         equal = (args.steps % steps_per_launch) == 0
+        # The launch's duration for the roofline: HIP events ATTACHED to the dispatch (the kernel's own begin -> end, median
+        # of 20 isolated regions of the timed shape) where the stepper offers them -- that is the figure rocprofv3's
+        # --stats average for the kernel agrees with (profiles/r3_tron_n20_t20_*: 18.05 us back to back); two RECORDED
+        # marker events around the launch also see the gap between the first marker and the kernel's start (~3-5 us on a
+        # 20-us launch).  Both are in the line (`kernel_ms_dispatch`, `kernel_ms`).
         launch_s = kernel_s / launches
+        launch_source = "HIP marker events recorded around the launches of " + ("the timed region" if region_events else "one more region of the timed shape")
+        if kernel_dispatch_s and launches == 1:
+            launch_s = kernel_dispatch_s
+            launch_source = ("HIP events attached to the dispatch (hipExtLaunchKernel start / stop), median of 20 isolated regions of the "
+                             "timed shape; marker events recorded around such a launch: %.2f us" % (kernel_s * 1e6))
         row_bytes = int(gathered.shape[-1] * gathered.element_size())
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -803,14 +830,14 @@ def main():
                                          "%.0f ms of device copies + launches on a scratch stepper between the cold region and W + K "
                                          "(value_cold = the same region before it)" % device_warmup_ms)},
             "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
-            "kernel_ms_source": ("HIP events around the launches of the timed region" if region_events else
-                                 "HIP events around the launches of one more region of the same shape (timing events next to a "
-                                 "collective cost ~10 us of the region: not recorded inside it)"),
+            "kernel_ms_source": ("HIP marker events around the launches of the timed region" if region_events else
+                                 "HIP marker events around the launches of one more region of the same shape, right after the timed "
+                                 "one (two event records cost 3.6 us of the region, ~10 us next to a collective: not recorded inside it)"),
             "device_warmup_ms": round(device_warmup_ms, 1),
             "kernel_ms_dispatch": kernel_dispatch_s * 1e3 if kernel_dispatch_s else None,
             "value_cold": world * batch * args.steps / cold_elapsed, "cold_first_region_us": cold_elapsed * 1e6,
             "cold_kernel_us": cold[1] * 1e6,
-            "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs),
+            "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source),
         }
         if not equal:
             out["roofline"]["note"] = "launches of the timed region are not equal-sized; launch_ms is their mean"
@@ -831,9 +858,8 @@ def main():
             # records that keep only part of the line)
             ssr = out["steady_state"]["roofline"]
             out["roofline"].update({"steady_value": out["steady_state"]["value"], "steady_launch_ms": ssr["launch_ms"],
-                                    "steady_hbm_frac": ssr["frac"], "steady_valu_frac": ssr.get("valu_issue", {}).get("frac"),
-                                    "algorithmic_frac": out["roofline"]["algorithmic"]["frac"],
-                                    "steady_algorithmic_frac": ssr["algorithmic"]["frac"]})
+                                    "steady_frac": ssr["frac"], "steady_physical_frac": ssr["physical_frac"],
+                                    "steady_valu_frac": ssr.get("valu_issue", {}).get("frac")})
             others = {}
             for wl in WORKLOADS:
                 if wl == args.workload:

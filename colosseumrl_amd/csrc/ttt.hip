@@ -101,6 +101,9 @@ __device__ __forceinline__ void ttt_step_core(const ttt_dirs &dd, uint32_t (&o)[
 // min (r - c wraps to a huge value exactly when r < c), the position by a compare.
 __device__ __forceinline__ int nth_set_bit(const uint32_t m, int r)
 {
+    // (Round 3 tried the decision of a level as a sign mask -- t = rr - c, neg = t >> 31 (arithmetic), pos |= w & ~neg --
+    //  which keeps the chain off VCC and so saves the wait state (s_nop) each level's select needs behind the VALU write
+    //  of VCC; but the mask costs a VALU instruction and lengthens the dependent chain: 1.107 -> 1.180 ms per 2048 plies.)
     uint32_t rr = (uint32_t)r, pos = 0, c;
     c = (uint32_t)__popc(m & 0xffffu);                              pos = (rr >= c) ? 16u : 0u;          rr = min(rr, rr - c);
     c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 8u));        pos = (rr >= c) ? pos + 8u : pos;    rr = min(rr, rr - c);
@@ -176,30 +179,34 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     // once it has been through a ply of this kernel, because a finished game restarts at once: the random agent's move
     // is legal by construction, so next_state's checks (in range, cell empty, no winner yet: tictactoe_2p_env.py:293) and
     // the empty-board-is-full corner fall away, and the winner is known the moment the line test says so.
+    // Round 3: the players' masks ROTATE through the registers r[] -- r[0] is always the mover's, because the players move
+    // in strict rotation (:313) and a restart empties every mask, so that the rotation's phase means nothing across it.
+    // The mover's mask then costs no select chain (round 2: P compares, 2 P selects and an or3 per ply) and, the plies
+    // being unrolled, the rotation itself is register renaming.  Episode lengths are not summed per episode either: the
+    // lengths of the episodes a lane finished add up to the plies it played minus the length of the unfinished one, so
+    // a lane only remembers where its current episode began (ep0, a ply index of this launch), and the draws are the
+    // episodes nobody won.
     uint32_t all_run = 0;                                       // every player's marks (kept across running plies)
-    auto ply_running = [&](auto k_tag, const uint32_t word) {   // k_tag: K as a compile-time constant (0: read it from dd)
+    uint32_t r[P];
+    int ep0 = 0;                                                // ply index (of this launch) at which the current episode began
+    auto ply_running = [&](auto k_tag, const uint32_t word, const int t_after) {   // k_tag: K as a compile-time constant (0: read it from dd)
         constexpr int KC = decltype(k_tag)::value;
-        const uint32_t all = all_run;
-        const uint32_t empty = dd.full & ~all;                  // (not 0: the game is running)
+        const uint32_t empty = dd.full & ~all_run;              // (not 0: the game is running)
         const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, (uint32_t)__popc(empty)));
-        const int pl = tm;
-        uint32_t mine = bit;
-#pragma unroll
-        for (int p = 0; p < P; ++p) mine |= (p == pl) ? o[p] : 0u;
-#pragma unroll
-        for (int p = 0; p < P; ++p) o[p] = (p == pl) ? mine : o[p];                    // :295
+        const uint32_t mine = r[0] | bit;                                              // :295
         const bool won = ttt_has_line<ND, KC>(dd, mine);                               // :296-300
-        all_run = all | bit;
+        all_run |= bit;
         const bool term = won | (all_run == dd.full);                                  // :302-311
+#pragma unroll
+        for (int p = 0; p + 1 < P; ++p) r[p] = r[p + 1];
+        r[P - 1] = mine;
+        const int pl = tm;
         tm = (pl + 1 == P) ? 0 : pl + 1;                                               // :313
-        ts += 1;
         if (term) {
             n_ep += 1;
-            len_sum += ts;
-            draws += won ? 0u : 1u;
 #pragma unroll
-            for (int p = 0; p < P; ++p) { wins[p] += (won && pl == p) ? 1u : 0u; o[p] = 0; }
-            tm = 0; ts = 0; all_run = 0;
+            for (int p = 0; p < P; ++p) { wins[p] += (won && pl == p) ? 1u : 0u; r[p] = 0; }
+            tm = 0; all_run = 0; ep0 = t_after;
         }
     };
     auto next_word = [&]() -> uint32_t {                        // the word of step counter tc, then on to tc + 1
@@ -222,8 +229,20 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
             t = 1;
         }
     }
+    // into the rotating order: r[i] = the marks of player (tm + i) mod P
+    const int tm_in = (unsigned)tm < (unsigned)P ? tm : 0;
 #pragma unroll
-    for (int p = 0; p < P; ++p) all_run |= o[p];
+    for (int i = 0; i < P; ++i) {
+        int q = tm_in + i;
+        q = q >= P ? q - P : q;
+        uint32_t v = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { v = (q == p) ? o[p] : v; }
+        r[i] = v;
+        all_run |= v;
+    }
+    ep0 = t - (int)ts;                                          // the current episode is ts plies old
+    const int ep0_in = ep0;
     // One Philox call serves 4 plies.  When every game of the wave stands at a step counter that is a multiple of four
     // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
     // per-ply select chain, one refill test per trip.
@@ -231,19 +250,38 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     auto run_plies = [&](auto k_tag) {
         if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
             for (; t + 4 <= T; t += 4) {
-                ply_running(k_tag, rnd.w[0]);
-                ply_running(k_tag, rnd.w[1]);
-                ply_running(k_tag, rnd.w[2]);
-                ply_running(k_tag, rnd.w[3]);
+                ply_running(k_tag, rnd.w[0], t + 1);
+                ply_running(k_tag, rnd.w[1], t + 2);
+                ply_running(k_tag, rnd.w[2], t + 3);
+                ply_running(k_tag, rnd.w[3], t + 4);
                 tc += 4;
                 rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
             }
         }
-        for (; t < T; ++t) ply_running(k_tag, next_word());
+        for (; t < T; ++t) ply_running(k_tag, next_word(), t + 1);
     };
     if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
     else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
     else run_plies(std::integral_constant<int, 0>{});
+    // back out of the rotating order, and the bookkeeping the running plies left implicit
+    {
+        const int tm_out = (unsigned)tm < (unsigned)P ? tm : 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int i = p - tm_out;
+            i = i < 0 ? i + P : i;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) { v = (i == k) ? r[k] : v; }
+            o[p] = v;
+        }
+        ts = (uint32_t)(T - ep0);                               // plies of the unfinished episode
+        len_sum += (uint32_t)(ep0 - ep0_in);                    // = the lengths of the episodes finished by running plies
+        uint32_t won_total = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) won_total += wins[p];
+        draws = n_ep - won_total;                               // (the general ply counted its own outcome in both)
+    }
     int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
     for (int p = 0; p < P; ++p) {
