@@ -113,6 +113,17 @@ __device__ __forceinline__ int nth_set_bit(const uint32_t m, int r)
     return (int)pos;
 }
 
+// the random agent's 32-bit draw for the ply at step counter c of game g with n_empty empty cells (the RNG contract of
+// ttt_rollout_kernel, stated there): the ply picks empty cell number hi32(draw * n_empty)
+__device__ __forceinline__ uint32_t ttt_agent_word(const uint32_t g, const uint32_t c, const int n_empty, const uint32_t seed_lo,
+                                                   const uint32_t seed_hi)
+{
+    const philox_out rnd = philox4x32_10<true>(g, c >> 3, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    const uint32_t sel = (c >> 1) & 3u;
+    const uint32_t w = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+    return (c & 1u) ? w * (uint32_t)(n_empty + 1) : w;
+}
+
 template <int P, int ND>
 __global__ void __launch_bounds__(256)
 ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, int8_t *__restrict__ winner,
@@ -154,14 +165,21 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     int w = winner[b], tm = to_move[b];
     uint32_t tc = st.tcount[b], ts = st.tstep[b], n_ep = 0, draws = 0, len_sum = 0;
     const uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
-    philox_out rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
-    // one ply with random word `word`
-    auto ply = [&](const uint32_t word) {
+    // RNG contract (round 3, identical in the oracle): one Philox call serves EIGHT plies, a 32-bit word two -- block
+    // tc >> 3, word (tc >> 1) & 3.  The ply at an even step counter reads the word w itself, the ply at an odd one
+    // lo32(w * (n_empty + 1)): what the even ply's extraction hi32(w * n) left over when that ply was the one before in the
+    // same game (n = n_empty + 1 then; the two choices are the leading digits of w in the mixed radix (n, n - 1), bias
+    // < n^2 / 2^32).  The definition does not look back, so any ply follows from (seed, game, step counter, board) alone.
+    // Round 2 drew one word per ply: the ten Philox rounds were 36 % of a ply's vector instructions.
+    philox_out rnd = philox4x32_10<true>(g, tc >> 3, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+    // one ply with the Philox word `pw` of its step counter (odd: that counter is odd)
+    auto ply = [&](const uint32_t pw, const uint32_t odd) {
         uint32_t all = 0;
 #pragma unroll
         for (int p = 0; p < P; ++p) all |= o[p];
         const uint32_t empty = dd.full & ~all;
         const int n_empty = __popc(empty);
+        const uint32_t word = odd ? pw * (uint32_t)(n_empty + 1) : pw;
         const int action = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
         int r, term, ws;
         ttt_step_core<P, ND>(dd, o, w, tm, action, r, term, ws);
@@ -184,15 +202,38 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     // The mover's mask then costs no select chain (round 2: P compares, 2 P selects and an or3 per ply) and, the plies
     // being unrolled, the rotation itself is register renaming.  Episode lengths are not summed per episode either: the
     // lengths of the episodes a lane finished add up to the plies it played minus the length of the unfinished one, so
-    // a lane only remembers where its current episode began (ep0, a ply index of this launch), and the draws are the
-    // episodes nobody won.
+    // a lane only remembers where its current episode began (ep0, a ply index of this launch).  And the outcomes are
+    // counted in ONE register of byte fields -- field p the wins of player p, field P the draws (P = 8: the draws are the
+    // episodes nobody won) -- which a finished episode bumps with a select, a shift and an add (per-player counters: a
+    // compare, a select and an add EACH, in the block some lane of the wave runs on practically every ply); the fields are
+    // flushed into the 32-bit counters before any can reach 256, i.e. at least every 248 plies.
     uint32_t all_run = 0;                                       // every player's marks (kept across running plies)
     uint32_t r[P];
     int ep0 = 0;                                                // ply index (of this launch) at which the current episode began
-    auto ply_running = [&](auto k_tag, const uint32_t word, const int t_after) {   // k_tag: K as a compile-time constant (0: read it from dd)
+    constexpr bool DRAW_FIELD = P < 8;
+    using acc_t = std::conditional_t<(P <= 3), uint32_t, uint64_t>;
+    acc_t acc = 0;
+    int tm8 = 0;                                                // 8 * (player to move) while the running plies are at it
+    auto flush = [&]() {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t f = (uint32_t)(acc >> (8 * p)) & 0xffu;
+            wins[p] += f;
+            n_ep += f;
+        }
+        if (DRAW_FIELD) {
+            const uint32_t f = (uint32_t)(acc >> (8 * (P & 7))) & 0xffu;
+            draws += f;
+            n_ep += f;
+        }
+        acc = 0;
+    };
+    auto ply_running = [&](auto k_tag, const uint32_t w, const uint32_t odd, const int t_after) {   // k_tag: K as a compile-time constant (0: read it from dd)
         constexpr int KC = decltype(k_tag)::value;
         const uint32_t empty = dd.full & ~all_run;              // (not 0: the game is running)
-        const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, (uint32_t)__popc(empty)));
+        const uint32_t n_empty = (uint32_t)__popc(empty);
+        const uint32_t word = odd ? w * (n_empty + 1u) : w;     // (odd is a constant in the unrolled trips)
+        const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, n_empty));
         const uint32_t mine = r[0] | bit;                                              // :295
         const bool won = ttt_has_line<ND, KC>(dd, mine);                               // :296-300
         all_run |= bit;
@@ -200,23 +241,30 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
 #pragma unroll
         for (int p = 0; p + 1 < P; ++p) r[p] = r[p + 1];
         r[P - 1] = mine;
-        const int pl = tm;
-        tm = (pl + 1 == P) ? 0 : pl + 1;                                               // :313
+        const int pl8 = tm8;
+        tm8 = (pl8 + 8 == 8 * P) ? 0 : pl8 + 8;                                        // :313
         if (term) {
-            n_ep += 1;
+            if (DRAW_FIELD) {
+                acc += (acc_t)1 << (won ? pl8 : 8 * P);
+            } else {
+                acc += (acc_t)(won ? 1u : 0u) << pl8;
+                draws += won ? 0u : 1u;
+                n_ep += won ? 0u : 1u;
+            }
 #pragma unroll
-            for (int p = 0; p < P; ++p) { wins[p] += (won && pl == p) ? 1u : 0u; r[p] = 0; }
-            tm = 0; all_run = 0; ep0 = t_after;
+            for (int p = 0; p < P; ++p) r[p] = 0;
+            tm8 = 0; all_run = 0; ep0 = t_after;
         }
     };
-    auto next_word = [&]() -> uint32_t {                        // the word of step counter tc, then on to tc + 1
-        const uint32_t sel = tc & 3u;
+    auto next_word = [&](uint32_t &odd) -> uint32_t {           // the word of step counter tc, then on to tc + 1
+        const uint32_t sel = (tc >> 1) & 3u;
+        odd = tc & 1u;
         uint32_t word = rnd.w[0];
         word = (sel == 1) ? rnd.w[1] : word;
         word = (sel == 2) ? rnd.w[2] : word;
         word = (sel == 3) ? rnd.w[3] : word;
         tc += 1;
-        if ((tc & 3u) == 0) rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        if ((tc & 7u) == 0) rnd = philox4x32_10<true>(g, tc >> 3, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
         return word;
     };
     int t = 0;
@@ -225,7 +273,9 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
 #pragma unroll
         for (int p = 0; p < P; ++p) all |= o[p];
         if (T > 0 && __builtin_amdgcn_ballot_w64(w >= 0 || all == dd.full || (unsigned)tm >= (unsigned)P) != 0ull) {
-            ply(next_word());
+            uint32_t odd;
+            const uint32_t w0 = next_word(odd);
+            ply(w0, odd);
             t = 1;
         }
     }
@@ -241,31 +291,45 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         r[i] = v;
         all_run |= v;
     }
+    tm8 = 8 * tm_in;
     ep0 = t - (int)ts;                                          // the current episode is ts plies old
     const int ep0_in = ep0;
-    // One Philox call serves 4 plies.  When every game of the wave stands at a step counter that is a multiple of four
-    // (launches of 4 k steps keep it so) the plies run in trips of four with the word picked at compile time: no
-    // per-ply select chain, one refill test per trip.
+    // When every game of the wave stands at a step counter that is a multiple of eight (launches of 8 k steps keep it so)
+    // the plies run in trips of eight -- one Philox call -- with word and parity picked at compile time: no per-ply select
+    // chain, no refill test.
     // (K is wave-uniform: one branch here instead of one per ply)
     auto run_plies = [&](auto k_tag) {
-        if (__builtin_amdgcn_ballot_w64((tc & 3u) != 0u) == 0ull) {
-            for (; t + 4 <= T; t += 4) {
-                ply_running(k_tag, rnd.w[0], t + 1);
-                ply_running(k_tag, rnd.w[1], t + 2);
-                ply_running(k_tag, rnd.w[2], t + 3);
-                ply_running(k_tag, rnd.w[3], t + 4);
-                tc += 4;
-                rnd = philox4x32_10<true>(g, tc >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
+        if (__builtin_amdgcn_ballot_w64((tc & 7u) != 0u) == 0ull) {
+            for (int trips = 0; t + 8 <= T; t += 8) {
+                if (++trips == 32) { flush(); trips = 1; }      // <= 31 trips = 248 plies between flushes
+                ply_running(k_tag, rnd.w[0], 0u, t + 1);
+                ply_running(k_tag, rnd.w[0], 1u, t + 2);
+                ply_running(k_tag, rnd.w[1], 0u, t + 3);
+                ply_running(k_tag, rnd.w[1], 1u, t + 4);
+                ply_running(k_tag, rnd.w[2], 0u, t + 5);
+                ply_running(k_tag, rnd.w[2], 1u, t + 6);
+                ply_running(k_tag, rnd.w[3], 0u, t + 7);
+                ply_running(k_tag, rnd.w[3], 1u, t + 8);
+                tc += 8;
+                rnd = philox4x32_10<true>(g, tc >> 3, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
             }
         }
-        for (; t < T; ++t) ply_running(k_tag, next_word(), t + 1);
+        flush();
+        for (; t < T; ++t) {
+            uint32_t odd;
+            const uint32_t w1 = next_word(odd);
+            ply_running(k_tag, w1, odd, t + 1);
+            if ((t & 127) == 127) flush();
+        }
+        flush();
     };
     if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
     else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
     else run_plies(std::integral_constant<int, 0>{});
     // back out of the rotating order, and the bookkeeping the running plies left implicit
     {
-        const int tm_out = (unsigned)tm < (unsigned)P ? tm : 0;
+        tm = tm8 >> 3;
+        const int tm_out = tm;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             int i = p - tm_out;
@@ -277,10 +341,6 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         }
         ts = (uint32_t)(T - ep0);                               // plies of the unfinished episode
         len_sum += (uint32_t)(ep0 - ep0_in);                    // = the lengths of the episodes finished by running plies
-        uint32_t won_total = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) won_total += wins[p];
-        draws = n_ep - won_total;                               // (the general ply counted its own outcome in both)
     }
     int32_t *row = st.results ? st.results + b * (3 + P) : nullptr;    // packed result row for the gather
 #pragma unroll
@@ -375,10 +435,7 @@ ttt_step_observe_kernel(const ttt_dirs dd, const uint32_t inv_cells, const int64
             for (int p = 0; p < P; ++p) all |= o[p];
             const uint32_t empty = dd.full & ~all, c = tcount[b];
             const int n_empty = __popc(empty);
-            const philox_out rnd = philox4x32_10<true>((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
-            const uint32_t sel = c & 3u;
-            const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
-            act = n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1;
+            act = n_empty ? nth_set_bit(empty, (int)__umulhi(ttt_agent_word((uint32_t)(first_env_id + (uint64_t)b), c, n_empty, seed_lo, seed_hi), (uint32_t)n_empty)) : -1;
             tcount[b] = c + 1u;
         }
         int r, t, ws;
@@ -417,9 +474,7 @@ ttt_sample_kernel(const int P, const uint32_t full, const int64_t B, const uint3
     for (int p = 0; p < P; ++p) all |= occ[p * B + b];
     const uint32_t empty = full & ~all, c = tcount[b];
     const int n_empty = __popc(empty);
-    const philox_out rnd = philox4x32_10<true>((uint32_t)(first_env_id + (uint64_t)b), c >> 2, 0u, CRL_TAG_TTT, seed_lo, seed_hi);
-    const uint32_t sel = c & 3u;
-    const uint32_t word = sel == 0 ? rnd.w[0] : sel == 1 ? rnd.w[1] : sel == 2 ? rnd.w[2] : rnd.w[3];
+    const uint32_t word = ttt_agent_word((uint32_t)(first_env_id + (uint64_t)b), c, n_empty, seed_lo, seed_hi);
     action[b] = (int8_t)(n_empty ? nth_set_bit(empty, (int)__umulhi(word, (uint32_t)n_empty)) : -1);
     if (advance) tcount[b] = c + 1u;
 }

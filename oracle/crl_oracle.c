@@ -384,9 +384,16 @@ void orc_ttt_rollout(int n_cells, int P, int n_lines, const uint32_t *lines, int
             for (int p = 0; p < P; ++p) all |= o[p];
             uint32_t empty = full & ~all;
             int n_empty = __builtin_popcount(empty);
-            uint32_t ctr[4] = { g, tc >> 2, 0u, ORC_TAG_TTT }, rnd[4];
+            /* RNG contract (round 3): one Philox call serves EIGHT plies, a 32-bit word two.  The ply at an even step counter
+               reads the word w itself; the ply at an odd one reads lo32(w * (n_empty + 1)) -- what the even ply's extraction
+               hi32(w * n) left over, when that ply was the one before in the same game (n = n_empty + 1 then): the two
+               choices are the two leading digits of w in the mixed radix (n, n - 1).  The definition does not look back,
+               so a ply can be computed from (seed, game, step counter, board) alone. */
+            uint32_t ctr[4] = { g, tc >> 3, 0u, ORC_TAG_TTT }, rnd[4];
             orc_philox4x32(ctr, key, rnd);
-            int action = n_empty ? nth_set_bit(empty, (int)mulhi32(rnd[tc & 3u], (uint32_t)n_empty)) : -1;
+            uint32_t word = rnd[(tc >> 1) & 3u];
+            if (tc & 1u) word *= (uint32_t)(n_empty + 1);
+            int action = n_empty ? nth_set_bit(empty, (int)mulhi32(word, (uint32_t)n_empty)) : -1;
             tc += 1;
             int r, term, ws;
             ttt_step_env(n_cells, P, n_lines, lines, o, &w, &tm, action, &r, &term, &ws);

@@ -58,8 +58,12 @@ def test_rollout_equals_stepwise():
         for e in range(B):
             cells = [c for c in range(15) if (int(valid[e]) >> c) & 1]
             if cells:
-                w = O.philox4x32([first + e, t >> 2, 0, O.TAG_TTT], [seed, 0])
-                act[e] = cells[(int(w[t & 3]) * len(cells)) >> 32]
+                # one Philox call per 8 plies, one word per 2: the odd ply reads what the even ply's extraction left over
+                w = O.philox4x32([first + e, t >> 3, 0, O.TAG_TTT], [seed, 0])
+                word = int(w[(t >> 1) & 3])
+                if t & 1:
+                    word = (word * (len(cells) + 1)) & 0xffffffff
+                act[e] = cells[(word * len(cells)) >> 32]
         r, term, win = b.step(act, auto_reset=True)
         ts += 1
         tm = term.astype(bool)
