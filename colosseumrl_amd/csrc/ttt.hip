@@ -113,6 +113,35 @@ __device__ __forceinline__ int nth_set_bit(const uint32_t m, int r)
     return (int)pos;
 }
 
+// The same search with its last three levels out of a table: [byte][rank] = position of the rank-th set bit of the byte,
+// 2 KB of LDS filled by the 256 threads of the workgroup (ttt_fill_rank_table; the caller puts a __syncthreads behind it).
+// Two levels by arithmetic find the byte, one LDS read the bit in it: 15 vector instructions + 1 LDS read where the
+// five-level search takes 26 (in the rollout's ply, where this chain is a third of the instructions).
+__device__ __forceinline__ void ttt_fill_rank_table(uint8_t (&tab)[256 * 8])
+{
+    const uint32_t t = threadIdx.x & 255u;
+    uint32_t lo = 0, hi = 0, n = 0;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 8; ++bit) {
+        const bool set = (t >> bit) & 1u;
+        const uint32_t v = set ? bit << ((n & 3u) * 8u) : 0u;
+        lo |= (n < 4u) ? v : 0u;
+        hi |= (n < 4u) ? 0u : v;
+        n += set ? 1u : 0u;
+    }
+    *reinterpret_cast<uint2 *>(&tab[t * 8]) = make_uint2(lo, hi);
+}
+
+// SMALL: the board has at most 16 cells (3x3, 3x5): the first level falls away.
+template <bool SMALL = false>
+__device__ __forceinline__ uint32_t nth_set_bit_tab(const uint8_t (&tab)[256 * 8], const uint32_t m, const uint32_t r)
+{
+    uint32_t rr = r, pos = 0, c;
+    if (!SMALL) { c = (uint32_t)__popc(m & 0xffffu);                pos = (rr >= c) ? 16u : 0u;          rr = min(rr, rr - c); }
+    c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 8u));        pos = (rr >= c) ? pos + 8u : pos;    rr = min(rr, rr - c);
+    return pos + tab[__builtin_amdgcn_ubfe(m, pos, 8u) * 8u + rr];
+}
+
 // the random agent's 32-bit draw for the ply at step counter c of game g with n_empty empty cells (the RNG contract of
 // ttt_rollout_kernel, stated there): the ply picks empty cell number hi32(draw * n_empty)
 __device__ __forceinline__ uint32_t ttt_agent_word(const uint32_t g, const uint32_t c, const int n_empty, const uint32_t seed_lo,
@@ -158,6 +187,11 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
                    int8_t *__restrict__ winner, int8_t *__restrict__ to_move, const crl_ttt_stats st)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef TTT_NO_RANK_TABLE
+    __shared__ uint8_t rank_tab[256 * 8];
+    ttt_fill_rank_table(rank_tab);
+    __syncthreads();
+#endif
     if (b >= B) return;
     uint32_t o[P], wins[P];
 #pragma unroll
@@ -229,11 +263,16 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         acc = 0;
     };
     auto ply_running = [&](auto k_tag, const uint32_t w, const uint32_t odd, const int t_after) {   // k_tag: K as a compile-time constant (0: read it from dd)
-        constexpr int KC = decltype(k_tag)::value;
+        constexpr int KC = decltype(k_tag)::value & 7;            // k_tag: K (0: read it from dd) | 8 for boards of <= 16 cells
+        constexpr bool SMALL = (decltype(k_tag)::value & 8) != 0;
         const uint32_t empty = dd.full & ~all_run;              // (not 0: the game is running)
         const uint32_t n_empty = (uint32_t)__popc(empty);
         const uint32_t word = odd ? w * (n_empty + 1u) : w;     // (odd is a constant in the unrolled trips)
+#ifndef TTT_NO_RANK_TABLE
+        const uint32_t bit = 1u << nth_set_bit_tab<SMALL>(rank_tab, empty, __umulhi(word, n_empty));
+#else
         const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, n_empty));
+#endif
         const uint32_t mine = r[0] | bit;                                              // :295
         const bool won = ttt_has_line<ND, KC>(dd, mine);                               // :296-300
         all_run |= bit;
@@ -325,7 +364,8 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         }
         flush();
     };
-    if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
+    if (dd.K == 3 && dd.n_cells <= 16) run_plies(std::integral_constant<int, 3 | 8>{});    // 3x3, 3x5 (the reference's 2p / 3p boards)
+    else if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
     else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
     else run_plies(std::integral_constant<int, 0>{});
     // back out of the rotating order, and the bookkeeping the running plies left implicit
