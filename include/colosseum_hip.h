@@ -265,8 +265,12 @@ typedef struct {
     uint32_t *len_sum;     /* [B] */
     int32_t  *results;     /* [B][3+P] or NULL: packed row n_episodes, len_sum, draw_count, win_count[P] (as crl_tron_stats) */
 } crl_ttt_stats;
-/* random agent, one Philox call per 4 steps: with c = tcount,
- *   r = mulhi32(Philox(ctr={g, c >> 2, 0, 0x54540000}, seed)[c & 3], n_empty); r-th empty cell in row-major order */
+/* random agent, one Philox call per 8 plies, one 32-bit word per 2: with c = tcount and n = the number of empty cells,
+ *   w = Philox(ctr={g, c >> 3, 0, 0x54540000}, seed)[(c >> 1) & 3]
+ *   draw = w when c is even, lo32(w * (n + 1)) when c is odd  (what the even ply's extraction hi32(w * (n + 1)) left over,
+ *          when that ply was the one before in the same game: the two choices are w's leading digits in the mixed radix
+ *          (n + 1, n); the definition does not look back, any ply follows from (seed, g, c, board) alone)
+ *   r = mulhi32(draw, n); the ply marks the r-th empty cell in row-major order */
 int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, int T,
                     uint32_t *occ, int8_t *winner, int8_t *to_move, crl_ttt_stats stats, void *stream);
 
@@ -284,7 +288,7 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 #define CRL_BLOKUS_MASK_WORDS 10500
 int crl_blokus_create(crl_ctx **out);
 /* The random agent of crl_ttt_rollout as a stand-alone call: action[b] = the r-th empty cell (flat index, row-major
- * np.where order) with r = mulhi32(Philox(...)[tcount & 3], number of empty cells), -1 on a full board; advance != 0
+ * np.where order) with r as crl_ttt_rollout's RNG contract defines it for step counter tcount[b], -1 on a full board; advance != 0
  * also increments tcount.  T x (crl_ttt_sample; crl_ttt_step with CRL_STEP_AUTO_RESET) == crl_ttt_rollout(T). */
 int crl_ttt_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id, const uint32_t *occ,
                    uint32_t *tcount, int advance, int8_t *action, void *stream);
