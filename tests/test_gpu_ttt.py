@@ -61,6 +61,16 @@ def test_rollout_vs_oracle(dims, K, P, B, chunks):
     assert torch.equal(tb.results(), tb.results_from_columns())      # the row the kernel packs == the column statistics
 
 
+@pytest.mark.parametrize("dims,K,P,B,chunks", [((3, 3), 3, 2, 1500, (600, 1003, 5)), ((3, 3, 3), 3, 4, 700, (1024, 8)),
+                                                ((4, 8), 4, 5, 600, (520, 3, 253)), ((2, 4, 4), 3, 8, 500, (504, 77, 300)),
+                                                ((2, 3), 2, 1, 300, (250, 250)), ((4, 4), 3, 7, 300, (999,))])
+def test_rollout_long_launches_every_player_count(dims, K, P, B, chunks):
+    """The rollout kernel counts outcomes in byte fields that it flushes every 248 plies (32-bit fields up to 3 players, 64-bit
+    up to 7, 8 players without a draw field) and draws one Philox block per 8 plies: launches long enough to cross several
+    flushes, lengths that leave the step counter off a multiple of 8, and every accumulator variant -- against the oracle."""
+    test_rollout_vs_oracle(dims, K, P, B, chunks)
+
+
 @pytest.mark.parametrize("dims,K,P,B", [((3, 3), 3, 2, 3000), ((3, 5), 3, 3, 1000 + 7), ((2, 2, 2), 2, 4, 300)])
 def test_rollout_from_finished_states_that_were_not_restarted(dims, K, P, B):
     """A rollout may come in on states the step API left FINISHED (stepped without auto-reset: sticky winner, full board)
