@@ -47,6 +47,7 @@ void crl_destroy(crl_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->ttt_lines_dev) (void)hipFree(ctx->ttt_lines_dev);
+    if (ctx->ttt_win_dev) (void)hipFree(ctx->ttt_win_dev);
     if (ctx->blokus) crl_blokus_free(ctx->blokus);
     delete ctx;
 }

@@ -36,6 +36,8 @@ struct crl_ctx {
     ttt_dirs ttt_dd;
     uint32_t ttt_lines_host[CRL_TTT_MAX_LINES];
     uint32_t *ttt_lines_dev;   // DEVICE copy of the win-line table
+    uint32_t *ttt_win_dev;     // boards of <= 16 cells: DEVICE bit table, bit m = "the mask m holds a K-line" (8 KB), or NULL
+    int ttt_win_device;        // the device that table lives on
     void *blokus;              // blokus tables (blokus.hip)
 };
 

@@ -15,6 +15,7 @@
 // wave-uniform kernel arguments (SGPRs) -- no table traffic at all.
 #include "crl_common.hpp"
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -180,18 +181,25 @@ ttt_step_kernel(const ttt_dirs dd, const int64_t B, uint32_t *__restrict__ occ, 
     to_move[b] = (int8_t)tm;
 }
 
-template <int P, int ND>
+// WT: the board has at most 16 cells and win_tab is its table of winning masks (crl_ttt_create); ND = 4 then
+template <int P, int ND, bool WT = false>
 __global__ void __launch_bounds__(256)
 ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, const uint32_t seed_hi,
                    const uint64_t first_env_id, const int T, uint32_t *__restrict__ occ,
-                   int8_t *__restrict__ winner, int8_t *__restrict__ to_move, const crl_ttt_stats st)
+                   int8_t *__restrict__ winner, int8_t *__restrict__ to_move, const crl_ttt_stats st,
+                   const uint32_t *__restrict__ win_tab)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-#ifndef TTT_NO_RANK_TABLE
     __shared__ uint8_t rank_tab[256 * 8];
+    __shared__ uint32_t win_bits[WT ? 2048 : 1];             // boards of <= 16 cells: bit m = the mask m holds a K-line
     ttt_fill_rank_table(rank_tab);
+    if (WT) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(win_tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(win_bits);
+        dst[threadIdx.x] = src[threadIdx.x];
+        dst[threadIdx.x + 256] = src[threadIdx.x + 256];
+    }
     __syncthreads();
-#endif
     if (b >= B) return;
     uint32_t o[P], wins[P];
 #pragma unroll
@@ -264,17 +272,16 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
     };
     auto ply_running = [&](auto k_tag, const uint32_t w, const uint32_t odd, const int t_after) {   // k_tag: K as a compile-time constant (0: read it from dd)
         constexpr int KC = decltype(k_tag)::value & 7;            // k_tag: K (0: read it from dd) | 8 for boards of <= 16 cells
-        constexpr bool SMALL = (decltype(k_tag)::value & 8) != 0;
+        constexpr bool SMALL = (decltype(k_tag)::value & 8) != 0;  //        | 16: ... whose win test is a table lookup
+        constexpr bool TABLE = WT && (decltype(k_tag)::value & 16) != 0;
         const uint32_t empty = dd.full & ~all_run;              // (not 0: the game is running)
         const uint32_t n_empty = (uint32_t)__popc(empty);
         const uint32_t word = odd ? w * (n_empty + 1u) : w;     // (odd is a constant in the unrolled trips)
-#ifndef TTT_NO_RANK_TABLE
         const uint32_t bit = 1u << nth_set_bit_tab<SMALL>(rank_tab, empty, __umulhi(word, n_empty));
-#else
-        const uint32_t bit = 1u << nth_set_bit(empty, (int)__umulhi(word, n_empty));
-#endif
         const uint32_t mine = r[0] | bit;                                              // :295
-        const bool won = ttt_has_line<ND, KC>(dd, mine);                               // :296-300
+        bool won;                                                                      // :296-300
+        if constexpr (TABLE) won = ((win_bits[mine >> 5] >> (mine & 31u)) & 1u) != 0u;
+        else won = ttt_has_line<ND, KC>(dd, mine);
         all_run |= bit;
         const bool term = won | (all_run == dd.full);                                  // :302-311
 #pragma unroll
@@ -364,10 +371,14 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         }
         flush();
     };
-    if (dd.K == 3 && dd.n_cells <= 16) run_plies(std::integral_constant<int, 3 | 8>{});    // 3x3, 3x5 (the reference's 2p / 3p boards)
-    else if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
-    else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
-    else run_plies(std::integral_constant<int, 0>{});
+    if constexpr (WT) {
+        run_plies(std::integral_constant<int, 8 | 16>{});        // 3x3, 3x5 (the reference's 2p / 3p boards), 4x4, ...
+    } else {
+        if (dd.K == 3 && dd.n_cells <= 16) run_plies(std::integral_constant<int, 3 | 8>{});
+        else if (dd.K == 3) run_plies(std::integral_constant<int, 3>{});
+        else if (dd.K == 4) run_plies(std::integral_constant<int, 4>{});
+        else run_plies(std::integral_constant<int, 0>{});
+    }
     // back out of the rotating order, and the bookkeeping the running plies left implicit
     {
         tm = tm8 >> 3;
@@ -733,6 +744,27 @@ int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out)
     }
     c->ttt.n_lines = n_lines;
     c->ttt_dd = dd;
+    // Boards of at most 16 cells (the reference's 3x3 and 3x5 among them): "does this mask hold a K-line" for all 65,536
+    // masks as a bit table on the device, which crl_ttt_rollout stages into LDS -- one LDS read and four vector
+    // instructions per ply instead of the four-direction shift-and test.  Optional: without it (no device at create
+    // time, or a rollout on another device) the rollout computes the test as everywhere else.
+    if (c->ttt.n_cells <= 16) {
+        std::vector<uint32_t> tab(2048, 0u);
+        for (uint32_t m = 0; m < 65536u; ++m)
+            for (int i = 0; i < n_lines; ++i)
+                if ((m & c->ttt_lines_host[i]) == c->ttt_lines_host[i]) { tab[m >> 5] |= 1u << (m & 31u); break; }
+        int dev = -1;
+        void *d = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipMalloc(&d, tab.size() * sizeof(uint32_t)) == hipSuccess) {
+            if (hipMemcpy(d, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess) {
+                c->ttt_win_dev = (uint32_t *)d;
+                c->ttt_win_device = dev;
+            } else {
+                (void)hipFree(d);
+            }
+        }
+        (void)hipGetLastError();                           // (a failure here is not an error of the call)
+    }
     *out = c;
     return CRL_OK;
 }
@@ -886,13 +918,21 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_ttt_rollout: T=%d out of range", T);
     if (T == 0) return CRL_OK;
     const ttt_dirs dd = dirs_of(ctx);
+    const uint32_t *win_tab = nullptr;                      // the <= 16-cell win table, when it lives on this device
+    if (ctx->ttt_win_dev) {
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev == ctx->ttt_win_device) win_tab = ctx->ttt_win_dev;
+    }
     TTT_DISPATCH_P(ctx->ttt.P, {
-        if (dd.n_dirs <= 4)
+        if (dd.n_dirs <= 4 && dd.n_cells <= 16 && win_tab != nullptr)
+            hipLaunchKernelGGL((ttt_rollout_kernel<PP, 4, true>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st, win_tab);
+        else if (dd.n_dirs <= 4)
             hipLaunchKernelGGL((ttt_rollout_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st, win_tab);
         else
             hipLaunchKernelGGL((ttt_rollout_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st);
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, T, occ, winner, to_move, st, win_tab);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;
