@@ -34,6 +34,7 @@ namespace {
 constexpr int BN = 20;
 constexpr int NPIECE = 21;
 constexpr int NSHAPE = NPIECE * 8;
+constexpr int NDISTINCT = 91;                             // distinct oriented shapes over all 21 pieces (build_distinct checks)
 constexpr uint32_t ROWMASK = (1u << BN) - 1u;
 constexpr int ACTION_IDS = NPIECE * 400 * 8 * 5;          // 336,000 dense ids
 constexpr int MASK_WORDS = ACTION_IDS / 32;               // 10,500
@@ -134,11 +135,17 @@ void build_tables(BlkTables &t)
     }
 }
 
-// rows per shift of the pre-shifted table of the count pass: 28 are used; the stride decides which (shift, row) pairs
-// of a shape x row loop share an LDS bank (28 / 29 / 30 / 31 / 33 tried with tools/lib_variant.sh + lib_ab.py: 28 is the fastest)
+// rows per shift of the pre-shifted table of the count pass: 28 are used (board rows -4..23; only 0..19 are not zero); the
+// stride decides which (shift, row) pairs of a shape x row loop share an LDS bank (28 / 29 / 30 / 31 / 33 tried with
+// tools/lib_variant.sh + lib_ab.py: 28 is the fastest; 31 costs 12 %).
+// A shape that shares its origin rows out over two or four lanes runs every lane for the same number of rows (scalar loop
+// control), so the last lane overshoots the row range by up to three rows and reads table rows 28..30: with this stride those
+// ARE rows 0..2 of the next shift -- board rows -4..-2, zero like the rows they stand for -- and behind the last shift the
+// first rows of `pad9`, {all ones, 0}: "no constraint, no anchor".  Nothing is counted on such rows (blk_shape_count).
 #ifndef BLK_SH_ROWS
 #define BLK_SH_ROWS 28
 #endif
+constexpr int BLK_PAD_ROWS = 31;         // rows of `pad9`: origin rows up to 22 + row offsets up to 8
 
 // per-wave working set in LDS
 struct WaveLds {
@@ -152,10 +159,13 @@ struct WaveLds {
         uint2 sh[9][BLK_SH_ROWS];   // the player being counted: sh[s][r] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell;
                                     // rows 0..27 are used, the row count sets the LDS bank offset between shifts
     } u;
-    uint2 pad9[28];          // {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh`
+    uint2 pad9[BLK_PAD_ROWS];// {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh` (directly behind `u`)
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
     uint8_t items[NSHAPE];   // work list of a count / existence pass: indices into BlkTables::distinct
 };
+
+static_assert(sizeof(((WaveLds *)nullptr)->u) == sizeof(uint2) * 9 * BLK_SH_ROWS && offsetof(WaveLds, pad9) == offsetof(WaveLds, u) + sizeof(uint2) * 9 * BLK_SH_ROWS,
+              "the rows behind the last shift of the pre-shifted table must be the first rows of pad9");
 
 // the `distinct` / `first` part of the tables (needs the layout of WaveLds)
 void build_distinct(BlkTables &t)
@@ -294,13 +304,20 @@ __device__ __forceinline__ DistinctRegs blk_load_distinct(const BlkTables &T, co
     return DistinctRegs{raw.x, raw.y, raw.z};
 }
 
+// Origin rows ya .. ya + n - 1: `ya` may differ from lane to lane (lanes that share a shape take a part of its rows each),
+// `n` is wave-uniform -- the loop is controlled on the scalar unit.  Rows behind the range proper (at most three, and at
+// most up to board row 22) count nothing: behind the last board row the origin cell itself lies on a zero row of the
+// table (table rows 24..26 of its shift), and behind a range that ends four rows past the last anchor row no cell of a
+// shape can reach an anchor -- whatever a cell reads from the rows 28..30 that alias the next shift (see BLK_SH_ROWS).
+// (Round 2 / early round 3 gave such lanes their own first and last row: a loop with per-lane bounds, exec-masked and
+//  without the four-rows-per-trip form -- the lanes of a split batch then cost ~1.6x a full batch's per row.)
 template <bool ANY_ONLY>
 __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const DistinctRegs &e, const bool active,
-                                                    const int y0, const int y1)
+                                                    const int ya, const int n)
 {
-    // per cell: the table row of origin row 0 (cell j at column offset dx + 4, row offset dy + 4); slots beyond the shape's
+    // per cell: the table row of origin row ya (cell j at column offset dx + 4, row offset dy + 4); slots beyond the shape's
     // cells read {all ones, 0}: no constraint on the fit, no anchor -- the five addresses come ready-made out of the table
-    const char *base = reinterpret_cast<const char *>(&L);
+    const char *base = reinterpret_cast<const char *>(&L) + ya * (int)sizeof(uint2);
     const uint2 *cellrow[5] = {reinterpret_cast<const uint2 *>(base + (e.o01 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o01 >> 16)),
                                reinterpret_cast<const uint2 *>(base + (e.o23 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o23 >> 16)),
                                reinterpret_cast<const uint2 *>(base + (e.o4mp & 0xffffu))};
@@ -320,7 +337,7 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
 #endif
     if (ANY_ONLY) {
 #pragma nounroll
-        for (int y = y0; y <= y1; ++y) {
+        for (int y = 0; y < n; ++y) {
             one_row(y);
             if (__ballot(active && cnt > 0)) break;
         }
@@ -329,14 +346,14 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
         // the LDS reads, so the five table pointers move once per trip instead of once per row (5 of a row's 17 VALU) and the
         // loop control is shared.  (Two register sets with the next row's reads in flight behind the current row's
         // counting -- a software pipeline -- were 7 % SLOWER: 64 VGPRs, and the eight waves of a SIMD hide the latency.)
-        int y = y0;
+        int y = 0;
 #pragma nounroll
-        for (; y + BLK_COUNT_UNROLL - 1 <= y1; y += BLK_COUNT_UNROLL) {
+        for (; y + BLK_COUNT_UNROLL - 1 < n; y += BLK_COUNT_UNROLL) {
 #pragma unroll
             for (int u = 0; u < BLK_COUNT_UNROLL; ++u) one_row(y + u);
         }
 #pragma nounroll
-        for (; y <= y1; ++y) one_row(y);
+        for (; y < n; ++y) one_row(y);
     }
     return active ? cnt : 0u;
 }
@@ -352,20 +369,23 @@ __device__ __forceinline__ void blk_row_range(const WaveLds &L, const int q, con
     y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4;
 }
 
-// work list of the distinct oriented shapes of the pieces in `inv` (piece-major); returns its length
+// work list of the distinct oriented shapes of the pieces in `inv` (piece-major); returns its length.  One lane per distinct
+// shape (91: lanes 0..63, then 0..26): a shape whose piece is held finds its place in the list by counting the held shapes
+// before it -- two ballots and v_mbcnt, no scan -- and stores its index there, one byte store per lane.  (Round 2 / early
+// round 3: one lane per PIECE, a wave scan of the pieces' shape counts and a loop of up to eight byte stores per lane; with
+// the wave barrier behind it, 17 % of a ply together with the pre-shifted table.)  No barrier here: blk_build_shifted,
+// which every caller runs next, ends with one.
 __device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, const uint32_t inv, const int lane)
 {
-    const bool held = lane < NPIECE && ((inv >> lane) & 1u);
-    const uint32_t nu = held ? T.nuniq[lane] : 0u;
-    const uint32_t incl = wave_scan_incl(nu, lane);
-    const int pos = (int)(incl - nu);
-    // plain byte stores, one per distinct orientation (<= 8 trips): left to itself the compiler vectorises this into
-    // 16-byte stores fed by a register-resident {0..7} table that it then SPILLS to scratch in the rollout kernel
-    const uint32_t d0 = lane < NPIECE ? T.first[lane] : 0u;
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (uint32_t k = 0; k < nu; ++k) L.items[pos + (int)k] = (uint8_t)(d0 + k);   // index into T.distinct
-    wave_sync();
-    return __builtin_amdgcn_readlane((int)incl, NPIECE - 1);
+    const uint32_t pa = T.distinct[lane].piece, pb = T.distinct[lane < NDISTINCT - 64 ? 64 + lane : 0].piece;
+    const bool ha = (inv >> pa) & 1u, hb = lane < NDISTINCT - 64 && ((inv >> pb) & 1u);
+    const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
+    const uint32_t na = (uint32_t)__builtin_popcountll(ma);
+    const uint32_t ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+    const uint32_t rb = __builtin_amdgcn_mbcnt_lo((uint32_t)mb, na);          // (lanes 0..26 only: the low word)
+    if (ha) L.items[ra] = (uint8_t)lane;                                        // index into T.distinct
+    if (hb) L.items[rb] = (uint8_t)(64 + lane);
+    return (int)(na + (uint32_t)__builtin_popcountll(mb));
 }
 
 // does player q have any legal action with inventory inv? (board.py:170-193 non-empty)
@@ -381,7 +401,7 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
         const int i = base + lane;
         const bool active = i < items;
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
-        const uint32_t c = blk_shape_count<true>(L, e, active, y0, y1);
+        const uint32_t c = blk_shape_count<true>(L, e, active, y0, y1 - y0 + 1);
         if (__ballot(c > 0)) return true;
     }
     return false;
@@ -389,8 +409,17 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
 
 // legal-action count per piece of player q into L.pcnt[], returns the total (valid_actions length)
 // *piece_incl (lane p: the inclusive prefix of the per-piece counts up to piece p) is what level 1 of blk_select needs
+#ifdef BLK_STAMPS
+#define BLK_COUNT_STAMP(slot) do { if (stamp_acc_p) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc_p[slot] += now_ - *stamp_prev_p; *stamp_prev_p = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define BLK_COUNT_STAMP(slot) do { } while (0)
+#endif
 __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
-                                              uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr)
+                                              uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr
+#ifdef BLK_STAMPS
+                                              , unsigned long long *stamp_acc_p = nullptr, unsigned long long *stamp_prev_p = nullptr
+#endif
+                                              )
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
@@ -398,24 +427,25 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
     const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
     blk_build_shifted(L, q, lane);
-    // 64 lanes per batch of shapes.  A batch with at most 32 (16) shapes left gives each shape two (four) lanes, each with
+    BLK_COUNT_STAMP(7);                                   // diagnostic builds: work list + pre-shifted table
+    // 64 lanes per batch of shapes.  A batch with at most 48 (16) shapes left gives each of up to 32 (16) shapes two (four) lanes, each with
     // its share of the origin rows -- the counts meet in pcnt[] anyway: the second batch of an early-game inventory (91
     // shapes: 64 + 27) and the only batch of a late one then take half or a quarter of the row loop.
     const int n_rows = y1 - y0 + 1;
     for (int base = 0; base < items; ) {
         const int left = items - base;
-        const int split_log = left <= 16 ? 2 : (left <= 32 ? 1 : 0);         // wave-uniform
+        // (33..48 left: 32 of them at two lanes each, the rest at four in the next batch -- three quarters of a full batch's rows)
+        const int split_log = left <= 16 ? 2 : (left <= 48 ? 1 : 0);         // wave-uniform
         const int i = base + (lane >> split_log), part = lane & ((1 << split_log) - 1);
-        const int share = (n_rows + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up
-        const int ya = y0 + part * share, yb = min(ya + share - 1, y1);
+        const int share = (n_rows + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up: the last part
+        const int ya = y0 + part * share;                                     // overshoots y1 by up to three rows
         const bool active = i < items;
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
-        // (a full batch keeps the wave-uniform row range: scalar loop control)
-        const uint32_t c = (split_log == 0 ? blk_shape_count<false>(L, e, active, y0, y1)
-                                           : blk_shape_count<false>(L, e, active, ya, yb)) * ((e.o4mp >> 16) & 0xffu);
+        const uint32_t c = blk_shape_count<false>(L, e, active, ya, share) * ((e.o4mp >> 16) & 0xffu);
         if (c) atomicAdd(&L.pcnt[e.o4mp >> 24], c);
         base += 64 >> split_log;
     }
+    BLK_COUNT_STAMP(6);                                   // ... the shape x row batches
     wave_sync();
     const uint32_t mine = lane < 32 ? L.pcnt[lane] : 0u;
     const uint32_t total = wave_scan_incl(mine, lane);
@@ -670,7 +700,7 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
     WaveLds &L = Lw[wave_];                                                                       \
     /* rows -4..-1 and 20..27 of the padded ac[] rows are zero for the whole launch (only 0..19 are rewritten) */     \
     for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);            \
-    for (int i = lane; i < 28; i += 64) L.pad9[i] = make_uint2(0xffffffffu, 0u);                  \
+    for (int i = lane; i < BLK_PAD_ROWS; i += 64) L.pad9[i] = make_uint2(0xffffffffu, 0u);        \
     const int64_t b = (int64_t)blockIdx.x * 4 + wave_;                                            \
     if (b >= B) return;
 
@@ -964,7 +994,11 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BLK_STAMP(1);
         const uint32_t ip = (uint32_t)__builtin_amdgcn_readlane((int)vinv, pl);
         uint32_t piece_incl = 0u, piece_cnt = 0u;
+#ifdef BLK_STAMPS
+        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt, stamp_acc, &stamp_prev);
+#else
         const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt);   // len(valid_actions) of the mover
+#endif
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
         // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lanes 4k .. 4k+3
@@ -1333,6 +1367,11 @@ int crl_blokus_create(crl_ctx **out)
     BlkTables host;
     build_tables(host);
     build_distinct(host);
+    {
+        int nd = 0;
+        for (int p = 0; p < NPIECE; ++p) nd += host.nuniq[p];
+        CRL_REQUIRE(nd == NDISTINCT, "crl_blokus_create: %d distinct oriented shapes, expected %d", nd, NDISTINCT);
+    }
     void *dev = nullptr;
     CRL_HIP(hipMalloc(&dev, sizeof(BlkTables)));
     hipError_t e = hipMemcpy(dev, &host, sizeof(BlkTables), hipMemcpyHostToDevice);
