@@ -414,20 +414,15 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
 #else
 #define BLK_COUNT_STAMP(slot) do { } while (0)
 #endif
-__device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
-                                              uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr
+// the shape x row batches of a count pass and the per-piece totals; the work list (`items` entries), the pre-shifted table
+// of player q, the cleared pcnt[] and the wave barrier behind them are the caller's (blk_count, or blk_prologue in the rollout)
+__device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLds &L, const int lane, const int items, const int y0, const int y1,
+                                                      uint32_t *piece_incl, uint32_t *piece_cnt
 #ifdef BLK_STAMPS
-                                              , unsigned long long *stamp_acc_p = nullptr, unsigned long long *stamp_prev_p = nullptr
+                                                      , unsigned long long *stamp_acc_p = nullptr, unsigned long long *stamp_prev_p = nullptr
 #endif
-                                              )
+                                                      )
 {
-    int y0, y1;
-    blk_row_range(L, q, lane, y0, y1);
-    if (lane < 32) L.pcnt[lane] = 0;
-    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
-    const int items = blk_build_items(T, L, inv, lane);   // also orders the pcnt clear before the atomics
-    blk_build_shifted(L, q, lane);
-    BLK_COUNT_STAMP(7);                                   // diagnostic builds: work list + pre-shifted table
     // 64 lanes per batch of shapes.  A batch with at most 48 (16) shapes left gives each of up to 32 (16) shapes two (four) lanes, each with
     // its share of the origin rows -- the counts meet in pcnt[] anyway: the second batch of an early-game inventory (91
     // shapes: 64 + 27) and the only batch of a late one then take half or a quarter of the row loop.
@@ -452,6 +447,61 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     if (piece_incl) *piece_incl = total;
     if (piece_cnt) *piece_cnt = mine;
     return (uint32_t)__builtin_amdgcn_readlane((int)total, 63);
+}
+
+__device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
+                                              uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr)
+{
+    int y0, y1;
+    blk_row_range(L, q, lane, y0, y1);
+    if (lane < 32) L.pcnt[lane] = 0;
+    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
+    const int items = blk_build_items(T, L, inv, lane);
+    blk_build_shifted(L, q, lane);                        // (its barrier also orders the pcnt clear and the work list)
+    return blk_count_batches(T, L, lane, items, y0, y1, piece_incl, piece_cnt);
+}
+
+// Everything a count pass of the ROLLOUT's mover needs, behind ONE wave barrier: player q's allowed / corner rows out of the
+// board (as blk_prep), straight from the registers into the pre-shifted table as well (as blk_build_shifted, without
+// reading the rows back), the rows that hold anchors as a ballot (as blk_row_range, without reading them back), the cleared
+// pcnt[] and the work list.  As separate steps (prep, barrier, row range, work list, table, barrier) the same work sat in
+// the dependent chain of every ply with three LDS round trips more.
+struct BlkPrologue { int items; uint32_t anchor_rows; };        // anchor_rows: bit y = board row y holds an anchor of q
+__device__ __forceinline__ BlkPrologue blk_prologue(const BlkTables &T, WaveLds &L, const int lane, const int round, const int q,
+                                                    const uint32_t inv)
+{
+    // lanes 0..27 and 32..59: table row r = lane & 31 = board row y = r - 4 (rows outside the board are zero); the low half
+    // writes shifts 0..4 and the rows themselves, the high half shifts 5..8
+    const int r = lane & 31, y = r - 4;
+    uint32_t allowed = 0u, corner = 0u;
+    if (y >= 0 && y < BN) {
+        const uint32_t any = L.occ[0][y] | L.occ[1][y] | L.occ[2][y] | L.occ[3][y];
+        const uint32_t own = L.occ[q][y];
+        const uint32_t up = y > 0 ? L.occ[q][y - 1] : 0u, dn = y < BN - 1 ? L.occ[q][y + 1] : 0u;
+        const uint32_t orth = up | dn | (own << 1) | (own >> 1);           // computation.py:89-119
+        allowed = ~any & ~orth & ROWMASK;                                 // computation.py:122-142
+        if (round == 0) {                                                // board.py:177-179, corners of board.py:50
+            const int cx = (q & 1) ? BN - 1 : 0, cy = (q & 2) ? BN - 1 : 0;
+            corner = (y == cy) ? (allowed & (1u << cx)) : 0u;
+        } else {                                                         // board.py:114-154
+            const uint32_t ud = up | dn;
+            corner = allowed & ((ud << 1) | (ud >> 1)) & ROWMASK;
+        }
+        if (lane < 32) L.ac[q][r] = make_uint2(allowed << 8, corner << 8);
+    }
+    const uint2 v = make_uint2(allowed << 8, corner << 8);
+    const int s0 = lane < 32 ? 0 : 5;
+    if (r < 28) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (s0 + k < 9) L.u.sh[s0 + k][r] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
+    }
+    BlkPrologue out;
+    out.anchor_rows = ((uint32_t)__ballot(lane < 32 && corner != 0u)) >> 4;
+    if (lane < 32) L.pcnt[lane] = 0;
+    out.items = blk_build_items(T, L, inv, lane);
+    wave_sync();
+    return out;
 }
 
 struct BlkMove { int piece, x, y, orient, shift; };
@@ -990,15 +1040,21 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
 #endif
     for (int t = 0; t < T_steps; ++t) {
         BLK_STAMP(0);
-        blk_prep(L, lane, round, pl);                            // the mover's rows; another player's only when the game may end
-        BLK_STAMP(1);
         const uint32_t ip = (uint32_t)__builtin_amdgcn_readlane((int)vinv, pl);
+        // the mover's rows (another player's only when the game may end), pre-shifted table and work list, one barrier
+        const BlkPrologue pro = blk_prologue(T, L, lane, round, pl, ip);
+        BLK_STAMP(1);
         uint32_t piece_incl = 0u, piece_cnt = 0u;
+        uint32_t total = 0u;                                     // len(valid_actions) of the mover
+        if (!((dead >> pl) & 1u) && pro.anchor_rows != 0u) {
+            const int lo = __builtin_ctz(pro.anchor_rows), hi = 31 - __builtin_clz(pro.anchor_rows);
+            const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4;      // as blk_row_range
 #ifdef BLK_STAMPS
-        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt, stamp_acc, &stamp_prev);
+            total = blk_count_batches(T, L, lane, pro.items, y0, y1, &piece_incl, &piece_cnt, stamp_acc, &stamp_prev);
 #else
-        const uint32_t total = ((dead >> pl) & 1u) ? 0u : blk_count(T, L, pl, ip, lane, &piece_incl, &piece_cnt);   // len(valid_actions) of the mover
+            total = blk_count_batches(T, L, lane, pro.items, y0, y1, &piece_incl, &piece_cnt);
 #endif
+        }
         if (total == 0 && round >= 1) dead |= 1u << pl;
         BLK_STAMP(2);
         // One Philox call serves 4 plies, and the calls of 16 plies are made TOGETHER on the vector unit: lanes 4k .. 4k+3
