@@ -74,10 +74,10 @@ struct BlkTables {
                                 // same cell set (symmetric pieces) yield the same NUMBER of legal actions, so the
                                 // count pass fits each distinct shape once and multiplies.
     // The 91 distinct oriented shapes as the count / existence passes want them (round 3): per cell the byte offset of its
-    // row 0 in the wave's pre-shifted table (WaveLds::u.sh[dx+4][dy+4], or the {all ones, 0} row WaveLds::pad9[4] for the
-    // slots behind the shape's cells) relative to the start of WaveLds, the multiplicity and the piece -- one 16-byte read
-    // per work item where round 2 went item -> uniq -> cells / ncell and then computed five addresses (~45 VALU per batch).
-    struct alignas(16) Distinct { uint16_t off[5]; uint8_t mult, piece; uint32_t unused; } distinct[92];
+    // row 0 in the wave's pre-shifted table (WaveLds::u.sh[dy+4][dx+4]) relative to the start of WaveLds -- the slots behind
+    // the shape's cells repeat cell 0, see blk_shape_count --, multiplicity | (cells - 1) << 4, and the piece: one 16-byte
+    // read per work item where round 2 went item -> uniq -> cells / ncell and then computed five addresses (~45 VALU per batch).
+    struct alignas(16) Distinct { uint16_t off[5]; uint8_t mult_n, piece; uint32_t unused; } distinct[92];
     uint8_t first[24];          // index of a piece's first distinct shape in `distinct`
 };
 
@@ -135,17 +135,16 @@ void build_tables(BlkTables &t)
     }
 }
 
-// rows per shift of the pre-shifted table of the count pass: 28 are used (board rows -4..23; only 0..19 are not zero); the
-// stride decides which (shift, row) pairs of a shape x row loop share an LDS bank (28 / 29 / 30 / 31 / 33 tried with
-// tools/lib_variant.sh + lib_ab.py: 28 is the fastest; 31 costs 12 %).
-// A shape that shares its origin rows out over two or four lanes runs every lane for the same number of rows (scalar loop
-// control), so the last lane overshoots the row range by up to three rows and reads table rows 28..30: with this stride those
-// ARE rows 0..2 of the next shift -- board rows -4..-2, zero like the rows they stand for -- and behind the last shift the
-// first rows of `pad9`, {all ones, 0}: "no constraint, no anchor".  Nothing is counted on such rows (blk_shape_count).
-#ifndef BLK_SH_ROWS
-#define BLK_SH_ROWS 28
-#endif
-constexpr int BLK_PAD_ROWS = 31;         // rows of `pad9`: origin rows up to 22 + row offsets up to 8
+// The pre-shifted table of the count pass: BLK_SH_ROWS rows (board rows -4 .. 26; only 0..19 are not zero) of 9 entries, one
+// per column offset a shape cell can have -- ROW-major since the second half of round 3.  Which (shift, row) pairs of a
+// shape x row loop share an LDS bank is what the layout decides, and the count pass is bound by the LDS array: modelled
+// on random inventories (the 64 lanes' five reads per origin row, `ds_read_b64` banking), shift-major with 28 rows per shift
+// -- the best of the shift-major strides, and what rounds 2 / 3 measured as fastest -- takes 1.39 LDS cycles per conflict-free
+// cycle, row-major with 9 entries per row 1.21 (10: 1.33, 11: 1.49, 12: 1.27).
+// Rows 28..30 stay zero for the whole launch: a shape that shares its origin rows out over two or four lanes runs every lane
+// for the same number of rows (scalar loop control), so the last lane overshoots the row range by up to three rows.
+constexpr int BLK_SH_ROWS = 31;
+constexpr int BLK_SH_ROW_BYTES = 9 * (int)sizeof(uint2);
 
 // per-wave working set in LDS
 struct WaveLds {
@@ -156,16 +155,12 @@ struct WaveLds {
             uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
             uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
         } sel;
-        uint2 sh[9][BLK_SH_ROWS];   // the player being counted: sh[s][r] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell;
+        uint2 sh[BLK_SH_ROWS][9];   // the player being counted: sh[r][s] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell;
                                     // rows 0..27 are used, the row count sets the LDS bank offset between shifts
     } u;
-    uint2 pad9[BLK_PAD_ROWS];// {all ones, 0}: what a shape's unused cell slots read instead of a row of `sh` (directly behind `u`)
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
     uint8_t items[NSHAPE];   // work list of a count / existence pass: indices into BlkTables::distinct
 };
-
-static_assert(sizeof(((WaveLds *)nullptr)->u) == sizeof(uint2) * 9 * BLK_SH_ROWS && offsetof(WaveLds, pad9) == offsetof(WaveLds, u) + sizeof(uint2) * 9 * BLK_SH_ROWS,
-              "the rows behind the last shift of the pre-shifted table must be the first rows of pad9");
 
 // the `distinct` / `first` part of the tables (needs the layout of WaveLds)
 void build_distinct(BlkTables &t)
@@ -178,11 +173,11 @@ void build_distinct(BlkTables &t)
             BlkTables::Distinct &e = t.distinct[d];
             for (int j = 0; j < 5; ++j) {
                 const int c = t.cells[p * 8 + o][j], sx = c & 15, ro = c >> 4;
-                const size_t off = j < t.ncell[p] ? offsetof(WaveLds, u) + (size_t)(sx * BLK_SH_ROWS + ro) * sizeof(uint2)
-                                                  : offsetof(WaveLds, pad9) + (size_t)ro * sizeof(uint2);
+                // (cells[][j] repeats cell 0 for j >= the piece's cell count: so do the table offsets)
+                const size_t off = offsetof(WaveLds, u) + (size_t)(ro * 9 + sx) * sizeof(uint2);
                 e.off[j] = (uint16_t)off;
             }
-            e.mult = (uint8_t)(t.uniq[p][k] >> 4);
+            e.mult_n = (uint8_t)((t.uniq[p][k] >> 4) | ((t.ncell[p] - 1) << 4));
             e.piece = (uint8_t)p;
         }
     }
@@ -286,7 +281,7 @@ __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const
         const uint2 v = L.ac[q][r];
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            if (s0 + k < 9) L.u.sh[s0 + k][r] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
+            if (s0 + k < 9) L.u.sh[r][s0 + k] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
     }
     wave_sync();
 }
@@ -296,7 +291,7 @@ __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const
 // (Tried in round 3: cell 0 of every shape is its origin, i.e. the same table row in all 64 lanes, so with wave-uniform
 //  rows it can come out of a register by v_readlane instead of out of the LDS -- four reads per row instead of five.
 //  7 % SLOWER: the pass is bound by instruction issue, not by the LDS, and a v_readlane with a scalar index stalls.)
-struct DistinctRegs { uint32_t o01, o23, o4mp; };    // BlkTables::Distinct as loaded: off[0..4], mult, piece
+struct DistinctRegs { uint32_t o01, o23, o4mp; };    // BlkTables::Distinct as loaded: off[0..4], mult | (cells - 1) << 4, piece
 
 __device__ __forceinline__ DistinctRegs blk_load_distinct(const BlkTables &T, const int d)
 {
@@ -306,31 +301,34 @@ __device__ __forceinline__ DistinctRegs blk_load_distinct(const BlkTables &T, co
 
 // Origin rows ya .. ya + n - 1: `ya` may differ from lane to lane (lanes that share a shape take a part of its rows each),
 // `n` is wave-uniform -- the loop is controlled on the scalar unit.  Rows behind the range proper (at most three, and at
-// most up to board row 22) count nothing: behind the last board row the origin cell itself lies on a zero row of the
-// table (table rows 24..26 of its shift), and behind a range that ends four rows past the last anchor row no cell of a
-// shape can reach an anchor -- whatever a cell reads from the rows 28..30 that alias the next shift (see BLK_SH_ROWS).
+// most up to board row 22, i.e. table row 30) count nothing: behind the last board row the origin cell itself lies on a
+// zero row of the table, and behind a range that ends four rows past the last anchor row no cell of a shape can reach an
+// anchor.
 // (Round 2 / early round 3 gave such lanes their own first and last row: a loop with per-lane bounds, exec-masked and
 //  without the four-rows-per-trip form -- the lanes of a split batch then cost ~1.6x a full batch's per row.)
+// A shape of fewer than five cells repeats its cell 0 in the slots behind: the fit is not changed by testing a cell twice,
+// and the anchor hits of cell 0, counted apart, come off the total once per repeat at the end (the slots used to read a
+// row of {all ones, 0} in a region of its own, which does not exist in a row-major table).
 template <bool ANY_ONLY>
 __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const DistinctRegs &e, const bool active,
                                                     const int ya, const int n)
 {
-    // per cell: the table row of origin row ya (cell j at column offset dx + 4, row offset dy + 4); slots beyond the shape's
-    // cells read {all ones, 0}: no constraint on the fit, no anchor -- the five addresses come ready-made out of the table
-    const char *base = reinterpret_cast<const char *>(&L) + ya * (int)sizeof(uint2);
-    const uint2 *cellrow[5] = {reinterpret_cast<const uint2 *>(base + (e.o01 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o01 >> 16)),
-                               reinterpret_cast<const uint2 *>(base + (e.o23 & 0xffffu)), reinterpret_cast<const uint2 *>(base + (e.o23 >> 16)),
-                               reinterpret_cast<const uint2 *>(base + (e.o4mp & 0xffffu))};
-    uint32_t cnt = 0;
+    // per cell: its table entry at origin row ya (row offset dy + 4, column offset dx + 4): the five addresses come
+    // ready-made out of the table; a row further on is 72 bytes further on
+    const char *base = reinterpret_cast<const char *>(&L) + ya * BLK_SH_ROW_BYTES;
+    const char *cellrow[5] = {base + (e.o01 & 0xffffu), base + (e.o01 >> 16), base + (e.o23 & 0xffffu), base + (e.o23 >> 16),
+                              base + (e.o4mp & 0xffffu)};
+    uint32_t cnt = 0, cnt0 = 0;                          // anchor hits of the slots 1..4 / of cell 0
     auto one_row = [&](const int y) {
         uint2 v[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) v[j] = cellrow[j][y];
+        for (int j = 0; j < 5; ++j) v[j] = *reinterpret_cast<const uint2 *>(cellrow[j] + y * BLK_SH_ROW_BYTES);
         const uint32_t F = v[0].x & v[1].x & v[2].x & v[3].x & v[4].x;   // bit x+4: the shape fits at origin (x, y)
         // bit x+4 of v[j].y: cell j of the shape at origin (x, y) is an anchor.  (v_bcnt_u32_b32 adds its second operand:
         // accumulate in the instruction itself; left to the compiler the five counts go through a tree of v_add3)
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt0) : "v"(F & v[0].y));
 #pragma unroll
-        for (int j = 0; j < 5; ++j) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & v[j].y));
+        for (int j = 1; j < 5; ++j) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt) : "v"(F & v[j].y));
     };
 #ifndef BLK_COUNT_UNROLL
 #define BLK_COUNT_UNROLL 4
@@ -339,7 +337,7 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
 #pragma nounroll
         for (int y = 0; y < n; ++y) {
             one_row(y);
-            if (__ballot(active && cnt > 0)) break;
+            if (__ballot(active && (cnt | cnt0) != 0u)) break;     // (any hit is a hit of a real cell)
         }
     } else {
         // BLK_COUNT_UNROLL rows per trip, one after the other through the same registers: the row offset is an immediate of
@@ -355,7 +353,10 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
 #pragma nounroll
         for (; y < n; ++y) one_row(y);
     }
-    return active ? cnt : 0u;
+    // slots 1..4 hold cells - 1 real cells and 5 - cells repeats of cell 0
+    const int cells = (int)((e.o4mp >> 20) & 7u) + 1;
+    const uint32_t total = cnt + cnt0 * (uint32_t)(cells - 4);
+    return active ? total : 0u;
 }
 
 // rows that can hold the origin of a shape touching an anchor of player q (wave-uniform)
@@ -436,7 +437,7 @@ __device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLd
         const int ya = y0 + part * share;                                     // overshoots y1 by up to three rows
         const bool active = i < items;
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
-        const uint32_t c = blk_shape_count<false>(L, e, active, ya, share) * ((e.o4mp >> 16) & 0xffu);
+        const uint32_t c = blk_shape_count<false>(L, e, active, ya, share) * ((e.o4mp >> 16) & 0xfu);
         if (c) atomicAdd(&L.pcnt[e.o4mp >> 24], c);
         base += 64 >> split_log;
     }
@@ -494,7 +495,7 @@ __device__ __forceinline__ BlkPrologue blk_prologue(const BlkTables &T, WaveLds 
     if (r < 28) {
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            if (s0 + k < 9) L.u.sh[s0 + k][r] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
+            if (s0 + k < 9) L.u.sh[r][s0 + k] = make_uint2(v.x >> (s0 + k), v.y >> (s0 + k));
     }
     BlkPrologue out;
     out.anchor_rows = ((uint32_t)__ballot(lane < 32 && corner != 0u)) >> 4;
@@ -750,7 +751,8 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
     WaveLds &L = Lw[wave_];                                                                       \
     /* rows -4..-1 and 20..27 of the padded ac[] rows are zero for the whole launch (only 0..19 are rewritten) */     \
     for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);            \
-    for (int i = lane; i < BLK_PAD_ROWS; i += 64) L.pad9[i] = make_uint2(0xffffffffu, 0u);        \
+    /* ... and so are rows 28..30 of the pre-shifted table (the count passes rewrite rows 0..27 only) */          \
+    for (int i = lane; i < 3 * 9; i += 64) L.u.sh[28 + i / 9][i % 9] = make_uint2(0u, 0u);        \
     const int64_t b = (int64_t)blockIdx.x * 4 + wave_;                                            \
     if (b >= B) return;
 
