@@ -1185,6 +1185,9 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const bool uni_wave = __builtin_amdgcn_ballot_w64(tc != (uint32_t)__builtin_amdgcn_readfirstlane((int)tc)) == 0ull;
     int sneg2 = __builtin_amdgcn_readfirstlane(neg2);
     uint32_t sdry2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dry2);
+#ifdef CRL_DIAG_STALE_PROBE
+    uint32_t stale_raw = 0;
+#endif
     auto one_step = [&](auto uni_tag) {
         constexpr bool UNI = decltype(uni_tag)::value;
         const bool run = a != 0;
@@ -1201,7 +1204,13 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
         const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
         uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+#ifdef CRL_DIAG_STALE_PROBE      /* diagnostic builds only (WRONG results): the step decides on the PREVIOUS step's probe word, so that the
+                                   probe's latency is hidden completely -- the upper bound of what a software-pipelined probe could buy */
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(stale_raw), "+v"(near) : : "memory");
+        { const uint32_t t_ = raw; raw = stale_raw; stale_raw = t_; }
+#else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw), "+v"(near) : : "memory");   // (near: the test runs while the probe is out)
+#endif
         // The common path, for every lane and without a branch: each player on its own (correct unless players interact).
         const uint32_t m = min(raw ^ tagbits, raw ^ 0xf8u);
         const bool dead = run & ((m - 1u) < 7u);                // :47-57

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""LDS bank-conflict model of the Blokus count pass (CPU only): for random inventories, the 64 lanes' five ds_read_b64 per origin
+row under candidate layouts of the pre-shifted table (shift-major strides, row-major widths, linear bank maps, pad handling);
+prints LDS cycles per conflict-free cycle.  Chose the row-major 9-wide table of round 3 (1.21 against 1.39)."""
+import itertools, random
+kPieces = [
+ [(0,0)],[(0,0),(1,0)],[(0,0),(1,0),(1,1)],[(0,0),(1,0),(2,0)],[(0,0),(1,0),(0,1),(1,1)],[(0,0),(1,-1),(1,0),(2,0)],
+ [(0,0),(1,0),(2,0),(3,0)],[(0,0),(1,0),(2,0),(2,-1)],[(0,0),(1,0),(1,-1),(2,-1)],[(0,0),(0,-1),(1,0),(2,0),(3,0)],
+ [(0,0),(0,-1),(0,1),(1,0),(2,0)],[(0,0),(0,-1),(0,-2),(1,-2),(2,-2)],[(0,0),(1,0),(1,-1),(2,-1),(3,-1)],
+ [(0,0),(0,1),(1,0),(2,0),(2,-1)],[(0,0),(1,0),(2,0),(3,0),(4,0)],[(0,0),(1,0),(2,0),(1,-1),(2,-1)],
+ [(0,0),(0,1),(1,0),(1,-1),(2,-1)],[(0,0),(1,0),(0,1),(0,2),(1,2)],[(0,0),(1,0),(1,-1),(1,1),(2,-1)],
+ [(0,0),(-1,0),(1,0),(0,-1),(0,1)],[(0,0),(1,0),(1,-1),(2,0),(3,0)]]
+def orient(o,dx,dy):
+    return [(dy,-dx),(dx,-dy),(dx,dy),(dy,dx),(-dy,dx),(-dx,dy),(-dx,-dy),(-dy,-dx)][o]
+shapes=[]  # list of (piece, cells[(s,ro)])
+for p,cells in enumerate(kPieces):
+    seen={}
+    for o in range(8):
+        oc=[orient(o,dx,dy) for dx,dy in cells]
+        mx=min(x for x,y in oc); my=min(y for x,y in oc)
+        key=tuple(sorted((x-mx,y-my) for x,y in oc))
+        if key in seen: continue
+        seen[key]=1
+        shapes.append((p,[(x+4,y+4) for x,y in oc]))
+print(len(shapes))
+def cycles(batch_lanes, R, layout):
+    # batch_lanes: list of 64 entries: (shape index or None, row offset extra)
+    tot=0; ideal=0
+    for j in range(5):
+        for g in range(2):
+            slots={}
+            for l in range(32*g,32*g+32):
+                it=batch_lanes[l]
+                if it is None: continue
+                sh,rowadd=it
+                cells=shapes[sh][1]
+                if j < len(cells):
+                    s,ro=cells[j]
+                    if layout=='sr': e=s*R+ro+rowadd
+                    else: e=(ro+rowadd)*R+s   # row-major with R shifts stride
+                    addr=('t',e)
+                    slot=e%32
+                else:
+                    ro=cells[0][1]
+                    e=PADBASE+ro+rowadd
+                    addr=('p',e); slot=e%32
+                slots.setdefault(slot,set()).add(addr)
+            if slots:
+                tot+=max(len(v) for v in slots.values()); ideal+=1
+    return tot,ideal
+random.seed(1)
+def sim(R, layout, trials=300):
+    T=0;I=0
+    for _ in range(trials):
+        # random inventory size
+        k=random.randint(3,21)
+        held=set(random.sample(range(21),k))
+        items=[i for i,(p,c) in enumerate(shapes) if p in held]
+        nrows=18
+        base=0
+        while base<len(items):
+            left=len(items)-base
+            sl=2 if left<=16 else (1 if left<=48 else 0)
+            share=(nrows+(1<<sl)-1)>>sl
+            lanes=[]
+            for l in range(64):
+                i=base+(l>>sl); part=l&((1<<sl)-1)
+                lanes.append((items[i],part*share) if i<len(items) else None)
+            t,i_=cycles(lanes,R,layout)
+            T+=t*share; I+=i_*share
+            base+=64>>sl
+    return T/I
+for R in (28,29,30,31,32,33,34,35,36,37,40):
+    PADBASE=9*R
+    print('sr',R,round(sim(R,'sr'),3))
+for R in (9,10,11,12,13,14,15,16,17):
+    PADBASE=31*R
+    print('rs',R,round(sim(R,'rs'),3))
+
+def cycles_f(batch_lanes, a, b, padslot):
+    tot=0; ideal=0
+    for j in range(5):
+        for g in range(2):
+            slots={}
+            for l in range(32*g,32*g+32):
+                it=batch_lanes[l]
+                if it is None: continue
+                sh,rowadd=it
+                cells=shapes[sh][1]
+                if j < len(cells):
+                    s,ro=cells[j]; r=ro+rowadd
+                    addr=('t',s,r); slot=(a*s+b*r)%32
+                else:
+                    ro=cells[0][1]; r=ro+rowadd
+                    addr=('p',r); slot=(padslot+r)%32
+                slots.setdefault(slot,set()).add(addr)
+            if slots:
+                tot+=max(len(v) for v in slots.values()); ideal+=1
+    return tot,ideal
+def simf(a,b,padslot=0,trials=120):
+    random.seed(1)
+    T=0;I=0
+    for _ in range(trials):
+        k=random.randint(3,21)
+        held=set(random.sample(range(21),k))
+        items=[i for i,(p,c) in enumerate(shapes) if p in held]
+        nrows=18; base=0
+        while base<len(items):
+            left=len(items)-base
+            sl=2 if left<=16 else (1 if left<=48 else 0)
+            share=(nrows+(1<<sl)-1)>>sl
+            lanes=[]
+            for l in range(64):
+                i=base+(l>>sl); part=l&((1<<sl)-1)
+                lanes.append((items[i],part*share) if i<len(items) else None)
+            t,i_=cycles_f(lanes,a,b,padslot)
+            T+=t*share; I+=i_*share
+            base+=64>>sl
+    return T/I
+res=[]
+for a in range(0,32):
+    for b in range(0,32):
+        res.append((simf(a,b),a,b))
+res.sort()
+print(res[:15])
+print([x for x in res if (x[1],x[2]) in ((28%32,1),(1,9))])
+
+print("--- row-major with an in-row pad column")
+def cycles_w(batch_lanes, W, padcol):
+    tot=0; ideal=0
+    for j in range(5):
+        for g in range(2):
+            slots={}
+            for l in range(32*g,32*g+32):
+                it=batch_lanes[l]
+                if it is None: continue
+                sh,rowadd=it
+                cells=shapes[sh][1]
+                if j < len(cells):
+                    s,ro=cells[j]; r=ro+rowadd
+                else:
+                    s=padcol; r=cells[0][1]+rowadd
+                e=r*W+s
+                slots.setdefault(e%32,set()).add(e)
+            if slots:
+                tot+=max(len(v) for v in slots.values()); ideal+=1
+    return tot,ideal
+def simw(W,padcol,trials=200):
+    random.seed(1)
+    T=0;I=0
+    for _ in range(trials):
+        k=random.randint(3,21)
+        held=set(random.sample(range(21),k))
+        items=[i for i,(p,c) in enumerate(shapes) if p in held]
+        nrows=18; base=0
+        while base<len(items):
+            left=len(items)-base
+            sl=2 if left<=16 else (1 if left<=48 else 0)
+            share=(nrows+(1<<sl)-1)>>sl
+            lanes=[]
+            for l in range(64):
+                i=base+(l>>sl); part=l&((1<<sl)-1)
+                lanes.append((items[i],part*share) if i<len(items) else None)
+            t,i_=cycles_w(lanes,W,padcol)
+            T+=t*share; I+=i_*share
+            base+=64>>sl
+    return T/I
+for W in (10,11,12,13):
+    for pc in range(9,W):
+        print(W,pc,round(simw(W,pc),3))
+
+print("--- pads read the origin cell again")
+def cycles_o(batch_lanes, fn):
+    tot=0; ideal=0
+    for j in range(5):
+        for g in range(2):
+            slots={}
+            for l in range(32*g,32*g+32):
+                it=batch_lanes[l]
+                if it is None: continue
+                sh,rowadd=it
+                cells=shapes[sh][1]
+                s,ro=cells[j] if j < len(cells) else cells[0]
+                e=fn(s,ro+rowadd)
+                slots.setdefault(e%32,set()).add(e)
+            if slots:
+                tot+=max(len(v) for v in slots.values()); ideal+=1
+    return tot,ideal
+def simo(fn,trials=200):
+    random.seed(1)
+    T=0;I=0
+    for _ in range(trials):
+        k=random.randint(3,21)
+        held=set(random.sample(range(21),k))
+        items=[i for i,(p,c) in enumerate(shapes) if p in held]
+        nrows=18; base=0
+        while base<len(items):
+            left=len(items)-base
+            sl=2 if left<=16 else (1 if left<=48 else 0)
+            share=(nrows+(1<<sl)-1)>>sl
+            lanes=[]
+            for l in range(64):
+                i=base+(l>>sl); part=l&((1<<sl)-1)
+                lanes.append((items[i],part*share) if i<len(items) else None)
+            t,i_=cycles_o(lanes,fn)
+            T+=t*share; I+=i_*share
+            base+=64>>sl
+    return T/I
+print('sr28', round(simo(lambda s,r: s*28+r),3))
+for W in (9,10,11,12,13):
+    print('rs',W, round(simo(lambda s,r: r*W+s),3))
