@@ -14,7 +14,7 @@ _native.lib().crl_blokus_stamps(buf, 1)
 bb.rollout(256, 1)
 torch.cuda.synchronize()
 _native.lib().crl_blokus_stamps(buf, 1)
-names = ["loop/outcome", "prep", "count: row range, scan of the piece counts", "rng+select", "apply", "exists", "count: shape x row batches", "count: work list + pre-shifted table"]   # BLK_STAMP(k) closes segment k
+names = ["loop/outcome", "prologue: rows, pre-shifted table, work list", "count: row range, scan of the piece counts", "rng+select", "apply", "exists", "count: shape x row batches", "-"]   # BLK_STAMP(k) closes segment k
 tot = sum(buf)
 for n, v in zip(names, buf):
     print("%-48s %6.1f %%   %8.0f cycles/wave-step" % (n, 100.0 * v / tot, v / 16384 / 256))
