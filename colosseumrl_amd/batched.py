@@ -335,7 +335,8 @@ class TTTBatch:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         handle = C.c_void_p()
-        check(lib.crl_ttt_create(d3[0], d3[1], d3[2], self.K, self.P, C.byref(handle)), "crl_ttt_create")
+        with torch.cuda.device(self.device):     # (boards of <= 16 cells: the context keeps its win-mask table on THIS device)
+            check(lib.crl_ttt_create(d3[0], d3[1], d3[2], self.K, self.P, C.byref(handle)), "crl_ttt_create")
         self._ctx = _Ctx(handle)
         self._lib = lib
         self.first_env_id = int(first_env_id)
