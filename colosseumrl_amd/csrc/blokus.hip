@@ -77,7 +77,10 @@ struct BlkTables {
     // row 0 in the wave's pre-shifted table (WaveLds::u.sh[dy+4][dx+4]) relative to the start of WaveLds -- the slots behind
     // the shape's cells repeat cell 0, see blk_shape_count --, multiplicity | (cells - 1) << 4, and the piece: one 16-byte
     // read per work item where round 2 went item -> uniq -> cells / ncell and then computed five addresses (~45 VALU per batch).
-    struct alignas(16) Distinct { uint16_t off[5]; uint8_t mult_n, piece; uint32_t unused; } distinct[92];
+    // `rows`: the least and the greatest row offset dy + 4 of the shape's cells (bits 3:0, 7:4).  The table is ordered by
+    // the shapes' extent in rows (greatest - least), flat shapes first -- the order of the work list, so that the shapes of
+    // a batch need about the same number of origin rows (blk_count_batches).
+    struct alignas(16) Distinct { uint16_t off[5]; uint8_t mult_n, piece; uint32_t rows; } distinct[92];
     uint8_t first[24];          // index of a piece's first distinct shape in `distinct`
 };
 
@@ -165,22 +168,33 @@ struct WaveLds {
 // the `distinct` / `first` part of the tables (needs the layout of WaveLds)
 void build_distinct(BlkTables &t)
 {
-    int d = 0;
+    BlkTables::Distinct all[NSHAPE];
+    int ext[NSHAPE], n = 0;
     for (int p = 0; p < NPIECE; ++p) {
-        t.first[p] = (uint8_t)d;
-        for (int k = 0; k < t.nuniq[p]; ++k, ++d) {
+        t.first[p] = (uint8_t)n;                    // (position in piece-major order: host-side bookkeeping only)
+        for (int k = 0; k < t.nuniq[p]; ++k, ++n) {
             const int o = t.uniq[p][k] & 7;
-            BlkTables::Distinct &e = t.distinct[d];
+            BlkTables::Distinct &e = all[n];
+            memset(&e, 0, sizeof(e));
+            int rmin = 8, rmax = 0;
             for (int j = 0; j < 5; ++j) {
                 const int c = t.cells[p * 8 + o][j], sx = c & 15, ro = c >> 4;
                 // (cells[][j] repeats cell 0 for j >= the piece's cell count: so do the table offsets)
                 const size_t off = offsetof(WaveLds, u) + (size_t)(ro * 9 + sx) * sizeof(uint2);
                 e.off[j] = (uint16_t)off;
+                rmin = ro < rmin ? ro : rmin;
+                rmax = ro > rmax ? ro : rmax;
             }
             e.mult_n = (uint8_t)((t.uniq[p][k] >> 4) | ((t.ncell[p] - 1) << 4));
             e.piece = (uint8_t)p;
+            e.rows = (uint32_t)(rmin | (rmax << 4));
+            ext[n] = rmax - rmin;
         }
     }
+    int d = 0;
+    for (int want = 0; want <= 8; ++want)           // stable: piece-major inside an extent
+        for (int i = 0; i < n; ++i)
+            if (ext[i] == want) t.distinct[d++] = all[i];
 }
 
 __device__ __forceinline__ void wave_sync()
@@ -291,12 +305,12 @@ __device__ __forceinline__ void blk_build_shifted(WaveLds &L, const int q, const
 // (Tried in round 3: cell 0 of every shape is its origin, i.e. the same table row in all 64 lanes, so with wave-uniform
 //  rows it can come out of a register by v_readlane instead of out of the LDS -- four reads per row instead of five.
 //  7 % SLOWER: the pass is bound by instruction issue, not by the LDS, and a v_readlane with a scalar index stalls.)
-struct DistinctRegs { uint32_t o01, o23, o4mp; };    // BlkTables::Distinct as loaded: off[0..4], mult | (cells - 1) << 4, piece
+struct DistinctRegs { uint32_t o01, o23, o4mp, rows; };   // BlkTables::Distinct as loaded: off[0..4], mult | (cells - 1) << 4, piece, rows
 
 __device__ __forceinline__ DistinctRegs blk_load_distinct(const BlkTables &T, const int d)
 {
     const uint4 raw = *reinterpret_cast<const uint4 *>(&T.distinct[d]);
-    return DistinctRegs{raw.x, raw.y, raw.z};
+    return DistinctRegs{raw.x, raw.y, raw.z, raw.w};
 }
 
 // Origin rows ya .. ya + n - 1: `ya` may differ from lane to lane (lanes that share a shape take a part of its rows each),
@@ -416,27 +430,47 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
 #define BLK_COUNT_STAMP(slot) do { } while (0)
 #endif
 // the shape x row batches of a count pass and the per-piece totals; the work list (`items` entries), the pre-shifted table
-// of player q, the cleared pcnt[] and the wave barrier behind them are the caller's (blk_count, or blk_prologue in the rollout)
-__device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLds &L, const int lane, const int items, const int y0, const int y1,
+// of player q, the cleared pcnt[] and the wave barrier behind them are the caller's (blk_count, or blk_prologue in the rollout).
+// lo / hi: the first and the last board row that holds an anchor of the player.
+// Every shape has its OWN origin rows: a cell with row offset dy can only touch an anchor when the origin lies in
+// lo - dy .. hi - dy, so the shape's rows are lo - (its greatest dy) .. hi - (its least dy), cut to the board -- the anchor
+// rows' span plus the shape's extent in rows (0..4), where one range for all shapes (round 2 / early round 3) was the span
+// plus 8 cut to the board: 13.7 rows on average over random games for a span of 9.2.  A lane starts at its shape's first row
+// and all lanes run the number of rows the widest shape of the batch needs (the work list is ordered by extent, so the
+// shapes of a batch are alike and the widest is the last); rows behind a shape's own count nothing (blk_shape_count).
+__device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLds &L, const int lane, const int items, const int lo, const int hi,
                                                       uint32_t *piece_incl, uint32_t *piece_cnt
 #ifdef BLK_STAMPS
                                                       , unsigned long long *stamp_acc_p = nullptr, unsigned long long *stamp_prev_p = nullptr
+#endif
+#ifdef BLK_COUNTERS
+                                                      , unsigned long long *cnt_acc = nullptr
 #endif
                                                       )
 {
     // 64 lanes per batch of shapes.  A batch with at most 48 (16) shapes left gives each of up to 32 (16) shapes two (four) lanes, each with
     // its share of the origin rows -- the counts meet in pcnt[] anyway: the second batch of an early-game inventory (91
     // shapes: 64 + 27) and the only batch of a late one then take half or a quarter of the row loop.
-    const int n_rows = y1 - y0 + 1;
     for (int base = 0; base < items; ) {
         const int left = items - base;
         // (33..48 left: 32 of them at two lanes each, the rest at four in the next batch -- three quarters of a full batch's rows)
         const int split_log = left <= 16 ? 2 : (left <= 48 ? 1 : 0);         // wave-uniform
         const int i = base + (lane >> split_log), part = lane & ((1 << split_log) - 1);
-        const int share = (n_rows + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up: the last part
-        const int ya = y0 + part * share;                                     // overshoots y1 by up to three rows
         const bool active = i < items;
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
+        // the batch runs as many rows as its widest shape can need: the anchor rows' span plus that shape's extent, at most
+        // the whole board -- the work list is ordered by extent, so the widest shape of a batch is its last (one v_readlane;
+        // the exact maximum over the lanes' own counts, board edges included, costs a wave reduction per batch and buys nothing)
+        const int rmax = (int)((e.rows >> 4) & 15u);
+        const int first = max(lo + 4 - rmax, 0);
+        const int last_lane = (min(left, 64 >> split_log) - 1) << split_log;
+        const uint32_t rows_last = (uint32_t)__builtin_amdgcn_readlane((int)e.rows, last_lane);
+        const int n_max = min(hi - lo + 1 + (int)((rows_last >> 4) & 15u) - (int)(rows_last & 15u), BN);
+        const int share = (n_max + (1 << split_log) - 1) >> split_log;       // rows per lane, rounded up: the last part
+        const int ya = first + part * share;                                  // overshoots by up to three rows
+#ifdef BLK_COUNTERS
+        if (cnt_acc) cnt_acc[3] += share;
+#endif
         const uint32_t c = blk_shape_count<false>(L, e, active, ya, share) * ((e.o4mp >> 16) & 0xfu);
         if (c) atomicAdd(&L.pcnt[e.o4mp >> 24], c);
         base += 64 >> split_log;
@@ -453,13 +487,12 @@ __device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLd
 __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
                                               uint32_t *piece_incl = nullptr, uint32_t *piece_cnt = nullptr)
 {
-    int y0, y1;
-    blk_row_range(L, q, lane, y0, y1);
+    const unsigned long long m = __ballot(lane < BN && L.ac[q][lane + 4].y != 0u);   // rows with anchors (as blk_row_range)
     if (lane < 32) L.pcnt[lane] = 0;
-    if (y1 < y0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
+    if (m == 0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
     const int items = blk_build_items(T, L, inv, lane);
     blk_build_shifted(L, q, lane);                        // (its barrier also orders the pcnt clear and the work list)
-    return blk_count_batches(T, L, lane, items, y0, y1, piece_incl, piece_cnt);
+    return blk_count_batches(T, L, lane, items, __builtin_ctzll(m), 63 - __builtin_clzll(m), piece_incl, piece_cnt);
 }
 
 // Everything a count pass of the ROLLOUT's mover needs, behind ONE wave barrier: player q's allowed / corner rows out of the
@@ -758,8 +791,10 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
 
 // ---- diagnostic build only (-DBLK_STAMPS): where a rollout step spends its cycles.  Stamp values leave the
 // kernel through g_blk_stamps alone; no output depends on them.  The shipped build compiles none of this.
-#ifdef BLK_STAMPS
+#if defined(BLK_STAMPS) || defined(BLK_COUNTERS)
 __device__ unsigned long long g_blk_stamps[8];
+#endif
+#ifdef BLK_STAMPS
 #define BLK_STAMP(slot)                                                                      \
     do {                                                                                     \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
@@ -1040,6 +1075,9 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
 #ifdef BLK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef BLK_COUNTERS
+    unsigned long long cnt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < T_steps; ++t) {
         BLK_STAMP(0);
         const uint32_t ip = (uint32_t)__builtin_amdgcn_readlane((int)vinv, pl);
@@ -1050,11 +1088,18 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         uint32_t total = 0u;                                     // len(valid_actions) of the mover
         if (!((dead >> pl) & 1u) && pro.anchor_rows != 0u) {
             const int lo = __builtin_ctz(pro.anchor_rows), hi = 31 - __builtin_clz(pro.anchor_rows);
-            const int y0 = lo - 4 < 0 ? 0 : lo - 4, y1 = hi + 4 > BN - 1 ? BN - 1 : hi + 4;      // as blk_row_range
-#ifdef BLK_STAMPS
-            total = blk_count_batches(T, L, lane, pro.items, y0, y1, &piece_incl, &piece_cnt, stamp_acc, &stamp_prev);
+#ifdef BLK_COUNTERS   /* diagnostic builds only: how many row trips a count pass takes, against the (shape, row) pairs it covers */
+            {
+                const int y0_ = lo - 4 < 0 ? 0 : lo - 4, y1_ = hi + 4 > BN - 1 ? BN - 1 : hi + 4, n_rows_ = y1_ - y0_ + 1;
+                cnt_acc[0] += 1; cnt_acc[1] += pro.items; cnt_acc[2] += n_rows_; cnt_acc[4] += hi - lo + 1;
+                cnt_acc[5] += (pro.items * n_rows_ + 63) / 64; cnt_acc[6] += (pro.items * (hi - lo + 1 + 3) + 63) / 64;
+                cnt_acc[7] += pro.items <= 32 ? 1 : 0;
+            }
+            total = blk_count_batches(T, L, lane, pro.items, lo, hi, &piece_incl, &piece_cnt, cnt_acc);
+#elif defined(BLK_STAMPS)
+            total = blk_count_batches(T, L, lane, pro.items, lo, hi, &piece_incl, &piece_cnt, stamp_acc, &stamp_prev);
 #else
-            total = blk_count_batches(T, L, lane, pro.items, y0, y1, &piece_incl, &piece_cnt);
+            total = blk_count_batches(T, L, lane, pro.items, lo, hi, &piece_incl, &piece_cnt);
 #endif
         }
         if (total == 0 && round >= 1) dead |= 1u << pl;
@@ -1144,6 +1189,10 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
 #ifdef BLK_STAMPS
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_blk_stamps[i], stamp_acc[i]);
+#endif
+#ifdef BLK_COUNTERS
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_blk_stamps[i], cnt_acc[i]);
 #endif
     wave_sync();
     for (int i = lane; i < 4 * BN; i += 64) occ[b * 4 * BN + i] = L.occ[i / BN][i % BN];
@@ -1449,7 +1498,7 @@ int crl_blokus_create(crl_ctx **out)
 int crl_blokus_stamps(uint64_t *out8, int reset)
 {
     CRL_REQUIRE(out8 != nullptr, "crl_blokus_stamps: out8 is NULL");
-#ifdef BLK_STAMPS
+#if defined(BLK_STAMPS) || defined(BLK_COUNTERS)
     CRL_HIP(hipDeviceSynchronize());
     CRL_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_blk_stamps), 8 * sizeof(uint64_t)));
     if (reset) {
