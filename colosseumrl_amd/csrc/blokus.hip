@@ -578,21 +578,27 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     // shift a right shift), five shifts, two three-way ANDs per visited row, no table, no wave barrier.  Slots behind the
     // shape's cells repeat cell 0 (the same test twice).
     const uint2 cw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + po][0]);
-    int rowoff[5];                                               // byte offset of cell k's row relative to ac[q][ay + 4]
+    int rowoff[5];                                               // byte offset of cell k's row relative to ac[q][ay + 4 - 8]
     uint32_t colsh[5];                                           // right shift that brings cell k's column onto the anchor's
     {
-        const uint32_t c[5] = {cw.x & 0xffu, (cw.x >> 8) & 0xffu, (cw.x >> 16) & 0xffu, cw.x >> 24, cw.y & 0xffu};
-        uint32_t mineb = c[0];
+        // all five cells at once, a byte each (round 3, second half; as ten chains of extract - subtract - scale this set-up was
+        // ~35 vector instructions per ply): the row offsets dy_k + 8 - dy_j (0..16) times 8, the shifts 8 + dx_k - dx_j (0..16)
+        uint32_t mineb = cw.x & 0xffu;
 #pragma unroll
-        for (int k = 1; k < 5; ++k) mineb = (pj == k) ? c[k] : mineb;
-        const int dxj = (int)(mineb & 15u), dyj = (int)(mineb >> 4);
+        for (int k = 1; k < 4; ++k) mineb = (pj == k) ? (cw.x >> (8 * k)) & 0xffu : mineb;
+        mineb = (pj == 4) ? cw.y & 0xffu : mineb;
+        const uint32_t dxj = mineb & 15u, dyj = mineb >> 4;
+        const uint32_t ro4 = (((cw.x >> 4) & 0x0f0f0f0fu) + (8u - dyj) * 0x01010101u) << 3;
+        const uint32_t cs4 = (cw.x & 0x0f0f0f0fu) + (8u - dxj) * 0x01010101u;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            rowoff[k] = ((int)(c[k] >> 4) - dyj) * (int)sizeof(uint2);
-            colsh[k] = (uint32_t)(8 + (int)(c[k] & 15u) - dxj);
+        for (int k = 0; k < 4; ++k) {
+            rowoff[k] = (int)__builtin_amdgcn_ubfe(ro4, 8u * k, 8u);
+            colsh[k] = __builtin_amdgcn_ubfe(cs4, 8u * k, 8u);
         }
+        rowoff[4] = (int)((((cw.y >> 4) & 15u) + 8u - dyj) << 3);
+        colsh[4] = (cw.y & 15u) + 8u - dxj;
     }
-    const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]);
+    const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]) - 8 * (int)sizeof(uint2);   // (the row offsets carry a bias of 8 rows)
     // The walk starts from whichever end of the anchor order is nearer in rank: the piece's total is known (pcnt), so an
     // action in the upper half of the piece's range is counted down from the last anchor -- a quarter of the anchors per
     // select on average instead of half.
