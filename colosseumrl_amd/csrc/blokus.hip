@@ -390,9 +390,17 @@ __device__ __forceinline__ void blk_row_range(const WaveLds &L, const int q, con
 // round 3: one lane per PIECE, a wave scan of the pieces' shape counts and a loop of up to eight byte stores per lane; with
 // the wave barrier behind it, 17 % of a ply together with the pre-shifted table.)  No barrier here: blk_build_shifted,
 // which every caller runs next, ends with one.
-__device__ __forceinline__ int blk_build_items(const BlkTables &T, WaveLds &L, const uint32_t inv, const int lane)
+// pa / pb: the pieces of the lane's two distinct shapes (blk_shape_owners) -- constants of the launch, which the rollout keeps
+// in registers instead of reading them out of the tables on every ply
+struct BlkOwners { uint32_t pa, pb; };
+__device__ __forceinline__ BlkOwners blk_shape_owners(const BlkTables &T, const int lane)
 {
-    const uint32_t pa = T.distinct[lane].piece, pb = T.distinct[lane < NDISTINCT - 64 ? 64 + lane : 0].piece;
+    return BlkOwners{T.distinct[lane].piece, T.distinct[lane < NDISTINCT - 64 ? 64 + lane : 0].piece};
+}
+
+__device__ __forceinline__ int blk_build_items(WaveLds &L, const uint32_t inv, const int lane, const BlkOwners own)
+{
+    const uint32_t pa = own.pa, pb = own.pb;
     const bool ha = (inv >> pa) & 1u, hb = lane < NDISTINCT - 64 && ((inv >> pb) & 1u);
     const unsigned long long ma = __ballot(ha), mb = __ballot(hb);
     const uint32_t na = (uint32_t)__builtin_popcountll(ma);
@@ -410,7 +418,7 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
     blk_row_range(L, q, lane, y0, y1);
     if (y1 < y0 || inv == 0) return false;
     if (inv & 1u) return true;                          // the monomino fits on any anchor (anchors are allowed cells)
-    const int items = blk_build_items(T, L, inv, lane);
+    const int items = blk_build_items(L, inv, lane, blk_shape_owners(T, lane));
     blk_build_shifted(L, q, lane);
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
@@ -490,7 +498,7 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
     const unsigned long long m = __ballot(lane < BN && L.ac[q][lane + 4].y != 0u);   // rows with anchors (as blk_row_range)
     if (lane < 32) L.pcnt[lane] = 0;
     if (m == 0) { wave_sync(); if (piece_incl) *piece_incl = 0u; if (piece_cnt) *piece_cnt = 0u; return 0; }
-    const int items = blk_build_items(T, L, inv, lane);
+    const int items = blk_build_items(L, inv, lane, blk_shape_owners(T, lane));
     blk_build_shifted(L, q, lane);                        // (its barrier also orders the pcnt clear and the work list)
     return blk_count_batches(T, L, lane, items, __builtin_ctzll(m), 63 - __builtin_clzll(m), piece_incl, piece_cnt);
 }
@@ -501,8 +509,8 @@ __device__ __forceinline__ uint32_t blk_count(const BlkTables &T, WaveLds &L, co
 // pcnt[] and the work list.  As separate steps (prep, barrier, row range, work list, table, barrier) the same work sat in
 // the dependent chain of every ply with three LDS round trips more.
 struct BlkPrologue { int items; uint32_t anchor_rows; };        // anchor_rows: bit y = board row y holds an anchor of q
-__device__ __forceinline__ BlkPrologue blk_prologue(const BlkTables &T, WaveLds &L, const int lane, const int round, const int q,
-                                                    const uint32_t inv)
+__device__ __forceinline__ BlkPrologue blk_prologue(WaveLds &L, const int lane, const int round, const int q, const uint32_t inv,
+                                                    const BlkOwners own)
 {
     // lanes 0..27 and 32..59: table row r = lane & 31 = board row y = r - 4 (rows outside the board are zero); the low half
     // writes shifts 0..4 and the rows themselves, the high half shifts 5..8
@@ -533,7 +541,7 @@ __device__ __forceinline__ BlkPrologue blk_prologue(const BlkTables &T, WaveLds 
     BlkPrologue out;
     out.anchor_rows = ((uint32_t)__ballot(lane < 32 && corner != 0u)) >> 4;
     if (lane < 32) L.pcnt[lane] = 0;
-    out.items = blk_build_items(T, L, inv, lane);
+    out.items = blk_build_items(L, inv, lane, own);
     wave_sync();
     return out;
 }
@@ -1077,6 +1085,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
     // what the reference recomputes every step; it starts empty at kernel entry and at every reset.
     uint32_t dead = 0, can_move = 0;
     const uint32_t piece_cells = lane < 24 ? T.ncell[lane] : 0u;   // lane p: cells of piece p, for the whole launch
+    const BlkOwners owners = blk_shape_owners(T, lane);            // lane l: the pieces of distinct shapes l and 64 + l
     uint32_t rnd_word = 0u;
 #ifdef BLK_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
@@ -1088,7 +1097,7 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
         BLK_STAMP(0);
         const uint32_t ip = (uint32_t)__builtin_amdgcn_readlane((int)vinv, pl);
         // the mover's rows (another player's only when the game may end), pre-shifted table and work list, one barrier
-        const BlkPrologue pro = blk_prologue(T, L, lane, round, pl, ip);
+        const BlkPrologue pro = blk_prologue(L, lane, round, pl, ip, owners);
         BLK_STAMP(1);
         uint32_t piece_incl = 0u, piece_cnt = 0u;
         uint32_t total = 0u;                                     // len(valid_actions) of the mover
