@@ -2109,12 +2109,22 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         const int tgt = pos + __builtin_amdgcn_sbfe((int)bstep4, dir8, 8);
         const int tq = run ? tgt : jpos;                        // a dead player probes its own junk word
         const int wa = (tq >> 3) & ~3;                          // the word holding the cell; its bit is tq & 31
-        uint32_t word;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(word) : "v"(wa) : "memory");
-        // right behind the probe: the LDS serves a wave's requests in order, so the store runs while the wave waits
-        if constexpr (GRP < kGroups) store_group(GRP);
         uint32_t bit;                                           // 1 << (tq & 31): the shift reads five bits by itself
         asm("v_lshlrev_b32 %0, %1, 1" : "=v"(bit) : "v"(tq));
+        // Probe and trail in ONE LDS operation (round 3, second half): an atomic OR that returns the word as it was.  A player
+        // that finds its bit set dies and has changed nothing; one that finds it clear has entered the cell.  (Round 2 read
+        // the word, decided, and then issued a second, non-returning atomic OR on the word -- or on the junk word for a player
+        // that had not moved: two of the step's LDS operations, both on random words, i.e. at ~3.5 LDS cycles per conflict-free
+        // one; the LDS array is what this kernel waits for.)  Two players of a game entering one cell in one step see each
+        // other's bit, whichever the LDS serves first: that is an interaction, and the fix-up below sorts it out.
+        uint32_t word;
+#ifdef CRL_QBITS_PROBE_THEN_OR     /* the round-2 form, kept for A/B builds */
+        asm volatile("ds_read_b32 %0, %1" : "=v"(word) : "v"(wa) : "memory");
+#else
+        asm volatile("ds_or_rtn_b32 %0, %1, %2" : "=v"(word) : "v"(wa), "v"(bit) : "memory");
+#endif
+        // right behind the probe: the LDS serves a wave's requests in order, so the store runs while the wave waits
+        if constexpr (GRP < kGroups) store_group(GRP);
         const int x1 = tq ^ tron_quad<0x39>(pos), x2 = tq ^ tron_quad<0x4E>(pos), x3 = tq ^ tron_quad<0x93>(pos);
         const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
         uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
@@ -2125,9 +2135,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         const int pos_was = pos;
         d8 = run ? dir8 : d8;                                   // :44 the direction is committed even if the move dies
         pos = moved ? tgt : pos;
-#ifdef CRL_DIAG_PLAIN_OR           /* diagnostic builds only (WRONG when two players set bits of one word in one step) */
-        *(lds_u32 *)(uintptr_t)(uint32_t)(moved ? wa : jaddr) = word | bit;
-#else
+#ifdef CRL_QBITS_PROBE_THEN_OR
         atomicOr((unsigned int *)(lds + ((moved ? wa : jaddr) - lds0)), bit);
 #endif
         bool alive_now = moved;
@@ -2143,7 +2151,21 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
             // in the reference's order from the pre-step state, redundantly in its four lanes
             if (moved) atomicAnd((unsigned int *)(lds + (wa - lds0)), ~bit);
             const int d = (run ? (dir8 - (int)(acts << 3)) >> 3 : d8 >> 3) & 3, dir = (dir8 >> 3) & 3;
-            const int al = run ? 1 : 0, oc = (word & bit) ? 1 : 0;
+            const int al = run ? 1 : 0;
+            int oc = (word & bit) ? 1 : 0;
+#ifndef CRL_QBITS_PROBE_THEN_OR
+            {   // the probe set its bit in the same operation: a player that found the bit of an EMPTY cell set by a player of
+                // its game that entered the cell in this very step must see the cell as it was before the step (had the cell
+                // been occupied before, nobody would have entered it)
+                // (every DPP read in ALL lanes before any lane selects: under a short-circuit && the second read would run
+                //  only in the lanes whose targets match, and a DPP read of a lane that sits the branch out returns 0)
+                const int mvi = moved ? 1 : 0;
+                const int t1 = tron_quad<0x39>(tq), t2 = tron_quad<0x4E>(tq), t3 = tron_quad<0x93>(tq);
+                const int m1 = tron_quad<0x39>(mvi), m2 = tron_quad<0x4E>(mvi), m3 = tron_quad<0x93>(mvi);
+                const int entered = (tq == t1 ? m1 : 0) | (tq == t2 ? m2 : 0) | (tq == t3 ? m3 : 0);
+                oc = entered ? 0 : oc;
+            }
+#endif
             int ps[4] = {tron_quad<0x00>(pos_was), tron_quad<0x55>(pos_was), tron_quad<0xAA>(pos_was), tron_quad<0xFF>(pos_was)};
             int ds[4] = {tron_quad<0x00>(d), tron_quad<0x55>(d), tron_quad<0xAA>(d), tron_quad<0xFF>(d)};
             int al4[4] = {tron_quad<0x00>(al), tron_quad<0x55>(al), tron_quad<0xAA>(al), tron_quad<0xFF>(al)};
