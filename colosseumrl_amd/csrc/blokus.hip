@@ -153,13 +153,9 @@ constexpr int BLK_SH_ROW_BYTES = 9 * (int)sizeof(uint2);
 struct WaveLds {
     uint32_t occ[4][BN];     // board rows per colour, bit x = column x
     uint2 ac[4][32];         // per player, index y+4: {allowed << 8, corner << 8}; rows outside the board are 0
-    union {                  // the count / existence passes and the select pass never overlap in time
-        struct {
-            uint32_t fit[8][32];     // chosen piece, per orientation, index y+4: origins where it fits, bit x+4
-            uint16_t alist[BN * BN]; // anchors of the mover in row-major order: y << 8 | x
-        } sel;
+    struct {                 // (a union with the select pass's fit table and anchor list until the middle of round 3: both are gone)
         uint2 sh[BLK_SH_ROWS][9];   // the player being counted: sh[r][s] = ac[q][r] >> s (both words), s = dx + 4 of a shape cell;
-                                    // rows 0..27 are used, the row count sets the LDS bank offset between shifts
+                                    // rows 0..27 are rewritten by every count pass, rows 28..30 stay zero
     } u;
     uint32_t pcnt[32];       // legal-action count per piece (0 for pieces not held)
     uint8_t items[NSHAPE];   // work list of a count / existence pass: indices into BlkTables::distinct
@@ -1283,58 +1279,15 @@ blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const u
 }
 
 // ---- the ordered legal-action list, compacted (what BlokusEnvironment.valid_actions returns, :453-500) -------------------
-// fit table of all 8 orientations of `piece` for player q into L.u.sel.fit (as level 1 of blk_select)
-__device__ __forceinline__ void blk_build_fit(const BlkTables &T, WaveLds &L, const int q, const int piece, const int lane)
-{
-    for (int i = lane; i < 8 * 12; i += 64) {
-        const int o = i / 12, k = i - o * 12;
-        L.u.sel.fit[o][k < 4 ? k : k + BN] = 0u;
-    }
-    for (int i = lane; i < 8 * BN; i += 64) {
-        const int o = i / BN, y = i - o * BN;
-        const ShapeRegs s = blk_load_shape(T, piece, o);
-        uint32_t F = 0xffffffffu;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) F &= L.ac[q][y + s.ro(j)].x >> s.sh(j);
-        L.u.sel.fit[o][y + 4] = F;
-    }
-    wave_sync();
-}
-
-// anchors of player q in row-major order into L.u.sel.alist (y << 8 | x); returns their number
-__device__ __forceinline__ int blk_build_anchors(WaveLds &L, const int q, const int lane)
-{
-    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
-    const uint32_t rinc = wave_scan_incl((uint32_t)__popc(crow), lane);
-    uint32_t m = crow;
-    int pos = (int)rinc - __popc(crow);
-    while (m) {
-        const int x = __builtin_ctz(m);
-        m &= m - 1;
-        L.u.sel.alist[pos++] = (uint16_t)((lane << 8) | x);
-    }
-    wave_sync();
-    return __builtin_amdgcn_readlane((int)rinc, BN - 1);
-}
-
-// legal (orientation, shift) pairs of `piece` (n cells) with its cell `shift` on anchor (ax, ay): bit o * n + j.
-// blk_build_fit(piece) must have run.  One lane per anchor (40 bit tests of the fit table).
-__device__ __forceinline__ unsigned long long blk_anchor_pairs(const BlkTables &T, const WaveLds &L, const int piece, const int n,
-                                                               const int ax, const int ay)
-{
-    unsigned long long m = 0;
-    for (int o = 0; o < 8; ++o)
-        for (int j = 0; j < n; ++j) {
-            const uint32_t cb = T.cells[piece * 8 + o][j];
-            const int dx4 = (int)(cb & 15u), dy4 = (int)(cb >> 4);
-            const uint32_t bit = (L.u.sel.fit[o][ay + 8 - dy4] >> (ax + 8 - dx4)) & 1u;
-            m |= (unsigned long long)bit << (o * n + j);
-        }
-    return m;
-}
-
 // count[b] and ids[b][0 .. min(count, cap)) = the dense ids of every legal action of `player` in ascending order, which is
-// the reference's order (piece -> anchor row-major -> orientation -> shift, board.py:184-189)
+// the reference's order (piece -> anchor row-major -> orientation -> shift, board.py:184-189).
+// Per piece one lane per (orientation, shift) pair, as in blk_select: lane o * n + j fits orientation o with its cell j on
+// the anchors of a row -- five reads of the padded allowed rows, five shifts, three ANDs give the row's legal anchors of the
+// pair as a bit mask --, and per anchor of the row one ballot lines the legal pairs up in reference order: a legal lane's
+// place in the list is the running total plus the legal lanes below it (v_mbcnt), its id the anchor's base id plus 5 o + j.
+// (The first version, earlier in round 3, built a fit table per piece and then gave every ANCHOR a lane that ran 8 n
+// dependent pairs of LDS reads and a loop over its set bits: ~1,100 dependent LDS round trips per list, 296 us for 16,384
+// mid-game positions; the rows of a piece are independent here.)
 __global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_list_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
                    const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
@@ -1354,33 +1307,59 @@ blokus_list_kernel(const BlkTables *__restrict__ tables, const int64_t B, const 
     if (lane == 0 && count) count[b] = (int32_t)total;
     if (!ids || total == 0) return;
     int32_t *out = ids + b * (int64_t)cap;
-    // the per-piece counts leave LDS before the select tables overwrite the count pass's (pcnt itself is not in the union)
-    const int n_anchor = blk_build_anchors(L, q, lane);
-    uint32_t base = 0;
+    // the rows with anchors (a scalar mask) and each row's anchors (lane y: bit x), as in blk_select
+    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
+    const uint32_t rows_mask = (uint32_t)__builtin_amdgcn_ballot_w64(crow != 0u);
+    const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]);
+    uint32_t base = 0;                                           // actions listed so far (wave-uniform)
     for (int piece = 0; piece < NPIECE; ++piece) {
         const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[piece]);
-        if (pc == 0) continue;
+        if (pc == 0) continue;                                   // not held, or no legal placement
         const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
-        blk_build_fit(T, L, q, piece, lane);
-        for (int a0 = 0; a0 < n_anchor; a0 += 64) {
-            const bool have = a0 + lane < n_anchor;
-            const int packed = have ? (int)L.u.sel.alist[a0 + lane] : 0;
-            const int ay = packed >> 8, ax = packed & 0xff;
-            const unsigned long long pairs = have ? blk_anchor_pairs(T, L, piece, n, ax, ay) : 0ull;
-            const uint32_t mine = (uint32_t)__builtin_popcountll(pairs);
-            const uint32_t incl = wave_scan_incl(mine, lane);
-            uint32_t pos = base + incl - mine;
-            unsigned long long m = pairs;
-            while (m) {
-                const int k = __builtin_ctzll(m);
-                m &= m - 1;
-                const int o = k / n, j = k - o * n;
-                if (pos < (uint32_t)cap) out[pos] = ((piece * 400 + ay * BN + ax) * 8 + o) * 5 + j;
-                ++pos;
-            }
-            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const bool pair = lane < 8 * n;
+        // lane / n without a division (n is 1..5, lane < 64: floor(2^32 / n) + 1 is exact there)
+        const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
+        const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
+        // my orientation's cells relative to my cell j: row offsets in bytes of the padded rows, right shifts that bring a
+        // cell's column onto the anchor's (the masks are stored << 8); slots behind the shape's cells repeat cell 0
+        const uint2 cw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + po][0]);
+        const uint32_t c[5] = {cw.x & 0xffu, (cw.x >> 8) & 0xffu, (cw.x >> 16) & 0xffu, cw.x >> 24, cw.y & 0xffu};
+        uint32_t mineb = c[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) mineb = (pj == k) ? c[k] : mineb;
+        const int dxj = (int)(mineb & 15u), dyj = (int)(mineb >> 4);
+        int rowoff[5];
+        uint32_t colsh[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            rowoff[k] = ((int)(c[k] >> 4) - dyj) * (int)sizeof(uint2);
+            colsh[k] = (uint32_t)(8 + (int)(c[k] & 15u) - dxj);
         }
-        wave_sync();                                       // the next piece rewrites the fit table
+        const int oj = po * 5 + pj;                              // my pair's part of the dense id
+        uint32_t rows = rows_mask;
+        while (rows) {
+            const int ay = __builtin_ctz(rows);
+            rows &= rows - 1u;
+            uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);      // this row's anchors, bit x
+            uint32_t fr = pair ? 0xffffffffu : 0u;
+            const char *rowp = acq + ay * (int)sizeof(uint2);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
+            const uint32_t m = fr & cr;                          // bit x: my pair is legal on anchor (x, ay)
+            if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;            // nothing of this piece on this row
+            const int row_id = (piece * 400 + ay * BN) * 40;
+            while (cr) {
+                const int ax = __builtin_ctz(cr);
+                cr &= cr - 1u;
+                const bool legal = ((m >> ax) & 1u) != 0u;
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(legal);
+                if (lm == 0ull) continue;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                const uint32_t pos = base + below;
+                if (legal && pos < (uint32_t)cap) out[pos] = row_id + ax * 40 + oj;
+                base += (uint32_t)__builtin_popcountll(lm);
+            }
+        }
     }
 }
 
