@@ -14,6 +14,7 @@
 // start mask (windows that stay on the board).  Direction strides and start masks are
 // wave-uniform kernel arguments (SGPRs) -- no table traffic at all.
 #include "crl_common.hpp"
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -748,7 +749,7 @@ int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out)
     // masks as a bit table on the device, which crl_ttt_rollout stages into LDS -- one LDS read and four vector
     // instructions per ply instead of the four-direction shift-and test.  Optional: without it (no device at create
     // time, or a rollout on another device) the rollout computes the test as everywhere else.
-    if (c->ttt.n_cells <= 16) {
+    if (c->ttt.n_cells <= 16 && getenv("CRL_TTT_NO_WIN_TABLE") == nullptr) {     // (the switch: tests of the table-less path)
         std::vector<uint32_t> tab(2048, 0u);
         for (uint32_t m = 0; m < 65536u; ++m)
             for (int i = 0; i < n_lines; ++i)

@@ -219,7 +219,8 @@ int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
  *   to_move int8   [B]
  * For boards of at most 16 cells (the reference's 3x3 and 3x5) crl_ttt_create also puts an 8 KB table of the winning masks
  * on the device that is current at the call; crl_ttt_rollout uses it when it runs on that device (and computes the win test
- * as everywhere else when it does not, or when no device was there at create time).  crl_destroy frees it.
+ * as everywhere else when it does not, or when no device was there at create time; the environment variable
+ * CRL_TTT_NO_WIN_TABLE, read by crl_ttt_create, skips the table: tests of that path).  crl_destroy frees it.
  */
 int crl_ttt_create(int D0, int D1, int D2, int K, int P, crl_ctx **out);
 /* number of win lines and a HOST copy of them (for tests); lines may be NULL */

@@ -71,6 +71,15 @@ def test_rollout_long_launches_every_player_count(dims, K, P, B, chunks):
     test_rollout_vs_oracle(dims, K, P, B, chunks)
 
 
+@pytest.mark.parametrize("dims,K,P,B,chunks", [((3, 3), 3, 2, 3000, (64, 13, 200)), ((3, 5), 3, 3, 2049, (100, 7)), ((4, 4), 4, 2, 500, (96,))])
+def test_rollout_small_boards_without_the_win_table(dims, K, P, B, chunks, monkeypatch):
+    """Boards of <= 16 cells normally run the rollout instance whose win test is a lookup in the context's table of winning
+    masks; a context without that table (no device at create time, or a rollout on another device) falls back to the
+    shift-and test.  CRL_TTT_NO_WIN_TABLE makes crl_ttt_create skip the table: the fallback against the oracle."""
+    monkeypatch.setenv("CRL_TTT_NO_WIN_TABLE", "1")
+    test_rollout_vs_oracle(dims, K, P, B, chunks)
+
+
 @pytest.mark.parametrize("dims,K,P,B", [((3, 3), 3, 2, 3000), ((3, 5), 3, 3, 1000 + 7), ((2, 2, 2), 2, 4, 300)])
 def test_rollout_from_finished_states_that_were_not_restarted(dims, K, P, B):
     """A rollout may come in on states the step API left FINISHED (stepped without auto-reset: sticky winner, full board)
