@@ -408,13 +408,14 @@ __device__ __forceinline__ int blk_build_items(WaveLds &L, const uint32_t inv, c
 }
 
 // does player q have any legal action with inventory inv? (board.py:170-193 non-empty)
-__device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane)
+__device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const int q, const uint32_t inv, const int lane,
+                                           const BlkOwners *own = nullptr)
 {
     int y0, y1;
     blk_row_range(L, q, lane, y0, y1);
     if (y1 < y0 || inv == 0) return false;
     if (inv & 1u) return true;                          // the monomino fits on any anchor (anchors are allowed cells)
-    const int items = blk_build_items(L, inv, lane, blk_shape_owners(T, lane));
+    const int items = blk_build_items(L, inv, lane, own ? *own : blk_shape_owners(T, lane));
     blk_build_shifted(L, q, lane);
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
@@ -702,9 +703,8 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
 }
 
 // the board part of blk_apply for a move known to be legal (its cells are empty: only the mover's colour changes)
-__device__ __forceinline__ void blk_place_legal(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv, const int lane)
-{
-    const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[mv.piece]);
+__device__ __forceinline__ void blk_place_legal(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv, const int lane, const int n)
+{   // n: the piece's cell count (the rollout has it in a register)
     const uint8_t *cells = &T.cells[mv.piece * 8 + mv.orient][0];
     const uint32_t oc = cells[mv.shift];
     const int ox = (int)(oc & 15u), oy = (int)(oc >> 4);
@@ -1153,15 +1153,15 @@ blokus_rollout_kernel(const BlkTables *__restrict__ tables, const int64_t B, con
             if (q == pl || ((dead >> q) & 1u)) continue;
             blk_prep(L, lane, round, q);
             const uint32_t iq = (uint32_t)__builtin_amdgcn_readlane((int)vinv, q);
-            any_move = blk_exists(T, L, q, iq, lane);
+            any_move = blk_exists(T, L, q, iq, lane, &owners);
             if (any_move) can_move |= 1u << q;
             if (!any_move && round >= 1) dead |= 1u << q;
         }
         BLK_STAMP(5);
         if (total > 0) {
-            blk_place_legal(T, L, pl, mv, lane);
+            const int n = __builtin_amdgcn_readlane((int)piece_cells, mv.piece);
+            blk_place_legal(T, L, pl, mv, lane, n);
             {                                                   // ai.py:44-54 for the mover's lane(s)
-                const int n = __builtin_amdgcn_readlane((int)piece_cells, mv.piece);
                 const uint32_t left = vinv & ~(1u << mv.piece);
                 const bool me = (lane & 3) == pl;
                 vscore += me ? n + (left == 0u ? (mv.piece == 0 ? 20 : 15) : 0) : 0;
