@@ -192,6 +192,16 @@ def test_rollout_full_size_vs_oracle(N, chunks, kernel):
     assert ost.n_episodes.sum() > 65536
 
 
+@pytest.mark.parametrize("B,chunks", [(65536 + 64 + 13, (20, 7)), (65536 + 1, (1, 64, 5)), (2 * 65536, (20,))])
+def test_rollout_beyond_full_size_ragged_vs_oracle(B, chunks):
+    """Short launches of 20x20 boards on more than a full chip's worth of games (B > 65,536): ragged batches whose last
+    workgroup is partly filled or has waves wholly beyond the batch, one-step launches -- against the oracle.  (Written for
+    a variant of the lane-per-player kernel that played two sets of 64 games per workgroup on short launches; the variant
+    was correct and 3 us slower, DESIGN 4.1, and is gone; the cases stay.)"""
+    ost = _rollout_pair(20, 4, B, chunks, seed=77, first=11, kernel="quad")
+    assert ost.n_episodes.sum() > 0
+
+
 def test_dropin_env_golden(golden):
     """The BaseEnvironment drop-in (strings in, numpy tuples out) replays a golden game exactly."""
     from colosseumrl_amd import get_environment
