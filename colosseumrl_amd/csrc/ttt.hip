@@ -289,7 +289,12 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         for (int p = 0; p + 1 < P; ++p) r[p] = r[p + 1];
         r[P - 1] = mine;
         const int pl8 = tm8;
-        tm8 = (pl8 + 8 == 8 * P) ? 0 : pl8 + 8;                                        // :313
+        if constexpr (P <= 4) {                                                        // :313: the next mover out of a constant of
+            constexpr uint32_t kNext = P == 1 ? 0u : P == 2 ? 0x0008u : P == 3 ? 0x001008u : 0x00181008u;   // bytes (one v_bfe)
+            tm8 = (int)__builtin_amdgcn_ubfe(kNext, (uint32_t)pl8, 8u);
+        } else {
+            tm8 = (pl8 + 8 == 8 * P) ? 0 : pl8 + 8;
+        }
         // (The end of an episode as selects instead of a branch -- some lane of the wave ends one on practically every ply
         //  -- is a wash: +0.7 % at 5x5, -2.3 % at 3x3x3; the selects cost 6 more vector instructions per ply.)
         if (term) {
