@@ -14,6 +14,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum_hip.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
+# the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
+CRL_ABI_VERSION = 104
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
@@ -133,6 +135,10 @@ def lib():
                     raise NativeError("%s does not export %s (stale build?)" % (LIB_PATH, name))
                 fn.restype = res
                 fn.argtypes = args
+            got = handle.crl_version()
+            if got != CRL_ABI_VERSION:                  # a stale or variant build (CRL_LIB_PATH): by-value structs would be mis-sized
+                raise NativeError("%s is ABI revision %d, this binding needs %d (include/colosseum_hip.h CRL_ABI_VERSION): "
+                                  "rebuild it" % (LIB_PATH, got, CRL_ABI_VERSION))
             _lib = handle
     return _lib
 

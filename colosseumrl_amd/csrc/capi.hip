@@ -30,7 +30,7 @@ extern "C" {
 
 const char *crl_last_error(void) { return g_err; }
 
-int crl_version(void) { return 100; }
+int crl_version(void) { return CRL_ABI_VERSION; }
 
 int crl_device_count(void)
 {

@@ -60,6 +60,12 @@ extern "C" {
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 
 const char *crl_last_error(void);
+/* ABI revision of this header: bumped whenever a struct passed by value (crl_*_stats), an argument list or the RNG
+ * contract of the sampled agents changes.  crl_version() returns the revision the LIBRARY was built from; a binding must
+ * refuse a library whose revision differs from the header it was written against (colosseumrl_amd/_native.py does).
+ * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
+ * 104: this header (round 4). */
+#define CRL_ABI_VERSION 104
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);

@@ -76,14 +76,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_native.PROTOTYPES) == declared      # the ctypes table binds every one of them
     _native.lib()
-    assert _native.lib().crl_version() >= 100
+    assert _native.lib().crl_version() == _native.CRL_ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_revision(monkeypatch):
+    """crl_*_stats structs travel by value: a stale / variant .so (CRL_LIB_PATH) must be refused at load, not called."""
+    header = open(os.path.join(ROOT, "include", "colosseum_hip.h")).read()
+    assert int(re.search(r"#define\s+CRL_ABI_VERSION\s+(\d+)", header).group(1)) == _native.CRL_ABI_VERSION
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "CRL_ABI_VERSION", _native.CRL_ABI_VERSION + 1)
+    with pytest.raises(_native.NativeError, match="ABI revision"):
+        _native.lib()
 
 
 def test_native_constants_mirror_the_header():
     """Flag / limit constants the Python side passes through the C ABI are the header's."""
     header = open(os.path.join(ROOT, "include", "colosseum_hip.h")).read()
     defines = {m.group(1): int(m.group(2).rstrip("u"), 0) for m in re.finditer(r"#define\s+(CRL_[A-Z_]+)\s+(-?[0-9a-fx]+u?)\b", header)}
-    for name in ("CRL_STEP_AUTO_RESET", "CRL_ROLLOUT_NO_LDS", "CRL_ROLLOUT_BYTES", "CRL_ROLLOUT_BITS"):
+    for name in ("CRL_ABI_VERSION", "CRL_STEP_AUTO_RESET", "CRL_ROLLOUT_NO_LDS", "CRL_ROLLOUT_BYTES", "CRL_ROLLOUT_BITS"):
         assert getattr(_native, name) == defines[name], name
 
 
