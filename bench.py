@@ -8,13 +8,22 @@ HEADLINE (the contract line).  One "step" = one env-step of EVERY game of the ba
 The workload is BASELINE.json configs[1]: 4-player 20x20 Tron, 65,536 games per GPU, uniform random agent drawn from
 the counter-based RNG, auto-reset on terminal.  State is resident in HBM before the timed region; the timed region is W
 untimed + exactly K timed steps, issued as fused launches of min(--chunk, remaining) steps, bracketed by barrier +
-synchronize; the time is the max over ranks.  With N > 1 each rank owns the games [rank*B, (rank+1)*B) (weak scaling,
-no data-path collective) and the per-game result rows (written by the rollout kernel itself) are gathered once to rank 0
-with a single RCCL gather at the end, inside the timed region (colosseumrl_amd.parallel.ShardedRollout; the collective
-also runs in a world of one rank when a process group exists, e.g. under `torchrun --nproc-per-node 1`).  The clock of a
-rank stops when its own work incl. the collective is complete; the value uses the MAX over ranks.
+synchronize; the time is the max over ranks.  `value` is the FIRST such region of the process: nothing runs between
+set-up and W (the device-warmed figure is `value_warmed` in the detail record).  With N > 1 each rank owns the games
+[rank*B, (rank+1)*B) (weak scaling, no data-path collective) and the per-game result rows (written by the rollout
+kernel itself) are gathered once to rank 0 with a single RCCL gather at the end, inside the timed region
+(colosseumrl_amd.parallel.ShardedRollout; the collective also runs in a world of one rank when a process group exists,
+e.g. under `torchrun --nproc-per-node 1`).  The clock of a rank stops when its own work incl. the collective is
+complete; the value uses the MAX over ranks.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unless --only-headline):
+`--gpus N` ALWAYS means N ranks: under a launcher WORLD_SIZE must equal N (else exit 2); without one and N > 1 this
+script starts `python -m torch.distributed.run --nproc-per-node N` on itself as a CHILD process before anything has
+touched the GPU, passes the child's stdout through and exits with its code; with fewer than N devices visible it exits
+2 and says so on stdout.  It never measures fewer GPUs than it was asked for.
+
+OUTPUT.  stdout carries exactly ONE line: the compact contract object (< 4 KB: the contract fields, `roofline`,
+`cpu_baseline`, `summary`).  Everything else (N = 1, unless --only-headline) goes to bench_detail.json next to this
+script (and gpurun_out/bench_detail.json when that directory exists) and, as one line, to stderr:
   roofline      the contract's formula: `achieved` = SURVEY 8(d)'s algorithmic bytes per env-step x the env-steps of one
                 launch / the launch's duration (HIP events attached to the dispatch; the marker-event figure beside it),
                 `frac` = / 8 TB/s; `traffic` = the HBM bytes the launch really moved (rocprofv3 PMC of the SAME launch
@@ -23,14 +32,17 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries (N = 1, unl
                 run) from it.  The fused kernels keep state in LDS across a launch, so on LONG launches the algorithmic
                 figure exceeds the physical one and 1.0 (noted in the object): their roof is instruction issue --
                 `valu_issue` = PMC SQ_INSTS_VALU of that launch shape / launch time against the MEASURED issue peak
-                (tools/ubench/valu_rate.hip -> profiles/r2_valu_issue_calibration.json)
+                (tools/ubench/valu_rate.hip -> profiles/r*_issue_calibration.json)
+  warmed        the same W + K region again after ~90 ms of device warm-up on a scratch stepper (`value_warmed`)
   steady_state  the same workload in long launches (the regime a rollout worker lives in)
   seeds         the headline region repeated for seeds {0, 1, 2}
   others        the other BASELINE workloads (TicTacToe 5x5 / 3x5 / 3x3x3, Blokus, the Tron 40x40 shard of config 5)
   step_api      the per-step batched API: sample / step(auto_reset) / observe_all / fused step+observe, TicTacToe and
                 Blokus step / valid / observe -- what replaces next_state + state_to_observation in a learner loop
-  cpu_baseline  the C oracle on this box's host cores: one thread and all threads, nproc stated, plus the reference's
-                own Python+Cython path as timed in the build container (it cannot run here)
+  cpu_baseline  the C oracle on this box's host cores at several thread counts (`value` = the best of them, `cores` =
+                its thread count), nproc stated, plus the reference's own Python+Cython path as timed in the build
+                container (it cannot run here)
+  gather        (--gather-probe) the cost of the end-of-rollout collective in a one-rank RCCL group
 """
 import argparse
 import json
@@ -47,7 +59,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec (6.29 
 # fallback issue peak when no calibration file is present: one wave64 VALU instruction per 2 cycles per SIMD-32
 # (MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc"), 256 CUs x 4 SIMDs at 2.4 GHz
 VALU_PEAK_MODEL = 256 * 4 * 2.4e9 / 2
-CALIBRATION = os.path.join(ROOT, "profiles", "r2_valu_issue_calibration.json")
+
+
+def newest_calibration():
+    """profiles/r<N>_*issue_calibration.json of the highest round (tools/ubench/valu_rate.hip), or None."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_*issue_calibration.json")):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return best[1] if best else None
+
+
+CALIBRATION = newest_calibration()
 
 WORKLOADS = {
     # name: (game, kwargs, per-GPU batch, env-steps fused into one launch by default, resident waves per SIMD)
@@ -124,14 +150,25 @@ def make_stepper(game, kw, batch, device, first_env_id):
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=True):
-    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample: every
-    hardware thread (`value`, `cores` = nproc), the 16 threads that are a 1-GPU box's share, and one thread; plus the
-    reference's own Python figure."""
+def cpu_thread_counts(nproc, quick=False):
+    """Thread counts the CPU baseline is timed at: the 16 cores that are a 1-GPU box's share (CRL_CPU_THREADS overrides),
+    every hardware thread the box shows, 32 in between, and one."""
+    share = max(1, min(nproc, int(os.environ.get("CRL_CPU_THREADS", "16"))))
+    counts = [share, nproc] if quick else [share, nproc, min(nproc, 2 * share), 1]
+    out = []
+    for c in counts:
+        if c not in out:
+            out.append(c)
+    return out
+
+
+def cpu_baseline(workload, seconds=6.0, quick=False):
+    """Time the CPU oracle (bit-exact C restatement, oracle/) on this box's host cores on a bounded sample at several
+    thread counts (`cpu_thread_counts`).  `value` = the BEST of them and `cores` = the threads that run used; every
+    count tried is listed as `threads_<n>`; plus the reference's own Python figure."""
     from oracle import oracle as O
     game, kw = WORKLOADS[workload][:2]
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads_all = max(1, min(nproc, int(os.environ.get("CRL_CPU_THREADS", "16"))))    # a 1-GPU box's CPU share is 16 cores
     extra = {}
 
     def runner(B, cores):
@@ -174,15 +211,15 @@ def cpu_baseline(workload, seconds_all=10.0, seconds_one=5.0, with_one_thread=Tr
         T = int(max(4, min(1 << 20, rate * seconds / B)))
         dt = run(T)
         return {"value": B * T / dt, "threads": cores,
-                "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %.1f s" % (B, T, dt)}
+                "sample": "%d games x %d steps, oracle/liboracle.so (C, OpenMP over games), %d threads, %.1f s" % (B, T, cores, dt)}
 
-    allt = timed(nproc, seconds_all)                     # every hardware thread the box shows
-    out = {"value": allt["value"], "unit": "env-steps/s", "cores": nproc, "kind": "port", "sample": allt["sample"],
-           "nproc": nproc, "threads_all": allt}
-    if threads_all != nproc:
-        out["threads_%d" % threads_all] = timed(threads_all, min(seconds_all, 5.0))     # a 1-GPU box's CPU share
-    if with_one_thread:
-        out["threads_1"] = timed(1, seconds_one)
+    counts = cpu_thread_counts(nproc, quick)
+    runs = {c: timed(c, seconds if i == 0 else max(2.0, seconds / 2)) for i, c in enumerate(counts)}
+    best = max(runs.values(), key=lambda r: r["value"])
+    out = {"value": best["value"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port", "sample": best["sample"],
+           "nproc": nproc}
+    for c, r in runs.items():
+        out["threads_%d" % c] = r
     if workload in REFERENCE_PYTHON:
         out["reference_python"] = {"value": REFERENCE_PYTHON[workload], "unit": "env-steps/s", "cores": 1,
                                    "where": "build container (the Python reference cannot travel to the GPU box)",
@@ -214,13 +251,13 @@ def pmc_for(workload, steps_per_launch):
 
 def valu_peaks(waves_per_simd):
     """(chip VALU issue peak, peak at this occupancy, source) in wave64 instructions / s from the calibration ubench."""
-    cal = _load_json(CALIBRATION)
+    cal = _load_json(CALIBRATION) if CALIBRATION else None
     if not cal:
         return VALU_PEAK_MODEL, None, "model: 1 wave64 VALU / 2 cycles / SIMD at 2.4 GHz (no calibration file)"
     rows = {int(r["waves_per_simd"]): r for r in cal["mixes"]["valu"]}
     peak = max(r["valu_wave_insts_per_s"] for r in rows.values())
     w = max(k for k in rows if k <= max(1, waves_per_simd))
-    return peak, rows[w]["valu_wave_insts_per_s"], "measured: profiles/r2_valu_issue_calibration.json (tools/ubench/valu_rate.hip)"
+    return peak, rows[w]["valu_wave_insts_per_s"], "measured: profiles/%s (tools/ubench/valu_rate.hip)" % os.path.basename(CALIBRATION)
 
 
 def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source=None):
@@ -288,19 +325,46 @@ def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
 
 
 # ---------------------------------------------------------------------------------------------- measurements
-def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None):
+class Plumbing:
+    """Device + process-group plumbing of the contract region, so that the same region runs on `cuda` over RCCL (the
+    product) and on `cpu` over gloo (tests/test_bench_contract.py drives it with a CPU stepper in a world of two)."""
+
+    def __init__(self, torch, dist, device, use_dist):
+        self.torch, self.dist, self.device, self.use_dist = torch, dist, device, bool(use_dist)
+        self.cuda = device.type == "cuda"
+        self.world = dist.get_world_size() if self.use_dist else 1
+        self.rank = dist.get_rank() if self.use_dist else 0
+
+    def sync(self):
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.use_dist:
+            self.dist.barrier()
+            self.sync()
+
+    def max_over_ranks(self, values):
+        if not self.use_dist:
+            return [float(v) for v in values]
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+
+def timed_rollout(pl, sr, steps, seed, chunk, events=None, dst=None):
     """The contract's timed region: exactly `steps` env-steps + the gather of the per-game results, bracketed by
     barrier + synchronize on both sides.  The clock stops when THIS rank's work (incl. the collective, which itself waits
     for the other ranks' shards) has completed on the device; the closing barrier follows, and the caller takes the MAX of
     the per-rank times -- the time of the slowest rank, without the latency of the closing barrier itself.
-    `events` = (ev0, ev1) brackets the launches with HIP events on the launch stream (kernel time for the roofline; two
-    hipEventRecord calls = 3.6 us of the region.  Events ATTACHED to the dispatch -- crl_tron_rollout_timed -- give the
-    kernel's own duration, 16.7 us against the 19.7 us between two recorded markers, but that launch path costs the host
-    5 us more: it is used by `dispatch_time_pass`, not here); None
-    leaves them out: next to a collective two timing events cost ~10 us of a ~40 us region (tools/debug/gather_latency.py:
-    39.5 -> 49.0 us in a one-rank RCCL group; 3.6 us without a process group), so runs under a process group measure the
-    launches in a separate pass (`launch_time_pass`)."""
-    barrier()
+    Returns (elapsed s, marker-event s or None, launches, SNAPSHOT of the gathered rows or None): `gather(copy=False)`
+    hands out a live buffer (without a process group the stepper's own rows), so the rows are cloned right after the
+    clock stops -- what the caller reads describes this region even if the stepper is advanced afterwards.
+    `events` = (ev0, ev1) brackets the launches with HIP events on the launch stream (two hipEventRecord calls = 3.6 us
+    of the region; ~10 us next to a collective: tools/debug/gather_latency.py); None leaves them out, and the launches
+    are timed in a separate pass (`launch_time_pass`, `dispatch_time_pass`)."""
+    pl.barrier()
     t0 = time.perf_counter()
     if events:
         events[0].record()                                 # same stream the kernels are launched on
@@ -308,10 +372,26 @@ def timed_rollout(torch, sr, steps, seed, chunk, barrier, events=None, dst=None)
     if events:
         events[1].record()
     gathered = sr.gather(dst=dst, copy=False)              # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
-    torch.cuda.synchronize()
+    pl.sync()
     elapsed = time.perf_counter() - t0
-    barrier()
+    if gathered is not None:
+        gathered = gathered.clone()                        # outside the clock
+    pl.barrier()
     return elapsed, (events[0].elapsed_time(events[1]) * 1e-3 if events else None), launches, gathered
+
+
+def contract_region(pl, sr, steps, warmup, seed, chunk, events=None):
+    """W untimed + exactly K timed steps, as the contract says: the warm-up goes through the very function that is timed
+    (same launch path, gather and barriers), so nothing in the timed region runs for the first time.  Every rank calls
+    this; returns {elapsed (MAX over ranks), elapsed_rank, marker_s, launches, rows (rank 0: snapshot of all games' result
+    rows, else None)}."""
+    dst = 0 if pl.use_dist else None                       # the episode-end gather goes to rank 0
+    if warmup > 0:
+        timed_rollout(pl, sr, warmup, seed, chunk, events, dst)
+    else:
+        sr.gather(dst=dst, copy=False)                     # brings the communicator / receive buffer up outside the clock
+    e, k, n, g = timed_rollout(pl, sr, steps, seed, chunk, events, dst)
+    return {"elapsed": pl.max_over_ranks([e])[0], "elapsed_rank": e, "marker_s": k, "launches": n, "rows": g}
 
 
 def dispatch_time_pass(torch, sr, steps, seed, chunk, events, reps=20):
@@ -342,6 +422,32 @@ def launch_time_pass(torch, sr, steps, seed, chunk, events):
 def mean_episode_len(gathered):
     n_ep = int(gathered[..., 0].sum().item())
     return int(gathered[..., 1].sum().item()) / max(n_ep, 1), n_ep
+
+
+def contract_record(workload, batch, world, steps, warmup, chunk, meas, launch_s, launch_source, copy_gbs, gather_desc):
+    """The contract fields + `roofline` of one measured region (`meas` = contract_region's result on rank 0)."""
+    game, kw = WORKLOADS[workload][:2]
+    mean_len, n_ep = mean_episode_len(meas["rows"])
+    steps_per_launch = min(chunk, steps)
+    elapsed = meas["elapsed"]
+    rec = {
+        "metric": "env-steps/sec", "value": world * batch * steps / elapsed, "unit": "env-steps/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8" if game != "ttt" else "u32", "data": "synthetic",
+        "config": {"workload": workload, "games_per_gpu": batch, "global_games": world * batch,
+                   "steps_per_launch": steps_per_launch, "launches": meas["launches"],
+                   "agent": "uniform random (Philox-4x32-10), auto-reset",
+                   "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
+                   "gather": gather_desc,
+                   "device_warmup": "none: `value` is the first W + K region of the process"},
+        "timed_region_ms": elapsed * 1e3,
+        "roofline": roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source),
+    }
+    if steps % steps_per_launch:
+        # the roofline describes the dominant (first) launch shape; the mean launch time is an approximation then
+        rec["roofline"]["note"] = "launches of the timed region are not equal-sized; launch_ms is their mean"
+    return rec
 
 
 def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
@@ -637,48 +743,128 @@ def world_of_one_gather_us(torch, dist, make, args, steps_per_launch):
         dist.destroy_process_group()
 
 
+def _sig(x, n=4):
+    return None if x is None else float("%.*g" % (n, x))
+
+
 def compact_summary(out):
-    """<= ~1.5 KB of scalars, emitted as the LAST key of the line so that a record that keeps only the tail of stdout
-    still carries every headline number: per workload env-steps/s (v), ms per launch (ms), HBM fraction of 8 TB/s
-    by the contract's formula (alg: algorithmic bytes / launch time; above 1 for long fused launches) and physical (hbm:
-    measured PMC traffic / launch time), VALU issue fraction of the measured peak (valu)."""
-    def sig(x, n=4):
-        return None if x is None else float("%.*g" % (n, x))
+    """~1.5 KB of scalars: per workload env-steps/s (v), ms per launch (ms), HBM fraction of 8 TB/s by the contract's
+    formula (alg: algorithmic bytes / launch time; above 1 for long fused launches) and physical (hbm: measured PMC
+    traffic / launch time), VALU issue fraction of the measured peak (valu), the CPU oracle's best rate (cpu)."""
+    sig = _sig
 
     def wl(rec):
         r = rec.get("roofline", {})
         return {"v": sig(rec.get("value")), "ms": sig(r.get("launch_ms")), "alg": sig(r.get("frac"), 3), "hbm": sig(r.get("physical_frac"), 3),
                 "valu": sig(r.get("valu_issue", {}).get("frac"), 3),
                 "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
-    sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig(out["kernel_ms"] * 1e3),
+    warmed = out.get("warmed") or {}
+    sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig((out.get("kernel_ms") or 0) * 1e3) or None,
                        "kernel_dispatch_us": sig((out.get("kernel_ms_dispatch") or 0) * 1e3) or None,
                        "alg": sig(out["roofline"].get("frac"), 3), "hbm": sig(out["roofline"].get("physical_frac"), 3),
-                       "of_copy": sig(out["roofline"].get("frac_of_copy"), 3), "cold_v": sig(out.get("value_cold")),
-                       "cold_us": sig(out.get("cold_first_region_us")), "gather_us": (out.get("gather") or {}).get("gather_us")}}
+                       "of_copy": sig(out["roofline"].get("frac_of_copy"), 3), "warmed_v": sig(warmed.get("value")),
+                       "warmed_us": sig(warmed.get("timed_region_us")), "gather_us": (out.get("gather") or {}).get("gather_us")}}
     if "steady_state" in out:
         sm[out["config"]["workload"]] = wl(dict(out["steady_state"], cpu_baseline=out.get("cpu_baseline", {})))
     for name, rec in out.get("others", {}).items():
         sm[name] = wl(rec)
     sa = out.get("step_api", {})
-    pick = {"tron_step": "tron_n20_step_auto_reset", "tron_step_lds": "tron_n20_step_staged", "tron_step_observe": "tron_n20_step_observe_fused",
+    pick = {"tron_step": "tron_n20_step_auto_reset", "tron_step_observe": "tron_n20_step_observe_fused",
             "tron_observe_all": "tron_n20_observe_all", "ttt_step_observe": "ttt_3x5_step_observe_fused",
             "blokus_step_observe": "blokus_step_observe_fused", "blokus_valid_list": "blokus_valid_list"}
-    sm["step_api_us"] = {k: sig(sa[v].get("gpu_us_per_call"), 3) for k, v in pick.items() if v in sa}
-    if "tron_n20_step_observe_fused" in sa:
-        sm["step_api_us"]["tron_step_observe_hbm"] = sig(sa["tron_n20_step_observe_fused"].get("frac_of_hbm_peak"), 3)
-    if "dropin" in out:
+    if sa:
+        sm["step_api_us"] = {k: sig(sa[v].get("gpu_us_per_call"), 3) for k, v in pick.items() if v in sa}
+        if "tron_n20_step_observe_fused" in sa:
+            sm["step_api_us"]["tron_step_observe_hbm"] = sig(sa["tron_n20_step_observe_fused"].get("frac_of_hbm_peak"), 3)
+    if "dropin" in out and "error" not in out["dropin"]:
         sm["dropin_us"] = {k: [v["next_state"], v["valid_actions"], v["state_to_observation"], v["new_state"],
                                (v.get("reference_us") or {}).get("next_state")]
                            for k, v in out["dropin"].items() if isinstance(v, dict)}
         sm["dropin_cols"] = "next_state, valid_actions, state_to_observation, new_state, reference next_state"
-    cb = out.get("cpu_baseline", {})
-    if cb:
-        sm["cpu"] = {"nproc": cb.get("nproc"), "all": sig(cb.get("value"), 3), "t16": sig((cb.get("threads_16") or {}).get("value"), 3),
-                     "t1": sig((cb.get("threads_1") or {}).get("value"), 3), "ref_py": (cb.get("reference_python") or {}).get("value")}
     return sm
 
 
-def main():
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+CONFIG_KEYS = ("workload", "games_per_gpu", "global_games", "steps_per_launch", "launches", "mean_episode_len", "episodes",
+               "parallelism", "gather", "device_warmup")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_env_step",
+                 "physical_frac", "frac_of_copy", "valu_frac", "steady_value", "steady_frac", "steady_valu_frac", "note")
+LINE_LIMIT = 4096
+
+
+def compact_line(full):
+    """The ONE stdout line: the contract fields, `config`, `roofline` and `cpu_baseline` as scalars, `summary` -- cut down
+    from the full record `full` (which goes to bench_detail.json).  Always below LINE_LIMIT bytes: if a summary ever
+    outgrows it, the summary's optional sections are dropped, never a contract field."""
+    line = {k: full[k] for k in CONTRACT_KEYS}
+    line["value"] = _sig(full["value"], 6)
+    line["ms_per_step"] = _sig(full["ms_per_step"], 6)
+    line["config"] = {k: full["config"][k] for k in CONFIG_KEYS if k in full["config"]}
+    r = dict(full["roofline"])
+    r["valu_frac"] = (r.get("valu_issue") or {}).get("frac")
+    if r.get("note"):
+        r["note"] = r["note"][:120]
+    line["roofline"] = {k: (_sig(r[k], 5) if isinstance(r[k], float) else r[k]) for k in ROOFLINE_KEYS if r.get(k) is not None}
+    line["roofline"].setdefault("traffic", None)
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {"value": _sig(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:140],
+             "nproc": cb.get("nproc")}
+        for k, v in cb.items():
+            if k.startswith("threads_") and isinstance(v, dict):
+                c[k] = _sig(v["value"], 4)
+        if cb.get("reference_python"):
+            c["reference_python"] = cb["reference_python"]["value"]
+        line["cpu_baseline"] = c
+    for k in ("value_warmed", "placement_tests_per_s", "detail"):
+        if full.get(k) is not None:
+            line[k] = _sig(full[k], 5) if isinstance(full[k], float) else full[k]
+    line["summary"] = compact_summary(full)
+    for drop in ("dropin_cols", "dropin_us", "step_api_us"):
+        if len(json.dumps(line)) < LINE_LIMIT - 96:
+            break
+        line["summary"].pop(drop, None)
+    return line
+
+
+def emit(full, out=None, detail_paths=None):
+    """Write the full record to the detail files and to stderr (one line), then the compact line -- the only thing that
+    ever goes to stdout -- to `out`."""
+    out = out or sys.stdout
+    written = []
+    for path in (detail_paths if detail_paths is not None else default_detail_paths()):
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(os.path.relpath(path, ROOT))
+        except OSError:
+            pass
+    full["detail"] = written[0] if written else "stderr"
+    line = json.dumps(compact_line(full))
+    assert len(line) < LINE_LIMIT, len(line)
+    sys.stderr.write("bench detail: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    out.write(line + "\n")
+    out.flush()
+    return line
+
+
+def default_detail_paths():
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    return paths
+
+
+def fail(msg, code=2):
+    """A run that cannot measure what it was asked to: one JSON line on stdout naming the cause, non-zero exit."""
+    sys.stdout.write(json.dumps({"error": msg}) + "\n")
+    sys.stdout.flush()
+    sys.exit(code)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=65536)
@@ -688,27 +874,86 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="env-steps fused into one kernel launch (default: the workload's)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-device-warmup", action="store_true",
-                    help="report the FIRST W + K region of the process as `value` (no device warm-up in between)")
-    ap.add_argument("--only-headline", action="store_true", help="skip steady_state / seeds / others / step_api / dropin (profiling runs)")
+    ap.add_argument("--device-warmup", action="store_true",
+                    help="with --only-headline: also run the W + K region again after ~90 ms of device warm-up (`value_warmed`; "
+                         "the full run always does).  `value` is the first W + K region of the process either way")
+    ap.add_argument("--gather-probe", action="store_true",
+                    help="single process only: afterwards, create a one-rank RCCL group and time the region with / without the gather")
+    ap.add_argument("--only-headline", action="store_true", help="skip warmed / steady_state / seeds / others / step_api / dropin (profiling runs)")
     ap.add_argument("--only-step-api", action="store_true", help="run just the per-step API section (profiling runs)")
     ap.add_argument("--only-dropin", action="store_true", help="run just the single-state drop-in latency section")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launcher_env():
+    """(under a launcher?, world, rank, local rank) from the environment torch.distributed.run sets."""
+    under = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR"))
+    return under, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def self_launch(args, argv):
+    """`--gpus N` with N > 1 and no launcher: start N ranks of this script under torch.distributed.run as a CHILD process
+    (this process has not touched the GPU: counting devices does not initialise it), pass its stdout / stderr through and
+    return its exit code.  Fewer than N visible devices is an error, never a smaller measurement."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        fail("--gpus %d but only %d GPU(s) visible to this process: refusing to measure fewer GPUs than asked for" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
+
+
+def device_warmup(torch, make_scratch, steps_per_launch, seed):
+    """~60 ms of large device copies, then ~30 ms of launches of the timed region's shape on a SCRATCH stepper (other
+    memory, other games): the memory clocks follow sustained HBM traffic, which 20-us launches with a synchronise between
+    them are not.  Returns the milliseconds spent.  Never part of `value`."""
+    t_dev = time.perf_counter()
+    blob = torch.empty((256 << 20,), dtype=torch.uint8, device="cuda")
+    while time.perf_counter() - t_dev < 0.06:
+        blob[: 128 << 20].copy_(blob[128 << 20:])
+        torch.cuda.synchronize()
+    del blob
+    scratch = make_scratch()
+    t_launch = time.perf_counter()
+    while time.perf_counter() - t_launch < 0.03:
+        scratch.rollout(steps_per_launch, seed)
+        torch.cuda.synchronize()
+    del scratch
+    return (time.perf_counter() - t_dev) * 1e3
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    under_launcher, world, rank, local_rank = launcher_env()
+    if under_launcher and args.gpus != world:
+        if rank == 0:
+            fail("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+        sys.exit(2)
+    if not under_launcher and (args.gpus > 1 or os.environ.get("CRL_BENCH_SELF_LAUNCH") == "1"):
+        sys.exit(self_launch(args, argv))           # (the variable forces the N > 1 start-up path at N = 1: tests on a 1-GPU box)
+    if args.gpus < 1:
+        fail("--gpus must be >= 1")
 
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if torch.cuda.device_count() < 1:
+        fail("no GPU visible to this process (torch.cuda.device_count() == 0): bench.py measures the HIP path only, there is no CPU fallback")
     torch.cuda.set_device(local_rank if under_launcher else 0)
     if under_launcher:                                     # also for a world of ONE rank: the RCCL path is the same code
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
-    use_dist = dist.is_initialized()
+    pl = Plumbing(torch, dist, device, dist.is_initialized())
+    assert pl.world == world and pl.rank == rank
 
     if args.only_dropin:
         print(json.dumps({"dropin": dropin_latencies()}))
@@ -730,17 +975,7 @@ def main():
         return make_stepper(game, kw, batch, device, first_env_id)
     # weak scaling: every rank owns `batch` games; global ids rank*batch .. (rank+1)*batch - 1
     sr = ShardedRollout(make, world * batch)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     steps_per_launch = min(args.chunk, args.steps)
-    # The W warm-up steps go through the very function that is timed afterwards (same events, launch path, gather and
-    # barriers), so nothing in the timed region runs for the first time (HIP events are created lazily at first record,
-    # code objects are loaded at first launch, the RCCL communicator comes up at the first collective).
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     for e in events:
         e.record()                                         # creates the HIP events (torch does so lazily)
@@ -750,121 +985,66 @@ def main():
     # N = 1 only would skew the scaling curve the driver derives from these lines.  The launches are timed in further
     # regions of the same shape right after (`launch_time_pass`: recorded markers; `dispatch_time_pass`: events attached
     # to the dispatch).  CRL_BENCH_REGION_EVENTS=1 puts the markers back into the region (single process only).
-    region_events = events if (not use_dist and os.environ.get("CRL_BENCH_REGION_EVENTS") == "1") else None
-    dst = 0 if use_dist else None                          # the episode-end gather goes to rank 0
+    region_events = events if (not pl.use_dist and os.environ.get("CRL_BENCH_REGION_EVENTS") == "1") else None
 
-    def contract_region():
-        """W untimed + K timed steps, exactly as the contract says; returns the timed region's measurements."""
-        if args.warmup > 0:
-            timed_rollout(torch, sr, args.warmup, args.seed, args.chunk, barrier, region_events, dst)
-        else:
-            sr.gather(dst=dst, copy=False)
-        e, k, n, g = timed_rollout(torch, sr, args.steps, args.seed, args.chunk, barrier, region_events, dst)
-        if k is None:
-            k = launch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events)
-        return e, k, n, g
-
-    # (1) COLD: the first W + K region of this process, on a box that has just been handed over (memory clocks at idle).
-    cold = contract_region()
-    # (2) Device warm-up on a SCRATCH stepper (other memory, other games), then W + K again = `value`.  The memory clocks
-    # follow sustained HBM traffic, which 20-us launches with a synchronise between them are not: ~60 ms of large device
-    # copies, then ~30 ms of launches of the timed region's own shape.  Not part of W or K; `value_cold` / `cold_first_region_us`
-    # above is the same region without it, `--no-device-warmup` makes that one the headline.
-    device_warmup_ms = 0.0
-    if args.no_device_warmup:
-        elapsed, kernel_s, launches, gathered = cold
-    else:
-        t_dev = time.perf_counter()
-        blob = torch.empty((256 << 20,), dtype=torch.uint8, device=device)
-        while time.perf_counter() - t_dev < 0.06:
-            blob[: 128 << 20].copy_(blob[128 << 20:])
-            torch.cuda.synchronize()
-        del blob
-        scratch = make_stepper(game, kw, batch, device, 0)
-        t_launch = time.perf_counter()
-        while time.perf_counter() - t_launch < 0.03:
-            scratch.rollout(steps_per_launch, args.seed)
-            torch.cuda.synchronize()
-        del scratch
-        device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
-        sr.stepper.reset()
-        sr.stepper.reset_stats()
-        elapsed, kernel_s, launches, gathered = contract_region()
-    cold_elapsed = cold[0]
+    # ---- THE measurement: the first W + K region of the process.  Everything below it is evidence around it.
+    meas = contract_region(pl, sr, args.steps, args.warmup, args.seed, args.chunk, region_events)
+    kernel_s = meas["marker_s"]
+    if kernel_s is None:
+        kernel_s = launch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events)
     kernel_dispatch_s = dispatch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events) if args.steps <= 4096 else None
-    if use_dist:
-        tt = torch.tensor([elapsed, cold_elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, cold_elapsed = float(tt[0].item()), float(tt[1].item())
     if rank == 0:
-        mean_len, n_ep = mean_episode_len(gathered)
         copy_gbs, write_gbs = measure_copy_bandwidth(torch, device) if world == 1 else (None, None)
-        value = world * batch * args.steps / elapsed
-        # launches of the timed region are equal-sized when steps % chunk == 0; otherwise the roofline describes the
-        # dominant (first) launch shape and uses the mean launch time only as an approximation -- flagged below
-        equal = (args.steps % steps_per_launch) == 0
         # The launch's duration for the roofline: HIP events ATTACHED to the dispatch (the kernel's own begin -> end, median
         # of 20 isolated regions of the timed shape) where the stepper offers them -- that is the figure rocprofv3's
-        # --stats average for the kernel agrees with (profiles/r3_tron_n20_t20_*: 18.05 us back to back); two RECORDED
-        # marker events around the launch also see the gap between the first marker and the kernel's start (~3-5 us on a
-        # 20-us launch).  Both are in the line (`kernel_ms_dispatch`, `kernel_ms`).
+        # --stats average for the kernel agrees with; two RECORDED marker events around the launch also see the gap
+        # between the first marker and the kernel's start (~3-5 us on a 20-us launch).  Both are in the detail record.
+        launches = meas["launches"]
         launch_s = kernel_s / launches
         launch_source = "HIP marker events recorded around the launches of " + ("the timed region" if region_events else "one more region of the timed shape")
         if kernel_dispatch_s and launches == 1:
             launch_s = kernel_dispatch_s
             launch_source = ("HIP events attached to the dispatch (hipExtLaunchKernel start / stop), median of 20 isolated regions of the "
                              "timed shape; marker events recorded around such a launch: %.2f us" % (kernel_s * 1e6))
-        row_bytes = int(gathered.shape[-1] * gathered.element_size())
-        out = {
-            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8" if game != "ttt" else "u32", "data": "synthetic",
-            "config": {"workload": args.workload, "games_per_gpu": batch, "global_games": world * batch,
-                       "steps_per_launch": steps_per_launch, "launches": launches,
-                       "agent": "uniform random (Philox-4x32-10), auto-reset",
-                       "mean_episode_len": round(mean_len, 3), "episodes": n_ep, "parallelism": "dp%d" % world,
-                       "gather": ("rccl gather to rank 0 (torch.distributed.gather), %d-byte rows" % row_bytes) if use_dist
-                                 else "none (single process, no process group)",
-                       "device_warmup": ("none: `value` is the first W + K region of the process" if args.no_device_warmup else
-                                         "%.0f ms of device copies + launches on a scratch stepper between the cold region and W + K "
-                                         "(value_cold = the same region before it)" % device_warmup_ms)},
-            "timed_region_ms": elapsed * 1e3, "kernel_ms": kernel_s * 1e3,
-            "kernel_ms_source": ("HIP marker events around the launches of the timed region" if region_events else
-                                 "HIP marker events around the launches of one more region of the same shape, right after the timed "
-                                 "one (two event records cost 3.6 us of the region, ~10 us next to a collective: not recorded inside it)"),
-            "device_warmup_ms": round(device_warmup_ms, 1),
-            "kernel_ms_dispatch": kernel_dispatch_s * 1e3 if kernel_dispatch_s else None,
-            "value_cold": world * batch * args.steps / cold_elapsed, "cold_first_region_us": cold_elapsed * 1e6,
-            "cold_kernel_us": cold[1] * 1e6,
-            "roofline": roofline(args.workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source),
-        }
-        if not equal:
-            out["roofline"]["note"] = "launches of the timed region are not equal-sized; launch_ms is their mean"
-        if world == 1 and not args.only_headline:
+        row_bytes = int(meas["rows"].shape[-1] * meas["rows"].element_size())
+        gather_desc = ("rccl gather to rank 0 (torch.distributed.gather), %d-byte rows" % row_bytes) if pl.use_dist \
+            else "none (single process, no process group)"
+        out = contract_record(args.workload, batch, world, args.steps, args.warmup, args.chunk, meas, launch_s, launch_source,
+                              copy_gbs, gather_desc)
+        out.update({"kernel_ms": kernel_s * 1e3, "kernel_ms_dispatch": kernel_dispatch_s * 1e3 if kernel_dispatch_s else None,
+                    "kernel_ms_source": ("HIP marker events around the launches of the timed region" if region_events else
+                                         "HIP marker events around the launches of one more region of the same shape, right after the timed "
+                                         "one (two event records cost 3.6 us of the region, ~10 us next to a collective: not recorded inside it)")})
+        full_run = world == 1 and not args.only_headline
+        if world == 1 and (full_run or args.device_warmup):
+            ms = device_warmup(torch, lambda: make_stepper(game, kw, batch, device, 0), steps_per_launch, args.seed)
+            sr.stepper.reset()
+            sr.stepper.reset_stats()
+            w = contract_region(pl, sr, args.steps, args.warmup, args.seed, args.chunk, region_events)
+            out["warmed"] = {"value": batch * args.steps / w["elapsed"], "timed_region_us": w["elapsed"] * 1e6,
+                             "device_warmup_ms": round(ms, 1), "mean_episode_len": round(mean_episode_len(w["rows"])[0], 3),
+                             "what": "the same W + K region again after device copies + launches on a scratch stepper; NOT `value`"}
+            out["value_warmed"] = out["warmed"]["value"]
+        if full_run:
             seeds = {}
             for sd in (0, 1, 2):                            # SURVEY 8(d): seeds {0, 1, 2}, same timed region
                 sr.stepper.reset()
                 sr.stepper.reset_stats()
-                if args.warmup > 0:
-                    timed_rollout(torch, sr, args.warmup, sd, args.chunk, barrier, region_events, dst)
-                e, _, _, g = timed_rollout(torch, sr, args.steps, sd, args.chunk, barrier, region_events, dst)
-                seeds[str(sd)] = {"value": batch * args.steps / e, "mean_episode_len": round(mean_episode_len(g)[0], 3)}
+                m = contract_region(pl, sr, args.steps, args.warmup, sd, args.chunk, region_events)
+                ml, ne = mean_episode_len(m["rows"])
+                seeds[str(sd)] = {"value": batch * args.steps / m["elapsed"], "mean_episode_len": round(ml, 3), "episodes": ne}
             vals = [v["value"] for v in seeds.values()]
             seeds["spread"] = (max(vals) - min(vals)) / (sum(vals) / len(vals))
             out["seeds"] = seeds
             out["steady_state"] = steady_state(torch, args.workload, device, args.seed, copy_gbs)
-            # the steady-state figures of the headline workload as scalars of `roofline` too (scalars there survive into
-            # records that keep only part of the line)
             ssr = out["steady_state"]["roofline"]
             out["roofline"].update({"steady_value": out["steady_state"]["value"], "steady_launch_ms": ssr["launch_ms"],
                                     "steady_frac": ssr["frac"], "steady_physical_frac": ssr["physical_frac"],
                                     "steady_valu_frac": ssr.get("valu_issue", {}).get("frac")})
             others = {}
             for wl in WORKLOADS:
-                if wl == args.workload:
-                    continue
-                others[wl] = steady_state(torch, wl, device, args.seed, copy_gbs)
+                if wl != args.workload:
+                    others[wl] = steady_state(torch, wl, device, args.seed, copy_gbs)
             out["others"] = others
             out["step_api"] = step_api_rates(torch, device, copy_gbs, write_gbs)
             out["stream_peaks"] = {"copy_GBs": copy_gbs, "write_GBs": write_gbs,
@@ -876,49 +1056,34 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
             if "placement_tests_per_env_step" in out["cpu_baseline"]:
-                out["placement_tests_per_s"] = value * out["cpu_baseline"]["placement_tests_per_env_step"]
-            if "others" in out:
-                for wl, rec in out["others"].items():
-                    rec["cpu_baseline"] = cpu_baseline(wl, seconds_all=3.0, with_one_thread=False)
-                    if "placement_tests_per_env_step" in rec["cpu_baseline"]:
-                        # reference-equivalent work: placements the reference's loops test per env-step (counted by the
-                        # oracle on its sample) x the GPU's env-steps/s; the HIP kernel fits whole shapes instead
-                        rec["placement_tests_per_s"] = rec["value"] * rec["cpu_baseline"]["placement_tests_per_env_step"]
-        # the collective's cost in a world of one rank, to read a multi-GPU record against
-        if world == 1 and game == "tron":
-            try:
-                if use_dist:
-                    ts = []
-                    for with_gather in (False, True, False, True):
-                        tt = []
-                        for _ in range(40):
-                            torch.cuda.synchronize()
-                            t0 = time.perf_counter()
-                            sr.rollout(steps_per_launch, args.seed, steps_per_launch)
-                            if with_gather:
-                                sr.gather(dst=0, copy=False)
-                            torch.cuda.synchronize()
-                            tt.append(time.perf_counter() - t0)
-                        ts.append(sorted(tt)[20] * 1e6)
-                    out["gather"] = {"gather_us": round(min(ts[1], ts[3]) - min(ts[0], ts[2]), 2), "region_us": round(min(ts[1], ts[3]), 2),
-                                     "region_no_gather_us": round(min(ts[0], ts[2]), 2), "what": "this run's own one-rank RCCL group"}
-                elif not args.only_headline:
-                    out["gather"] = world_of_one_gather_us(torch, dist, make, args, steps_per_launch)
-            except Exception as exc:                        # never fatal for the bench line
+                out["placement_tests_per_s"] = out["value"] * out["cpu_baseline"]["placement_tests_per_env_step"]
+            for wl, rec in out.get("others", {}).items():
+                rec["cpu_baseline"] = cpu_baseline(wl, seconds=3.0, quick=True)
+                if "placement_tests_per_env_step" in rec["cpu_baseline"]:
+                    # reference-equivalent work: placements the reference's loops test per env-step (counted by the
+                    # oracle on its sample) x the GPU's env-steps/s; the HIP kernel fits whole shapes instead
+                    rec["placement_tests_per_s"] = rec["value"] * rec["cpu_baseline"]["placement_tests_per_env_step"]
+        if world == 1 and not pl.use_dist and args.gather_probe and game == "tron":
+            try:                                            # creates (and destroys) a one-rank RCCL group: behind a flag
+                out["gather"] = world_of_one_gather_us(torch, dist, make, args, steps_per_launch)
+            except Exception as exc:
                 out["gather"] = {"error": repr(exc)[:300]}
-        out["summary"] = compact_summary(out)               # LAST key: survives a record that keeps only the tail of stdout
-        print(json.dumps(out))
-    if use_dist and dist.is_initialized():
+        emit(out)
+    if pl.use_dist and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    # stdout carries the JSON line(s) and nothing else: libraries that write to file descriptor 1 behind Python's back
-    # (RCCL prints a version banner when its communicator comes up) are sent to stderr for the duration
-    sys.stdout.flush()
-    _real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    sys.stdout = os.fdopen(_real_stdout, "w")
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 behind Python's back
+    # (RCCL prints a version banner when its communicator comes up) are sent to stderr for the duration.  A self-launch
+    # (--gpus N > 1 without a launcher) happens inside main() before anything is imported that could write there, and its
+    # child does this redirection itself, so the parent's descriptor 1 is passed through untouched.
+    _under, _, _, _ = launcher_env()
+    if _under or (parse_args().gpus <= 1 and os.environ.get("CRL_BENCH_SELF_LAUNCH") != "1"):
+        sys.stdout.flush()
+        _real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(_real_stdout, "w")
     main()
     sys.stdout.flush()

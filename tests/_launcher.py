@@ -3,7 +3,8 @@
 tests/conftest.py starts this helper at session start, i.e. before the pytest process has initialised the GPU.  The helper
 never touches the GPU itself; it only forks + execs the commands it is sent.  That keeps every exec out of processes that
 hold a GPU context (on the GPU pool an exec from such a process is refused).  Protocol: one JSON object per line on stdin
-({"cmd": [...], "env": {...}, "cwd": ..., "timeout": s}), one per line on stdout ({"rc": int, "out": str}).
+({"cmd": [...], "env": {...}, "cwd": ..., "timeout": s, "split": bool}), one per line on stdout ({"rc": int, "out": str};
+with "split" stderr is kept apart from stdout and returned as "err").
 The text "@FREE_PORT@" in an argument or an environment value is replaced by a TCP port that was free a moment ago (one
 port per request), so a leftover of an earlier session cannot make a rendezvous fail with EADDRINUSE.  A command runs in
 its own session; on timeout the WHOLE process group is killed (torch.distributed.run is an agent whose rank process would
@@ -36,11 +37,14 @@ def main():
         if env is not None:
             env = {k: v.replace("@FREE_PORT@", port) for k, v in env.items()}
         try:
-            p = subprocess.Popen(cmd, env=env, cwd=req.get("cwd"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                 text=True, start_new_session=True)
+            split = bool(req.get("split"))
+            p = subprocess.Popen(cmd, env=env, cwd=req.get("cwd"), stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE if split else subprocess.STDOUT, text=True, start_new_session=True)
             try:
-                out, _ = p.communicate(timeout=req.get("timeout", 600))
+                out, err = p.communicate(timeout=req.get("timeout", 600))
                 rep = {"rc": p.returncode, "out": out[-20000:]}
+                if split:
+                    rep["err"] = (err or "")[-20000:]
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(p.pid, signal.SIGKILL)

@@ -47,15 +47,17 @@ def pytest_sessionfinish(session, exitstatus):
 
 @pytest.fixture(scope="session")
 def run_fresh():
-    """run_fresh(cmd, env=None, cwd=None, timeout=600) -> (returncode, output): runs `cmd` in a fresh process started by
+    """run_fresh(cmd, env=None, cwd=None, timeout=600, split=False) -> (returncode, output[, stderr]): runs `cmd` in a fresh process started by
     tests/_launcher.py, a helper forked at session start, BEFORE this process touched the GPU (see its docstring)."""
     import json
 
-    def run(cmd, env=None, cwd=None, timeout=600):
+    def run(cmd, env=None, cwd=None, timeout=600, split=False):
         assert _launcher is not None and _launcher.poll() is None, "tests/_launcher.py is not running"
-        _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "cwd": cwd, "timeout": timeout}) + "\n")
+        _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "cwd": cwd, "timeout": timeout, "split": split}) + "\n")
         _launcher.stdin.flush()
         rep = json.loads(_launcher.stdout.readline())
+        if split:                                       # (returncode, stdout alone, stderr)
+            return rep["rc"], rep["out"], rep.get("err", "")
         return rep["rc"], rep["out"]
     return run
 

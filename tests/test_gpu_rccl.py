@@ -78,3 +78,57 @@ def test_bench_under_torchrun_world_of_one(run_fresh):
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["config"]["gather"].startswith("rccl") and rec["value"] > 1e8
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly ONE line, got %d: %r" % (len(lines), stdout[:2000])
+    assert len(lines[0]) < 4096
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_driver_style_line(run_fresh):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's N = 1 command, minus the slow evidence sections):
+    stdout is ONE compact line; its episodes / mean_episode_len describe the W + K = 25 steps that were timed -- not the
+    hundreds of steps the later timing passes add to the stepper (round 3's live-buffer bug: 3.1e6 episodes, 9.25)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--only-headline",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}
+    rc, out, err = run_fresh(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, timeout=600, split=True)
+    assert rc == 0, err[-3000:]
+    rec = _one_json_line(out)
+    assert rec["n_gpus"] == 1 and rec["steps"] == 20 and rec["warmup"] == 5 and rec["config"]["gather"].startswith("none")
+    assert rec["config"]["workload"] == "tron_p4_n20_b65536" and rec["config"]["global_games"] == 65536
+    assert 1.5e5 < rec["config"]["episodes"] <= 65536 * 25 // 2
+    assert abs(rec["config"]["mean_episode_len"] - 8.45) < 0.1
+    assert rec["value"] == pytest.approx(65536 * 20 / (rec["ms_per_step"] * 20 * 1e-3), rel=1e-4) and rec["value"] > 1e9
+    r = rec["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "tron_rollout_quad_kernel" and 0.3 < r["frac"] < 1.2
+    assert r["achieved"] == pytest.approx(r["bytes_per_env_step"] * 65536 * 20 / (r["launch_ms"] * 1e-3) / 1e9, rel=1e-3)
+    assert "RCCL" not in err and "NCCL version" not in err      # the contract run creates no process group
+
+
+def test_bench_self_launch_runs_ranks_under_rccl(run_fresh):
+    """`--gpus N` without a launcher starts N ranks under torch.distributed.run as a child process (CRL_BENCH_SELF_LAUNCH=1
+    forces that path at N = 1 on this one-GPU box): one line, n_gpus = the ranks RCCL saw, the gather inside the region."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--only-headline",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}
+    rc, out, err = run_fresh(cmd, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0", CRL_BENCH_SELF_LAUNCH="1"), cwd=ROOT, timeout=600, split=True)
+    assert rc == 0, err[-3000:]
+    rec = _one_json_line(out)
+    assert rec["n_gpus"] == 1 and rec["config"]["gather"].startswith("rccl") and rec["config"]["parallelism"] == "dp1"
+    assert "torch.distributed.run" in err
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails(run_fresh):
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with one GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "LOCAL_RANK")}
+    rc, out, err = run_fresh([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                             env=env, cwd=ROOT, timeout=300, split=True)
+    assert rc != 0
+    rec = _one_json_line(out)
+    assert "value" not in rec and "--gpus 2" in rec["error"]
