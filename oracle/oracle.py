@@ -16,11 +16,16 @@ TAG_TRON, TAG_TTT, TAG_BLOKUS = 0x54520000, 0x54540000, 0x424C0000
 
 
 def build(force=False):
-    so = os.path.join(HERE, "liboracle.so")
+    """Build (when stale) and return the library to load: liboracle.so, or the Makefile target named by ORACLE_LIB
+    (`liboracle_asan.so`: the ASan + UBSan build tests/test_oracle_asan.py runs the fixtures through)."""
+    target = os.path.basename(os.environ.get("ORACLE_LIB") or "liboracle.so")
+    if target not in ("liboracle.so", "liboracle_asan.so"):
+        raise ValueError("ORACLE_LIB must name a target of oracle/Makefile, got %r" % target)
+    so = os.path.join(HERE, target)
     srcs = [os.path.join(HERE, f) for f in ("crl_oracle.c", "blokus_oracle.c", "crl_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", HERE, "-B", target], stdout=subprocess.DEVNULL)
     return so
 
 
