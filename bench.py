@@ -608,6 +608,9 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     wall, gpu = rate(lambda: bb.select(rk), 50)
     out["blokus_select"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "what": "the r-th legal action for caller-chosen ranks"}
     act = bb.sample(5, advance=False)
+    if hasattr(bb, "is_valid"):
+        wall, gpu = rate(lambda: bb.is_valid(act), 50)
+        out["blokus_is_valid"] = {"games_per_s": Bb / wall, "gpu_us_per_call": gpu * 1e6, "what": "is_valid_action of one dense id per game, no enumeration"}
     occ0, inv0, sc0, rd0, tm0 = bb.occ.clone(), bb.inv.clone(), bb.score.clone(), bb.round.clone(), bb.to_move.clone()
 
     def bstep():

@@ -63,7 +63,7 @@ const int8_t kPieces[NPIECE][5][2] = {
     {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}},
     {{0, 0}, {1, 0}, {1, -1}, {2, 0}, {3, 0}},
 };
-const int8_t kPieceCells[NPIECE] = {1, 2, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+constexpr int8_t kPieceCells[NPIECE] = {1, 2, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
 
 // device-resident tables, staged into LDS by every workgroup
 struct BlkTables {
@@ -1281,86 +1281,177 @@ blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const u
 // ---- the ordered legal-action list, compacted (what BlokusEnvironment.valid_actions returns, :453-500) -------------------
 // count[b] and ids[b][0 .. min(count, cap)) = the dense ids of every legal action of `player` in ascending order, which is
 // the reference's order (piece -> anchor row-major -> orientation -> shift, board.py:184-189).
-// Per piece one lane per (orientation, shift) pair, as in blk_select: lane o * n + j fits orientation o with its cell j on
-// the anchors of a row -- five reads of the padded allowed rows, five shifts, three ANDs give the row's legal anchors of the
-// pair as a bit mask --, and per anchor of the row one ballot lines the legal pairs up in reference order: a legal lane's
-// place in the list is the running total plus the legal lanes below it (v_mbcnt), its id the anchor's base id plus 5 o + j.
-// (The first version, earlier in round 3, built a fit table per piece and then gave every ANCHOR a lane that ran 8 n
-// dependent pairs of LDS reads and a loop over its set bits: ~1,100 dependent LDS round trips per list, 296 us for 16,384
-// mid-game positions; the rows of a piece are independent here.)
-__global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
+//
+// Round 4 formulation: WINDOW x PATTERN.  Whether (piece, orientation o, shift j) is legal on anchor a depends only on the
+// 9 x 9 neighbourhood of a in the player's `allowed` mask: every cell of the oriented shape, moved so that its cell j lies
+// on a, must be allowed, and no cell is further than 4 from another.  So
+//   * once per call every anchor gets its window: 81 bits of NOT-allowed in three words (rows -4..-2, -1..1, 2..4 of nine
+//     bits each), plus the anchor's part of the dense id -- 16 bytes per anchor in LDS (WaveLds::u.sh, free here);
+//   * a table built at context creation holds, for every (piece, o, j), the 81-bit pattern of the cells relative to cell j
+//     and the (piece, o, j) part of the id -- 16 bytes each, 13 KB, staged in LDS per workgroup;
+//   * a candidate is legal iff (window & pattern) == 0: v_and + 2 v_and_or + v_cmp.
+// The candidates of a piece are enumerated in output order -- anchor, o, j -- 64 at a time: a unit of n passes (n = cells of
+// the piece) covers 8 anchors x 8 orientations x n shifts, so a lane's (o, j) and its anchor slot are fixed per (piece, pass
+// of the unit) and its pattern sits in registers for the whole piece.  A legal lane's place in the list is the running
+// total plus the legal lanes below it (ballot + v_mbcnt), and ONE store per pass writes them: a raw buffer store whose
+// descriptor ends at `cap` entries, so the hardware drops what does not fit (and everything when ids is NULL).
+// (Round 3: lanes = (o, j), bit-parallel over the columns of an anchor row, then one ballot PER ANCHOR: 4,600 VALU + 2,900
+// SALU per list, issue-bound at 157 us for 16,384 mid-game positions -- profiles/r4_step_api_*; the count pass it started
+// with is gone too: the list counts itself.)
+constexpr int BLK_WT = 128;                                  // anchors per chunk of the window table (2 KB of WaveLds::u)
+static_assert(BLK_WT * sizeof(uint4) <= sizeof(WaveLds::u), "window table must fit the pre-shifted table's space");
+
+// cells per piece, 3 bits each (a wave-uniform shift instead of a table read)
+constexpr unsigned long long blk_ncell_packed()
+{
+    unsigned long long v = 0;
+    for (int p = 0; p < NPIECE; ++p) v |= (unsigned long long)kPieceCells[p] << (3 * p);
+    return v;
+}
+
+struct BlkPatterns { uint32_t e[NPIECE * 40][4]; };          // [piece * 40 + o * n + j] = {rows -4..-2, -1..1, 2..4, id part}
+constexpr size_t BLK_PAT_OFFSET = (sizeof(BlkTables) + 15) & ~(size_t)15;
+
+// false when a shape's cells do not fit a 9 x 9 window around each other (cannot happen with the 21 pieces)
+bool build_patterns(const BlkTables &t, BlkPatterns &pt)
+{
+    memset(&pt, 0xff, sizeof(pt));                           // unused slots: bit 31 is set in every window word -> never legal
+    for (int p = 0; p < NPIECE; ++p)
+        for (int o = 0; o < 8; ++o) {
+            const int n = t.ncell[p];
+            for (int j = 0; j < n; ++j) {
+                uint32_t w[3] = {0u, 0u, 0u};
+                const int jx = t.cells[p * 8 + o][j] & 15, jy = t.cells[p * 8 + o][j] >> 4;
+                for (int c = 0; c < n; ++c) {
+                    const int dx = (t.cells[p * 8 + o][c] & 15) - jx, dy = (t.cells[p * 8 + o][c] >> 4) - jy;
+                    if (dx < -4 || dx > 4 || dy < -4 || dy > 4) return false;
+                    const int idx = (dy + 4) * 9 + (dx + 4);
+                    w[idx / 27] |= 1u << (idx % 27);
+                }
+                uint32_t *e = pt.e[p * 40 + o * n + j];
+                e[0] = w[0]; e[1] = w[1]; e[2] = w[2];
+                e[3] = (uint32_t)(p * 16000 + o * 5 + j);
+            }
+        }
+    return true;
+}
+
+// window table entries [0, round-up-to-8 of the chunk's anchors) for the anchors [lo, lo + BLK_WT) of the player
+__device__ __forceinline__ void blk_list_windows(WaveLds &L, uint4 *Wt, const int q, const int lane, const uint32_t crow,
+                                                 const uint32_t row_start, const int lo, const int n_c)
+{
+    uint32_t *Ww = reinterpret_cast<uint32_t *>(Wt);
+    // lane y < 20 hands out its row's anchors: entry k gets (x, y) in its fourth word for now
+    uint32_t m = crow, idx = row_start;
+    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+        if (m != 0u) {
+            const int ax = __builtin_ctz(m);
+            m &= m - 1u;
+            const uint32_t k = idx - (uint32_t)lo;
+            if (k < (uint32_t)BLK_WT) Ww[k * 4 + 3] = (uint32_t)ax | ((uint32_t)lane << 8);
+            idx += 1u;
+        }
+    }
+    wave_sync();
+    const int padded = (n_c + 7) & ~7;
+#pragma unroll
+    for (int h = 0; h < BLK_WT / 64; ++h) {
+        const int k = h * 64 + lane;
+        if (k < n_c) {
+            const uint32_t xy = Ww[k * 4 + 3];
+            const int ax = (int)(xy & 0xffu), ay = (int)(xy >> 8);
+            uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int dy = 0; dy < 9; ++dy) {             // ac[q][y + 4] holds row y << 8: window column dx is bit ax + dx + 8
+                const uint32_t row = L.ac[q][ay + dy].x;
+                w[dy / 3] |= ((row >> (ax + 4)) & 0x1ffu) << (9 * (dy % 3));
+            }
+            Wt[k] = make_uint4(~w[0], ~w[1], ~w[2], (uint32_t)((ay * BN + ax) * 40));
+        } else if (k < padded) {
+            Wt[k] = make_uint4(~0u, ~0u, ~0u, 0u);       // the tail of the last unit of 8: never legal
+        }
+    }
+    wave_sync();
+}
+
+__global__ void __launch_bounds__(256, 5)
 blokus_list_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
                    const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
                    const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
                    const int8_t *__restrict__ player, int32_t *__restrict__ ids, int32_t *__restrict__ count, const int cap)
 {
-    BLK_SHARED_SETUP();
+    __shared__ uint4 Pt[NPIECE * 40];
+    __shared__ WaveLds Lw[4];
+    {
+        const uint4 *pat = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(tables) + BLK_PAT_OFFSET);
+        for (int i = threadIdx.x; i < NPIECE * 40; i += blockDim.x) Pt[i] = pat[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveLds &L = Lw[wave_];
+    for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);      // the padding rows stay zero
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_;
+    if (b >= B) return;
     uint32_t inv[4];
     int score[4];
     blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
     const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
-    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
+    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]), q);
     uint32_t iq = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
-    const uint32_t total = blk_count(T, L, q, iq, lane);
-    if (lane == 0 && count) count[b] = (int32_t)total;
-    if (!ids || total == 0) return;
-    int32_t *out = ids + b * (int64_t)cap;
-    // the rows with anchors (a scalar mask) and each row's anchors (lane y: bit x), as in blk_select
+    // the anchors in row-major order: lane y < 20 knows its row's and where they start in the list of anchors
     const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
-    const uint32_t rows_mask = (uint32_t)__builtin_amdgcn_ballot_w64(crow != 0u);
-    const char *acq = reinterpret_cast<const char *>(&L.ac[q][4]);
+    const uint32_t crow_n = (uint32_t)__popc(crow);
+    const uint32_t incl = wave_scan_incl(crow_n, lane);
+    const int A = __builtin_amdgcn_readlane((int)incl, 63);
     uint32_t base = 0;                                           // actions listed so far (wave-uniform)
-    for (int piece = 0; piece < NPIECE; ++piece) {
-        const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.pcnt[piece]);
-        if (pc == 0) continue;                                   // not held, or no legal placement
-        const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[piece]);
-        const bool pair = lane < 8 * n;
-        // lane / n without a division (n is 1..5, lane < 64: floor(2^32 / n) + 1 is exact there)
-        const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
-        const int po = pair ? (n == 1 ? lane : (int)__umulhi((uint32_t)lane, inv_n)) : 0, pj = pair ? lane - po * n : 0;
-        // my orientation's cells relative to my cell j: row offsets in bytes of the padded rows, right shifts that bring a
-        // cell's column onto the anchor's (the masks are stored << 8); slots behind the shape's cells repeat cell 0
-        const uint2 cw = *reinterpret_cast<const uint2 *>(&T.cells[piece * 8 + po][0]);
-        const uint32_t c[5] = {cw.x & 0xffu, (cw.x >> 8) & 0xffu, (cw.x >> 16) & 0xffu, cw.x >> 24, cw.y & 0xffu};
-        uint32_t mineb = c[0];
+    if (A > 0 && iq != 0u) {
+        uint4 *Wt = reinterpret_cast<uint4 *>(&L.u);
+        const int nchunks = (A + BLK_WT - 1) / BLK_WT;           // 1 unless a player has more than 128 anchors
+        if (nchunks == 1) blk_list_windows(L, Wt, q, lane, crow, incl - crow_n, 0, A);
+        // stores go through a buffer descriptor that ends after `cap` ids: what does not fit is dropped by the hardware
+        const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(
+            ids ? (void *)(ids + b * (int64_t)cap) : (void *)count, 0, ids ? cap * (int)sizeof(int32_t) : 0, 0x00020000);
+        for (int piece = 0; piece < NPIECE; ++piece) {
+            if (!((iq >> piece) & 1u)) continue;
+            const int n = (int)((blk_ncell_packed() >> (3 * piece)) & 7ull);
+            // pass s of a unit: lane -> candidate s * 64 + lane of the unit's 8 anchors x 8 n (o, j) pairs
+            const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
+            uint4 pat[5];
+            int slot[5];                                         // anchor of the unit (0..7)
 #pragma unroll
-        for (int k = 1; k < 5; ++k) mineb = (pj == k) ? c[k] : mineb;
-        const int dxj = (int)(mineb & 15u), dyj = (int)(mineb >> 4);
-        int rowoff[5];
-        uint32_t colsh[5];
+            for (int s = 0; s < 5; ++s) {
+                const uint32_t item = (uint32_t)(s * 64 + lane), g8 = item >> 3;    // < 40 for s < n
+                const uint32_t al = n == 1 ? g8 : __umulhi(g8, inv_n);                // g8 / n (exact below 64)
+                slot[s] = s < n ? (int)al : 0;
+                pat[s] = Pt[piece * 40 + (s < n ? (int)(item - al * 8u * (uint32_t)n) : 0)];
+            }
+            for (int c = 0; c < nchunks; ++c) {
+                const int n_c = A - c * BLK_WT < BLK_WT ? A - c * BLK_WT : BLK_WT;
+                if (nchunks > 1) blk_list_windows(L, Wt, q, lane, crow, incl - crow_n, c * BLK_WT, n_c);
+                for (int u = 0; u < n_c; u += 8) {
+                    // the unit's window reads go out together (a pass that waits for its own read is a chain of LDS
+                    // round trips); passes s >= n read entry u: in range, never used
+                    uint4 w[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            rowoff[k] = ((int)(c[k] >> 4) - dyj) * (int)sizeof(uint2);
-            colsh[k] = (uint32_t)(8 + (int)(c[k] & 15u) - dxj);
-        }
-        const int oj = po * 5 + pj;                              // my pair's part of the dense id
-        uint32_t rows = rows_mask;
-        while (rows) {
-            const int ay = __builtin_ctz(rows);
-            rows &= rows - 1u;
-            uint32_t cr = (uint32_t)__builtin_amdgcn_readlane((int)crow, ay);      // this row's anchors, bit x
-            uint32_t fr = pair ? 0xffffffffu : 0u;
-            const char *rowp = acq + ay * (int)sizeof(uint2);
+                    for (int s = 0; s < 5; ++s) w[s] = Wt[u + slot[s]];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
-            const uint32_t m = fr & cr;                          // bit x: my pair is legal on anchor (x, ay)
-            if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue;            // nothing of this piece on this row
-            const int row_id = (piece * 400 + ay * BN) * 40;
-            while (cr) {
-                const int ax = __builtin_ctz(cr);
-                cr &= cr - 1u;
-                const bool legal = ((m >> ax) & 1u) != 0u;
-                const unsigned long long lm = __builtin_amdgcn_ballot_w64(legal);
-                if (lm == 0ull) continue;
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                const uint32_t pos = base + below;
-                if (legal && pos < (uint32_t)cap) out[pos] = row_id + ax * 40 + oj;
-                base += (uint32_t)__builtin_popcountll(lm);
+                    for (int s = 0; s < 5; ++s) {
+                        if (s >= n) break;
+                        const bool legal = ((w[s].x & pat[s].x) | (w[s].y & pat[s].y) | (w[s].z & pat[s].z)) == 0u;
+                        const unsigned long long lm = __builtin_amdgcn_ballot_w64(legal);
+                        if (lm == 0ull) continue;
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                        if (legal) __builtin_amdgcn_raw_buffer_store_b32(w[s].w + pat[s].w, out, (int)((base + below) << 2), 0, 0);
+                        base += (uint32_t)__builtin_popcountll(lm);
+                    }
+                }
             }
         }
     }
+    if (lane == 0 && count) count[b] = (int32_t)base;
 }
 
 // the rank[b]-th legal action of `player` in reference order as a dense id (-1 when rank is outside [0, count)):
@@ -1473,9 +1564,16 @@ int crl_blokus_create(crl_ctx **out)
         for (int p = 0; p < NPIECE; ++p) nd += host.nuniq[p];
         CRL_REQUIRE(nd == NDISTINCT, "crl_blokus_create: %d distinct oriented shapes, expected %d", nd, NDISTINCT);
     }
+    // one allocation: the tables, then (16-byte aligned) the window patterns of the list pass
+    struct PatternBuf {                                           // 13 KB: not on the stack, freed on every path
+        BlkPatterns *p = new BlkPatterns;
+        ~PatternBuf() { delete p; }
+    } patterns;
+    CRL_REQUIRE(build_patterns(host, *patterns.p), "crl_blokus_create: a piece does not fit the 9 x 9 window of the list pass");
     void *dev = nullptr;
-    CRL_HIP(hipMalloc(&dev, sizeof(BlkTables)));
+    CRL_HIP(hipMalloc(&dev, BLK_PAT_OFFSET + sizeof(BlkPatterns)));
     hipError_t e = hipMemcpy(dev, &host, sizeof(BlkTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy((char *)dev + BLK_PAT_OFFSET, patterns.p, sizeof(BlkPatterns), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(dev);
         crl_set_error("crl_blokus_create: hipMemcpy failed: %s", hipGetErrorString(e));

@@ -211,6 +211,64 @@ def test_blokus_list_select_is_valid_pack_vs_oracle_random():
     assert c.tolist() == [116] * 5 and np.array_equal(ids, ids2[:, :16])
 
 
+def test_blokus_valid_list_more_than_128_anchors():
+    """Boards no game reaches but set_board accepts: a lattice of single cells gives a player ~170 anchors, more than one
+    chunk (128) of the list kernel's window table -- count and ordered ids vs the oracle, uncut and cut by `cap`; plus
+    select / is_valid / the count pass on the same boards."""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    B = 8
+    board = np.zeros((B, 20, 20), np.int8)
+    board[0, 1::3, 1::3] = 1                                   # player 0: 49 cells, anchors on all four diagonals
+    board[1, 0::3, 0::3] = 2
+    board[2, 1::3, 1::3] = 3
+    board[2, 2::6, 2::6] = 1                                   # some of those anchors taken by another colour
+    board[3, 2::3, 1::3] = 4
+    board[4, 1::3, 1::3] = 1
+    board[4, 10:, :] = 0                                       # exactly the top half: fewer than 128
+    board[5, 1::3, 1::3] = 2
+    board[5, 0, :] = 4                                         # a wall of another colour
+    board[6, 1::3, 2::3] = 1
+    board[6, ::7, ::5] = 3
+    rng = np.random.default_rng(5)
+    board[7] = (rng.random((20, 20)) < 0.12) * rng.integers(1, 5, (20, 20))
+    player = np.array([0, 1, 2, 3, 0, 1, 0, 2], np.int8)
+    bb = BlokusBatch(B)
+    bb.set_board(torch.from_numpy(board).cuda())
+    bb.round.fill_(3)
+    inv = np.full((B, 4), (1 << 21) - 1, np.uint32)
+    inv[3] = 0b101010101010101010101                           # a partial inventory
+    inv[6] = 1 << 20
+    bb.inv.copy_(torch.from_numpy(inv.view(np.int32)).cuda().view(bb.inv.dtype))
+    st = O.BlokusState(B)
+    st.set_board(board)
+    st.inv[:] = inv
+    st.round[:] = 3
+    pl = torch.from_numpy(player).cuda()
+    c2, ids2 = O.blokus_valid(st, player=player, cap=16384)
+    assert c2.max() > 2048 and c2[0] > 2048                    # the big lists do not fit the usual cap
+    for cap in (16384, 2048, 100):
+        count, ids = bb.valid_list(cap, player=pl)
+        assert np.array_equal(count.cpu().numpy(), c2), cap
+        got = ids.cpu().numpy()
+        for e in range(B):
+            k = min(int(c2[e]), cap)
+            assert np.array_equal(got[e, :k], ids2[e, :k]), (cap, e)
+            assert (got[e, k:] == -1).all(), (cap, e)            # nothing is written past the list or past `cap`
+    assert np.array_equal(bb.valid(player=pl).cpu().numpy(), c2)
+    rank = np.where(c2 > 0, c2 - 1, 0).astype(np.int32)       # the LAST action of every list
+    act, cnt = bb.select(torch.from_numpy(rank).cuda(), player=pl)
+    want = np.array([ids2[e, rank[e]] if c2[e] else -1 for e in range(B)], np.int32)
+    assert np.array_equal(act.cpu().numpy(), want) and np.array_equal(cnt.cpu().numpy(), c2)
+    assert bb.is_valid(act, player=pl).cpu().numpy().tolist() == [int(c > 0) for c in c2]
+    # count only (ids NULL): no store at all
+    cnt_only = torch.empty((B,), dtype=torch.int32, device="cuda")
+    from colosseumrl_amd._native import check, lib
+    from colosseumrl_amd.batched import _ptr, _stream
+    check(lib().crl_blokus_valid_list(bb._ctx.handle, B, *bb._state(), _ptr(pl), None, _ptr(cnt_only), 0, _stream()), "list")
+    assert np.array_equal(cnt_only.cpu().numpy(), c2)
+
+
 def test_blokus_valid_list_full_size_counts():
     """BASELINE config 4's batch: list lengths == the count pass at B = 16,384 on mid-game positions, lists ascending."""
     import torch
