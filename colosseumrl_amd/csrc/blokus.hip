@@ -234,25 +234,30 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane)
 
 // ---- derive allowed / corner rows from the board: of all four players (lanes 0..79: player q, row y), or of player
 // `only` alone (lanes 0..19)
+__device__ __forceinline__ uint2 blk_prep_row(const uint32_t (&occ)[4][BN], const int q, const int y, const int round)
+{
+    const uint32_t any = occ[0][y] | occ[1][y] | occ[2][y] | occ[3][y];
+    const uint32_t own = occ[q][y];
+    const uint32_t up = y > 0 ? occ[q][y - 1] : 0u, dn = y < BN - 1 ? occ[q][y + 1] : 0u;
+    const uint32_t orth = up | dn | (own << 1) | (own >> 1);           // computation.py:89-119
+    const uint32_t allowed = ~any & ~orth & ROWMASK;                  // computation.py:122-142
+    uint32_t corner;
+    if (round == 0) {                                                // board.py:177-179, corners of board.py:50
+        const int cx = (q & 1) ? BN - 1 : 0, cy = (q & 2) ? BN - 1 : 0;
+        corner = (y == cy) ? (allowed & (1u << cx)) : 0u;
+    } else {                                                         // board.py:114-154
+        const uint32_t ud = up | dn;
+        corner = allowed & ((ud << 1) | (ud >> 1)) & ROWMASK;
+    }
+    return make_uint2(allowed << 8, corner << 8);
+}
+
 __device__ __forceinline__ void blk_prep(WaveLds &L, const int lane, const int round, const int only = -1)
 {
     const int first = only < 0 ? 0 : only * BN, last = only < 0 ? 4 * BN : (only + 1) * BN;
     for (int i = first + lane; i < last; i += 64) {
         const int q = i / BN, y = i - q * BN;
-        const uint32_t any = L.occ[0][y] | L.occ[1][y] | L.occ[2][y] | L.occ[3][y];
-        const uint32_t own = L.occ[q][y];
-        const uint32_t up = y > 0 ? L.occ[q][y - 1] : 0u, dn = y < BN - 1 ? L.occ[q][y + 1] : 0u;
-        const uint32_t orth = up | dn | (own << 1) | (own >> 1);           // computation.py:89-119
-        const uint32_t allowed = ~any & ~orth & ROWMASK;                  // computation.py:122-142
-        uint32_t corner;
-        if (round == 0) {                                                // board.py:177-179, corners of board.py:50
-            const int cx = (q & 1) ? BN - 1 : 0, cy = (q & 2) ? BN - 1 : 0;
-            corner = (y == cy) ? (allowed & (1u << cx)) : 0u;
-        } else {                                                         // board.py:114-154
-            const uint32_t ud = up | dn;
-            corner = allowed & ((ud << 1) | (ud >> 1)) & ROWMASK;
-        }
-        L.ac[q][y + 4] = make_uint2(allowed << 8, corner << 8);
+        L.ac[q][y + 4] = blk_prep_row(L.occ, q, y, round);
     }
     wave_sync();
 }
@@ -1298,8 +1303,16 @@ blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const u
 // (Round 3: lanes = (o, j), bit-parallel over the columns of an anchor row, then one ballot PER ANCHOR: 4,600 VALU + 2,900
 // SALU per list, issue-bound at 157 us for 16,384 mid-game positions -- profiles/r4_step_api_*; the count pass it started
 // with is gone too: the list counts itself.)
-constexpr int BLK_WT = 128;                                  // anchors per chunk of the window table (2 KB of WaveLds::u)
-static_assert(BLK_WT * sizeof(uint4) <= sizeof(WaveLds::u), "window table must fit the pre-shifted table's space");
+constexpr int BLK_WT = 128;                                  // anchors per chunk of the window table
+constexpr int BLK_LIST_WAVES = 8;                            // waves (= games) per workgroup of the list kernel (4: 65.6 us, 8: 61.7, 16: 61.8)
+
+// per-wave working set of the list kernel: 2.6 KB, so that 8 waves + the 13 KB pattern table stay below 35 KB per workgroup and
+// four workgroups = 8 waves per SIMD fit a CU's 160 KB (with WaveLds and 4-wave groups it was 5 per SIMD)
+struct ListLds {
+    uint32_t occ[4][BN];     // board rows per colour
+    uint2 acq[32];           // the player's {allowed << 8, corner << 8}, index y + 4; rows outside the board are 0
+    uint4 wt[BLK_WT];        // window table: {~rows -4..-2, ~rows -1..1, ~rows 2..4, anchor part of the id}
+};
 
 // cells per piece, 3 bits each (a wave-uniform shift instead of a table read)
 constexpr unsigned long long blk_ncell_packed()
@@ -1337,10 +1350,10 @@ bool build_patterns(const BlkTables &t, BlkPatterns &pt)
 }
 
 // window table entries [0, round-up-to-8 of the chunk's anchors) for the anchors [lo, lo + BLK_WT) of the player
-__device__ __forceinline__ void blk_list_windows(WaveLds &L, uint4 *Wt, const int q, const int lane, const uint32_t crow,
-                                                 const uint32_t row_start, const int lo, const int n_c)
+__device__ __forceinline__ void blk_list_windows(ListLds &S, const int lane, const uint32_t crow, const uint32_t row_start,
+                                                 const int lo, const int n_c)
 {
-    uint32_t *Ww = reinterpret_cast<uint32_t *>(Wt);
+    uint32_t *Ww = reinterpret_cast<uint32_t *>(S.wt);
     // lane y < 20 hands out its row's anchors: entry k gets (x, y) in its fourth word for now
     uint32_t m = crow, idx = row_start;
     while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
@@ -1362,91 +1375,110 @@ __device__ __forceinline__ void blk_list_windows(WaveLds &L, uint4 *Wt, const in
             const int ax = (int)(xy & 0xffu), ay = (int)(xy >> 8);
             uint32_t w[3] = {0u, 0u, 0u};
 #pragma unroll
-            for (int dy = 0; dy < 9; ++dy) {             // ac[q][y + 4] holds row y << 8: window column dx is bit ax + dx + 8
-                const uint32_t row = L.ac[q][ay + dy].x;
+            for (int dy = 0; dy < 9; ++dy) {             // acq[y + 4] holds row y << 8: window column dx is bit ax + dx + 8
+                const uint32_t row = S.acq[ay + dy].x;
                 w[dy / 3] |= ((row >> (ax + 4)) & 0x1ffu) << (9 * (dy % 3));
             }
-            Wt[k] = make_uint4(~w[0], ~w[1], ~w[2], (uint32_t)((ay * BN + ax) * 40));
+            S.wt[k] = make_uint4(~w[0], ~w[1], ~w[2], (uint32_t)((ay * BN + ax) * 40));
         } else if (k < padded) {
-            Wt[k] = make_uint4(~0u, ~0u, ~0u, 0u);       // the tail of the last unit of 8: never legal
+            S.wt[k] = make_uint4(~0u, ~0u, ~0u, 0u);     // the tail of the last unit of 8: never legal
         }
     }
     wave_sync();
 }
 
-__global__ void __launch_bounds__(256, 5)
+// the units of one piece over one chunk of anchors, N = the piece's cells (compile time: N passes per unit, no loop control
+// inside a unit).  Returns the new running total.
+template <int N>
+__device__ __forceinline__ uint32_t blk_list_units(const ListLds &S, const uint4 *__restrict__ Pp, const int lane, const int n_c,
+                                                   const __amdgpu_buffer_rsrc_t out, uint32_t base)
+{
+    // pass s of a unit: lane -> candidate s * 64 + lane of the unit's 8 anchors x 8 N (o, j) pairs
+    uint4 pat[N];
+    int slot[N];                                                 // anchor of the unit (0..7)
+    // (through an opaque copy of the lane id: otherwise the compiler computes the decode of all five N up front, keeps
+    // ~15 values alive across the piece loop and spills at the 64 registers of 8 waves per SIMD: 134 us instead of 62)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const int item = s * 64 + ln;
+        slot[s] = item / (8 * N);
+        pat[s] = Pp[item - slot[s] * (8 * N)];
+    }
+    for (int u = 0; u < n_c; u += 8) {
+        uint4 w[N];                                              // the unit's window reads go out together
+#pragma unroll
+        for (int s = 0; s < N; ++s) w[s] = S.wt[u + slot[s]];
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            const bool legal = ((w[s].x & pat[s].x) | (w[s].y & pat[s].y) | (w[s].z & pat[s].z)) == 0u;
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(legal);
+            if (lm == 0ull) continue;                            // (measured: skip + masked store 61.7 us, no skip 63.3,
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+            // every lane storing, the illegal ones past the descriptor's end, 65.8)
+            if (legal) __builtin_amdgcn_raw_buffer_store_b32(w[s].w + pat[s].w, out, (int)((base + below) << 2), 0, 0);
+            base += (uint32_t)__builtin_popcountll(lm);
+        }
+    }
+    return base;
+}
+
+__global__ void __launch_bounds__(64 * BLK_LIST_WAVES, 8)
 blokus_list_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
                    const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
                    const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
                    const int8_t *__restrict__ player, int32_t *__restrict__ ids, int32_t *__restrict__ count, const int cap)
 {
+    (void)score_g;
     __shared__ uint4 Pt[NPIECE * 40];
-    __shared__ WaveLds Lw[4];
+    __shared__ ListLds Sw[BLK_LIST_WAVES];
     {
         const uint4 *pat = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(tables) + BLK_PAT_OFFSET);
         for (int i = threadIdx.x; i < NPIECE * 40; i += blockDim.x) Pt[i] = pat[i];
     }
     const int lane = threadIdx.x & 63;
     const int wave_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    WaveLds &L = Lw[wave_];
-    for (int i = lane; i < 4 * 32; i += 64) L.ac[i >> 5][i & 31] = make_uint2(0u, 0u);      // the padding rows stay zero
+    ListLds &S = Sw[wave_];
+    if (lane < 32) S.acq[lane] = make_uint2(0u, 0u);             // the padding rows stay zero
     __syncthreads();
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave_;
+    const int64_t b = (int64_t)blockIdx.x * BLK_LIST_WAVES + wave_;
     if (b >= B) return;
-    uint32_t inv[4];
-    int score[4];
-    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    for (int i = lane; i < 4 * BN; i += 64) S.occ[i / BN][i % BN] = occ[b * 4 * BN + i];
     const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
-    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]), q);
-    uint32_t iq = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    const uint32_t iq = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv_g[b * 4 + q]);
+    const int round = __builtin_amdgcn_readfirstlane(round_g[b]);
+    wave_sync();
     // the anchors in row-major order: lane y < 20 knows its row's and where they start in the list of anchors
-    const uint32_t crow = lane < BN ? (L.ac[q][lane + 4].y >> 8) : 0u;
+    uint32_t crow = 0u;
+    if (lane < BN) {
+        const uint2 ac = blk_prep_row(S.occ, q, lane, round);
+        S.acq[lane + 4] = ac;
+        crow = ac.y >> 8;
+    }
     const uint32_t crow_n = (uint32_t)__popc(crow);
     const uint32_t incl = wave_scan_incl(crow_n, lane);
     const int A = __builtin_amdgcn_readlane((int)incl, 63);
     uint32_t base = 0;                                           // actions listed so far (wave-uniform)
     if (A > 0 && iq != 0u) {
-        uint4 *Wt = reinterpret_cast<uint4 *>(&L.u);
         const int nchunks = (A + BLK_WT - 1) / BLK_WT;           // 1 unless a player has more than 128 anchors
-        if (nchunks == 1) blk_list_windows(L, Wt, q, lane, crow, incl - crow_n, 0, A);
+        if (nchunks == 1) blk_list_windows(S, lane, crow, incl - crow_n, 0, A);          // (its first barrier covers acq)
         // stores go through a buffer descriptor that ends after `cap` ids: what does not fit is dropped by the hardware
         const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(
             ids ? (void *)(ids + b * (int64_t)cap) : (void *)count, 0, ids ? cap * (int)sizeof(int32_t) : 0, 0x00020000);
         for (int piece = 0; piece < NPIECE; ++piece) {
             if (!((iq >> piece) & 1u)) continue;
             const int n = (int)((blk_ncell_packed() >> (3 * piece)) & 7ull);
-            // pass s of a unit: lane -> candidate s * 64 + lane of the unit's 8 anchors x 8 n (o, j) pairs
-            const uint32_t inv_n = n == 5 ? 858993460u : n == 4 ? 1073741825u : n == 3 ? 1431655766u : 2147483649u;
-            uint4 pat[5];
-            int slot[5];                                         // anchor of the unit (0..7)
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const uint32_t item = (uint32_t)(s * 64 + lane), g8 = item >> 3;    // < 40 for s < n
-                const uint32_t al = n == 1 ? g8 : __umulhi(g8, inv_n);                // g8 / n (exact below 64)
-                slot[s] = s < n ? (int)al : 0;
-                pat[s] = Pt[piece * 40 + (s < n ? (int)(item - al * 8u * (uint32_t)n) : 0)];
-            }
+            const uint4 *Pp = &Pt[piece * 40];
             for (int c = 0; c < nchunks; ++c) {
                 const int n_c = A - c * BLK_WT < BLK_WT ? A - c * BLK_WT : BLK_WT;
-                if (nchunks > 1) blk_list_windows(L, Wt, q, lane, crow, incl - crow_n, c * BLK_WT, n_c);
-                for (int u = 0; u < n_c; u += 8) {
-                    // the unit's window reads go out together (a pass that waits for its own read is a chain of LDS
-                    // round trips); passes s >= n read entry u: in range, never used
-                    uint4 w[5];
-#pragma unroll
-                    for (int s = 0; s < 5; ++s) w[s] = Wt[u + slot[s]];
-#pragma unroll
-                    for (int s = 0; s < 5; ++s) {
-                        if (s >= n) break;
-                        const bool legal = ((w[s].x & pat[s].x) | (w[s].y & pat[s].y) | (w[s].z & pat[s].z)) == 0u;
-                        const unsigned long long lm = __builtin_amdgcn_ballot_w64(legal);
-                        if (lm == 0ull) continue;
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                        if (legal) __builtin_amdgcn_raw_buffer_store_b32(w[s].w + pat[s].w, out, (int)((base + below) << 2), 0, 0);
-                        base += (uint32_t)__builtin_popcountll(lm);
-                    }
+                if (nchunks > 1) blk_list_windows(S, lane, crow, incl - crow_n, c * BLK_WT, n_c);
+                switch (n) {
+                    case 1: base = blk_list_units<1>(S, Pp, lane, n_c, out, base); break;
+                    case 2: base = blk_list_units<2>(S, Pp, lane, n_c, out, base); break;
+                    case 3: base = blk_list_units<3>(S, Pp, lane, n_c, out, base); break;
+                    case 4: base = blk_list_units<4>(S, Pp, lane, n_c, out, base); break;
+                    default: base = blk_list_units<5>(S, Pp, lane, n_c, out, base); break;
                 }
             }
         }
@@ -1664,7 +1696,7 @@ int crl_blokus_valid_list(const crl_ctx *ctx, int64_t B, const uint32_t *occ, co
     CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_valid_list: NULL state pointer");
     CRL_REQUIRE(ids || count, "crl_blokus_valid_list: nothing to compute (ids and count are NULL)");
     CRL_REQUIRE(ids == nullptr || cap > 0, "crl_blokus_valid_list: cap must be positive");
-    hipLaunchKernelGGL(blokus_list_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(blokus_list_kernel, dim3((unsigned)((B + BLK_LIST_WAVES - 1) / BLK_LIST_WAVES)), dim3(64 * BLK_LIST_WAVES), 0, (hipStream_t)stream,
                        (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, ids, count, cap);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
