@@ -831,12 +831,12 @@ def compact_line(full):
     return line
 
 
-def emit(full, out=None, detail_paths=None):
+def emit(full, out=None, detail_paths=None, name="bench_detail.json"):
     """Write the full record to the detail files and to stderr (one line), then the compact line -- the only thing that
     ever goes to stdout -- to `out`."""
     out = out or sys.stdout
     written = []
-    for path in (detail_paths if detail_paths is not None else default_detail_paths()):
+    for path in (detail_paths if detail_paths is not None else default_detail_paths(name)):
         try:
             with open(path, "w") as f:
                 json.dump(full, f, indent=1)
@@ -853,10 +853,10 @@ def emit(full, out=None, detail_paths=None):
     return line
 
 
-def default_detail_paths():
-    paths = [os.path.join(ROOT, "bench_detail.json")]
+def default_detail_paths(name="bench_detail.json"):
+    paths = [os.path.join(ROOT, name)]
     if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        paths.append(os.path.join(ROOT, "gpurun_out", name))
     return paths
 
 
@@ -1071,7 +1071,8 @@ def main(argv=None):
                 out["gather"] = world_of_one_gather_us(torch, dist, make, args, steps_per_launch)
             except Exception as exc:
                 out["gather"] = {"error": repr(exc)[:300]}
-        emit(out)
+        # the full single-process run owns bench_detail.json; --only-headline and launcher runs write their own file
+        emit(out, name="bench_detail.json" if full_run else "bench_detail_n%d%s.json" % (world, "_rccl" if pl.use_dist else "_headline"))
     if pl.use_dist and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

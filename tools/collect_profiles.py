@@ -8,6 +8,9 @@ import json
 import os
 import shutil
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, prefix = sys.argv[1], sys.argv[2]

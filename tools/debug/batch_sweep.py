@@ -5,6 +5,9 @@ rises with more waves per SIMD)?
     python tools/debug/batch_sweep.py <workload> <steps per launch> <batch>[,<batch>...]"""
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench

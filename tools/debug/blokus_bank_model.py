@@ -2,6 +2,10 @@
 """LDS bank-conflict model of the Blokus count pass (CPU only): for random inventories, the 64 lanes' five ds_read_b64 per origin
 row under candidate layouts of the pre-shifted table (shift-major strides, row-major widths, linear bank maps, pad handling);
 prints LDS cycles per conflict-free cycle.  Chose the row-major 9-wide table of round 3 (1.21 against 1.39)."""
+import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 import itertools, random
 kPieces = [
  [(0,0)],[(0,0),(1,0)],[(0,0),(1,0),(1,1)],[(0,0),(1,0),(2,0)],[(0,0),(1,0),(0,1),(1,1)],[(0,0),(1,-1),(1,0),(2,0)],

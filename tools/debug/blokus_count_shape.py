@@ -5,6 +5,9 @@ the (shape, row) pairs over 64 lanes would take."""
 import ctypes as C
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("CRL_LIB_PATH", "build/ab_blkcnt/libcolosseum_hip.so")
 import torch

@@ -5,6 +5,9 @@ Times launch -> collective -> synchronise for a 20-step Tron launch with (a) no 
 (c) all_gather_into_tensor, for the wide int32 rows (44 B / game) and 16-byte rows."""
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -5,6 +5,9 @@ when, relative to the first wave's entry, the waves enter, have their boards in 
 import ctypes as C
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 
 import numpy as np
 

@@ -3,6 +3,9 @@
 through the rollout equivalence (sample + step T times == rollout(T)), against the rollout kernels, on random shapes and
 ragged batches.  usage: step_api_fuzz.py [n_cases] [seed]"""
 import os, sys, time
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np

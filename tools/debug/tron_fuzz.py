@@ -2,6 +2,9 @@
 """Randomised differential run of every Tron rollout kernel against the CPU oracle (bring-up / soak aid, not a test):
 random board sizes, player counts, ragged batches, split launches.  usage: tron_fuzz.py [n_cases] [seed]"""
 import os, sys, time
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -3,6 +3,9 @@
 captured HIP graph of 64 steps.  Run on the GPU box: python tools/step_api_rate.py"""
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

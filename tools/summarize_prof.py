@@ -5,6 +5,9 @@ import glob
 import json
 import os
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 from collections import defaultdict
 
 out = sys.argv[1]

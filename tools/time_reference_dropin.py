@@ -13,6 +13,9 @@ import json
 import os
 import random
 import sys
+if "-h" in sys.argv[1:] or "--help" in sys.argv[1:]:     # usage without touching the GPU (tests/test_tools_smoke.py)
+    print(__doc__)
+    sys.exit(0)
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
