@@ -105,6 +105,86 @@ def bonus_cases(R):
     return out
 
 
+def lattice_boards():
+    """Hand-made boards no game reaches but the API accepts: lattices of single cells give one player up to ~170 anchors
+    (the list kernel's window table takes 128 at a time), walls and foreign cells in the windows, partial inventories, the
+    board's edges and corners.  -> (board int8 [K,20,20], inv uint32 [K,4], round int32 [K], player int8 [K])"""
+    K = 10
+    board = np.zeros((K, 20, 20), np.int8)
+    board[0, 1::3, 1::3] = 1
+    board[1, 0::3, 0::3] = 2
+    board[2, 1::3, 1::3] = 3
+    board[2, 2::6, 2::6] = 1
+    board[3, 2::3, 1::3] = 4
+    board[4, 1::3, 1::3] = 1
+    board[4, 10:, :] = 0
+    board[5, 1::3, 1::3] = 2
+    board[5, 0, :] = 4
+    board[6, 1::3, 2::3] = 1
+    board[6, ::7, ::5] = 3
+    rng = np.random.default_rng(5)
+    board[7] = (rng.random((20, 20)) < 0.12) * rng.integers(1, 5, (20, 20))
+    board[8, 0::4, 0::4] = 4                                   # anchors on the edges and in the corners
+    board[8, 19, 19] = 4
+    board[9, 2::4, 1::2] = 3                                   # dense columns: windows full of own and forbidden cells
+    player = np.array([0, 1, 2, 3, 0, 1, 0, 2, 3, 2], np.int8)
+    inv = np.full((K, 4), (1 << 21) - 1, np.uint32)
+    inv[3] = 0b101010101010101010101
+    inv[6] = 1 << 20
+    inv[9] = 0b000000000111111111000
+    rnd = np.full(K, 3, np.int32)
+    return board, inv, rnd, player
+
+
+def _lattice_case(k):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_loader
+    R = ref_loader.load()
+    env = R["blokus"]()
+    board, inv, rnd, player = lattice_boards()
+    state, _ = env.new_state()
+    b, _, ais = state
+    b.board_contents[:] = board[k]
+    for q in range(4):
+        ais[q].current_pieces = [PIECES[i] for i in range(21) if (int(inv[k, q]) >> i) & 1]
+    st = (b, int(rnd[k]), ais)
+    va = env.valid_actions(st, int(player[k]))
+    ids = [encode(s) for s in va if s != ""]
+    assert ids == sorted(ids)
+    # is_valid_action on a sample: every 97th legal action and as many ids next to legal ones (mostly illegal)
+    probes = sorted(set(ids[::97] + [i + 1 for i in ids[::89]] + [i + 40 for i in ids[::101]]))
+    probes = [i for i in probes if 0 <= i < 336000]
+    ok = [bool(env.is_valid_action(st, int(player[k]), decode_str(i))) for i in probes]
+    return k, ids, probes, ok
+
+
+def decode_str(aid):
+    shift, o, cell, piece = aid % 5, (aid // 5) % 8, (aid // 40) % 400, aid // 16000
+    return "%s;(%d, %d);%s%d" % (PIECES[piece], cell % 20, cell // 20, ORIENT[o], shift)
+
+
+def gen_lattice(out_dir):
+    """`valid_actions` / `is_valid_action` of the REFERENCE on the hand-made boards of `lattice_boards`."""
+    board, inv, rnd, player = lattice_boards()
+    K = len(board)
+    with Pool(min(8, K)) as pool:
+        res = sorted(pool.map(_lattice_case, list(range(K))))
+    cap = max(len(r[1]) for r in res)
+    pcap = max(len(r[2]) for r in res)
+    ids = np.full((K, cap), -1, np.int32)
+    probes = np.full((K, pcap), -1, np.int32)
+    ok = np.zeros((K, pcap), np.uint8)
+    count = np.zeros(K, np.int32)
+    for k, l, pr, o in res:
+        ids[k, :len(l)] = l
+        count[k] = len(l)
+        probes[k, :len(pr)] = pr
+        ok[k, :len(pr)] = o
+        print("blokus lattice board", k, "player", int(player[k]), "legal", len(l), "probes", len(pr), "of them legal", int(sum(o)))
+    np.savez_compressed(os.path.join(out_dir, "blokus_lattice.npz"), board=board, inv=inv, round=rnd, player=player,
+                        count=count, ids=ids, probes=probes, probes_ok=ok)
+
+
 def gen(R, out_dir, n_games=8):
     with Pool(min(8, n_games)) as pool:
         games = pool.map(play_game, list(range(1, n_games + 1)))
@@ -124,6 +204,7 @@ def gen(R, out_dir, n_games=8):
     np.savez_compressed(os.path.join(out_dir, "blokus_bonus.npz"),
                         **{k: np.array([c[k] for c in cases]) for k in cases[0]})
     gen_observe(R, out_dir)
+    gen_lattice(out_dir)
 
 
 def gen_observe(R, out_dir, n_steps=28):
@@ -174,4 +255,8 @@ def gen_observe(R, out_dir, n_steps=28):
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import ref_loader
-    gen_observe(ref_loader.load(), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    if "lattice" in sys.argv[1:]:
+        gen_lattice(out)
+    else:
+        gen_observe(ref_loader.load(), out)

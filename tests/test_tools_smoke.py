@@ -51,7 +51,7 @@ GPU_RUNS = [
     (["tools/debug/step_api_fuzz.py", "12", "9"], "12 cases, 0 mismatches"),
     (["tools/debug/batch_sweep.py", "ttt_p3_3x5_k3_b262144", "64", "4096,8192"], "8192"),
     (["tools/debug/list_ab.py", "colosseumrl_amd/libcolosseum_hip.so"], "mean legal"),
-    (["tools/kernel_ab.py", "256", "2"], ""),
+    (["tools/kernel_ab.py", "20", "64"], "quad"),
     (["tools/debug/gather_latency.py"], "region median"),
 ]
 
