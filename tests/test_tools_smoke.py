@@ -52,12 +52,13 @@ GPU_RUNS = [
     (["tools/debug/batch_sweep.py", "ttt_p3_3x5_k3_b262144", "64", "4096,8192"], "8192"),
     (["tools/debug/list_ab.py", "colosseumrl_amd/libcolosseum_hip.so"], "mean legal"),
     (["tools/kernel_ab.py", "20", "64"], "quad"),
-    (["tools/debug/gather_latency.py"], "region median"),
+    (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "@FREE_PORT@",
+      "tools/debug/gather_latency.py"], "region median"),
 ]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("argv,expect", GPU_RUNS, ids=[a[0].split("/")[-1] for a, _ in GPU_RUNS])
+@pytest.mark.parametrize("argv,expect", GPU_RUNS, ids=[a[-1].split("/")[-1] if a[0] == "-m" else a[0].split("/")[-1] for a, _ in GPU_RUNS])
 def test_diagnostic_script_runs_on_the_gpu(run_fresh, argv, expect):
     rc, out = run_fresh([sys.executable] + argv, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, timeout=600)
     assert rc == 0, out[-3000:]
