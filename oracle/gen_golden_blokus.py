@@ -151,8 +151,10 @@ def _lattice_case(k):
     va = env.valid_actions(st, int(player[k]))
     ids = [encode(s) for s in va if s != ""]
     assert ids == sorted(ids)
-    # is_valid_action on a sample: every 97th legal action and as many ids next to legal ones (mostly illegal)
-    probes = sorted(set(ids[::97] + [i + 1 for i in ids[::89]] + [i + 40 for i in ids[::101]]))
+    # is_valid_action on a few ids only -- the reference answers it by enumerating valid_actions again (:667-719), ~1 min per
+    # call on these boards without numba: three legal ones and three neighbours of legal ones (other shift / other anchor)
+    n = len(ids)
+    probes = sorted(set([ids[0], ids[n // 2], ids[-1], ids[n // 3] + 1, ids[n // 5] + 40, ids[-1] + 5]))
     probes = [i for i in probes if 0 <= i < 336000]
     ok = [bool(env.is_valid_action(st, int(player[k]), decode_str(i))) for i in probes]
     return k, ids, probes, ok

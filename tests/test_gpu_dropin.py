@@ -211,6 +211,32 @@ def test_blokus_list_select_is_valid_pack_vs_oracle_random():
     assert c.tolist() == [116] * 5 and np.array_equal(ids, ids2[:, :16])
 
 
+def test_blokus_lattice_boards_reference_golden(golden):
+    """The reference's own valid_actions / is_valid_action on hand-made boards with up to ~170 anchors per player
+    (tests/golden/blokus_lattice.npz) against crl_blokus_valid_list / _valid / _select / _is_valid."""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    g = golden("blokus_lattice")
+    K, cap = len(g["count"]), g["ids"].shape[1]
+    bb = BlokusBatch(K)
+    bb.set_board(torch.from_numpy(g["board"]).cuda())
+    bb.round.copy_(torch.from_numpy(g["round"]).cuda())
+    bb.inv.copy_(torch.from_numpy(g["inv"].view(np.int32)).cuda().view(bb.inv.dtype))
+    pl = torch.from_numpy(g["player"]).cuda()
+    count, ids = bb.valid_list(cap, player=pl)
+    assert np.array_equal(count.cpu().numpy(), g["count"]) and np.array_equal(ids.cpu().numpy(), g["ids"])
+    assert np.array_equal(bb.valid(player=pl).cpu().numpy(), g["count"])
+    for frac in (0.0, 0.37, 1.0):                                         # first, some, last action of every list
+        rank = np.minimum((g["count"] * frac).astype(np.int32), g["count"] - 1)
+        act, _ = bb.select(torch.from_numpy(rank).cuda(), player=pl)
+        assert np.array_equal(act.cpu().numpy(), g["ids"][np.arange(K), rank])
+    for j in range(g["probes"].shape[1]):                                 # one probe per board and call
+        probe = np.where(g["probes"][:, j] >= 0, g["probes"][:, j], -1).astype(np.int32)
+        ok = bb.is_valid(torch.from_numpy(probe).cuda(), player=pl).cpu().numpy()
+        want = np.where(g["probes"][:, j] >= 0, g["probes_ok"][:, j], 0)
+        assert np.array_equal(ok, want), j
+
+
 def test_blokus_valid_list_more_than_128_anchors():
     """Boards no game reaches but set_board accepts: a lattice of single cells gives a player ~170 anchors, more than one
     chunk (128) of the list kernel's window table -- count and ordered ids vs the oracle, uncut and cut by `cap`; plus

@@ -49,6 +49,26 @@ def test_reference_games(golden):
     assert replay_games(golden, OracleBlokus(len(GAMES))) >= 62
 
 
+def test_lattice_boards_reference_lists(golden):
+    """Hand-made boards run through the REFERENCE (oracle/gen_golden_blokus.py lattice): up to ~170 anchors per player, walls,
+    foreign cells, partial inventories -- the oracle's ordered lists and membership == the reference's valid_actions /
+    is_valid_action.  (The 8 reference-played games never have more than ~60 anchors.)"""
+    g = golden("blokus_lattice")
+    K = len(g["count"])
+    st = O.BlokusState(K)
+    st.set_board(g["board"])
+    st.inv[:] = g["inv"]
+    st.round[:] = g["round"]
+    count, ids = O.blokus_valid(st, player=g["player"], cap=g["ids"].shape[1])
+    assert np.array_equal(count, g["count"]) and np.array_equal(ids, g["ids"])
+    assert g["count"].max() > 2048 and (g["count"] > 0).all()
+    for k in range(K):
+        legal = set(ids[k, :count[k]].tolist())
+        n = int((g["probes"][k] >= 0).sum())
+        assert n >= 4 and g["probes_ok"][k, :n].sum() >= 3                     # three legal ids, up to three neighbours
+        assert [int(p in legal) for p in g["probes"][k, :n]] == g["probes_ok"][k, :n].tolist(), k
+
+
 def test_last_piece_bonus(golden):
     check_bonus(golden, OracleBlokus)
 
