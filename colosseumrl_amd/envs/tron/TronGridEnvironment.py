@@ -227,8 +227,9 @@ class TronGridEnvironment(BaseEnvironment):
     @staticmethod
     def next_cell(x, y, direction, board_size: int = None):
         """Neighbour of (x, y) in ``direction``; clamped to the board when a size is given (:466-481)."""
-        x += (direction == 1) - (direction == 3)
-        y += (direction == 2) - (direction == 0)
+        # (int(): `direction` is a numpy scalar when it comes out of an observation, and numpy booleans do not subtract)
+        x += int(direction == 1) - int(direction == 3)
+        y += int(direction == 2) - int(direction == 0)
         if board_size:
             x = max(min(x, board_size - 1), 0)
             y = max(min(y, board_size - 1), 0)
