@@ -169,8 +169,8 @@ def test_tron_rllib_wrappers_vs_oracle():
         for t in range(200):
             ob, r, done, info = single.step(int(rng.integers(0, 3)))
             assert info == {}
-            if done or not single.players:
+            if done or len(single.players) == 0:
                 break
         lengths.append(t + 1)
-        assert done or not single.players
+        assert done or len(single.players) == 0
     assert max(lengths) >= 3
