@@ -204,7 +204,9 @@ class SingleBlokus(_Single):
     """One Blokus game: ``Board.board_contents`` (int8 [20][20], 0 empty else colour), inventories as bit masks,
     scores, round, mover -- on host-mapped memory; the row bitboards the kernels work on are derived on the GPU
     (``crl_blokus_pack``) in the same stream."""
-    CAP = 4096          # legal actions per state the list can hold (observed maximum in reference games: 1,693)
+    CAP = 4096          # legal actions the list holds at first (observed maximum in reference games: 1,693); a state with more
+                        # (hand-made boards: 12,952 seen) makes the list grow and the kernel run once more
+    MAX_IDS = 21 * 400 * 8 * 5
 
     def __init__(self):
         super().__init__()
@@ -216,20 +218,30 @@ class SingleBlokus(_Single):
             ("score", np.int32, 4), ("round", np.int32, 1), ("to_move", np.int32, 1), ("action", np.int32, 1),
             ("reward", np.int8, 1), ("terminal", np.uint8, 1), ("winners", np.uint8, 1), ("n_valid", np.int32, 1),
             ("obs_pieces", np.uint8, 84), ("obs_score", np.int32, 4), ("obs_player", np.int8, 1), ("player", np.int8, 1),
-            ("count", np.int32, 1), ("ok", np.uint8, 1), ("ids", np.int32, self.CAP)])
+            ("count", np.int32, 1), ("ok", np.uint8, 1)])
         v, d = self.blob.v, self.blob.d
         self.v = v
         h, s = self._handle, self._stream
         st = (d["occ"], d["inv"], d["score"], d["round"], d["to_move"])
+        self._st = st
         self._a_pack = (h, 1, d["board"], d["occ"], s)
         self._a_unpack = (h, 1, d["occ"], d["board"], s)
         self._a_step = (h, 1, 0, 0) + st + (d["action"], None, d["reward"], d["terminal"], d["winners"], d["n_valid"],
                                             d["obs_board"], d["obs_pieces"], d["obs_score"], d["obs_player"], 0, s)
-        self._a_list_mover = (h, 1) + st + (None, d["ids"], d["count"], self.CAP, s)
-        self._a_list = (h, 1) + st + (d["player"], d["ids"], d["count"], self.CAP, s)
+        self._bind_list(self.CAP)
         self._a_is_valid = (h, 1) + st + (d["player"], d["action"], d["ok"], s)
         self._a_observe = (h, 1, d["occ"], d["inv"], d["score"], d["player"], d["obs_board"], d["obs_pieces"],
                            d["obs_score"], s)
+        self._listed = None                                      # whose list is on the block: None = the mover's
+
+    def _bind_list(self, cap: int):
+        """(Re)allocate the mapped id list with room for `cap` ids and bind the list calls' arguments to it."""
+        self.cap = int(cap)
+        self._ids_blob = HostBlob(self._lib, [("ids", np.int32, self.cap)])      # (the old block is freed with its last view)
+        self._ids_view = self._ids_blob.v["ids"]
+        d, ids = self.blob.d, self._ids_blob.d["ids"]
+        self._a_list_mover = (self._handle, 1) + self._st + (None, ids, d["count"], self.cap, self._stream)
+        self._a_list = (self._handle, 1) + self._st + (d["player"], ids, d["count"], self.cap, self._stream)
 
     def load(self, cells, inv_masks, scores, round_count: int, mover: int):
         v = self.v
@@ -252,20 +264,38 @@ class SingleBlokus(_Single):
         if rc:
             check(rc, "crl_blokus_step_observe / board / valid_list")
         self.sync()
+        self._listed = None                                      # the list on the block is the new mover's
 
-    def legal_ids(self, player: int) -> np.ndarray:
-        self.v["player"][0] = player
-        rc = self._lib.crl_blokus_valid_list(*self._a_list)
+    def _issue_list(self, player):
+        if player is None:
+            rc = self._lib.crl_blokus_valid_list(*self._a_list_mover)
+        else:
+            self.v["player"][0] = player
+            rc = self._lib.crl_blokus_valid_list(*self._a_list)
         if rc:
             check(rc, "crl_blokus_valid_list")
+
+    def legal_ids(self, player: int) -> np.ndarray:
+        self._listed = player
+        self._issue_list(player)
         self.sync()
         return self.ids()
 
     def ids(self) -> np.ndarray:
+        """The list the last `step` (for the new mover) or `legal_ids` call left on the block.  A list longer than the
+        block's capacity -- the kernel still counted all of it -- gets a larger block and one more launch."""
         n = int(self.v["count"][0])
-        if n > self.CAP:
-            raise _native.NativeError("%d legal Blokus actions exceed the list capacity %d" % (n, self.CAP))
-        return self.v["ids"][:n].copy()
+        if n > self.cap:
+            if n > self.MAX_IDS:
+                raise _native.NativeError("%d legal Blokus actions: more than there are action ids" % n)
+            grow = self.cap
+            while grow < n:
+                grow *= 2
+            self._bind_list(min(grow, self.MAX_IDS))
+            self._issue_list(self._listed)                       # the exceptional second launch of this call
+            self.sync()
+            n = int(self.v["count"][0])
+        return self._ids_view[:n].copy()
 
     def is_valid(self, player: int, action_id: int) -> bool:
         self.v["player"][0] = player

@@ -187,6 +187,78 @@ def gen_lattice(out_dir):
                         count=count, ids=ids, probes=probes, probes_ok=ok)
 
 
+def _flatten(moves):
+    """{piece: {(x, y): [orientation+shift]}} -> dense ids in the dict's own iteration order."""
+    out = []
+    for piece, by_index in moves.items():
+        for (x, y), names in by_index.items():
+            for name in names:
+                out.append(((PIECES.index(piece) * 400 + int(y) * 20 + int(x)) * 8 + ORIENT.index(name[:-1])) * 5 + int(name[-1]))
+    return out
+
+
+def gen_records(R, out_dir, steps=(1, 5, 9, 17, 30, 45)):
+    """The methods of the state RECORDS (Board / AI) an agent may call: get_all_valid_moves (inventory order and a
+    caller-chosen piece order), gather_empty_corner_indexes, check_moves, update_board, update_player, calculate_winner --
+    on states of golden game 1 replayed through the reference."""
+    g = np.load(os.path.join(out_dir, "blokus_game_1.npz"))
+    env = R["blokus"]()
+    state, players = env.new_state()
+    rec = dict(board=[], round=[], color=[], inv=[], moves=[], n_moves=[], sub_pieces=[], sub_moves=[], n_sub=[],
+               corners=[], n_corners=[], has_move=[])
+    cap = 4096
+    for t in range(max(steps) + 1):
+        aid = int(g["action"][t])
+        state, players, _, term, _ = env.next_state(state, players, [decode_str(aid) if aid >= 0 else ""])
+        if t not in steps:
+            continue
+        board, rnd, ais = state
+        for c in (1, 2, 3, 4):
+            ai = ais[c - 1]
+            ids = _flatten(board.get_all_valid_moves(rnd, c, ai.current_pieces))
+            sub = ai.current_pieces[::-1][:6]                       # a caller-chosen order: the dict follows it
+            ids2 = _flatten(board.get_all_valid_moves(rnd, c, sub))
+            corners = board.gather_empty_corner_indexes(c)
+            row = np.full(cap, -1, np.int32); row[:len(ids)] = ids
+            row2 = np.full(cap, -1, np.int32); row2[:len(ids2)] = ids2
+            crow = np.full((128, 2), -1, np.int32); crow[:len(corners)] = np.array(corners, np.int32).reshape(-1, 2)
+            rec["board"].append(board.board_contents.astype(np.int8).copy()); rec["round"].append(rnd); rec["color"].append(c)
+            rec["inv"].append(inv_mask(ai)); rec["moves"].append(row); rec["n_moves"].append(len(ids))
+            rec["sub_pieces"].append([PIECES.index(p) for p in sub] + [-1] * (6 - len(sub)))
+            rec["sub_moves"].append(row2); rec["n_sub"].append(len(ids2))
+            rec["corners"].append(crow); rec["n_corners"].append(len(corners)); rec["has_move"].append(bool(ai.check_moves(board, rnd)))
+    # update_board / place_piece on an empty board, incl. pieces hanging over the left / top edge (numpy wraps negative indices)
+    Board, AI = state[0].__class__, state[2][0].__class__
+    placed, spec = [], []
+    for piece, index, orient, color in (("pentominoe5", (5, 5), "east0", 1), ("pentominoe2", (10, 3), "northwest3", 2),
+                                        ("tetrominoes3", (0, 0), "south2", 3), ("trominoe1", (1, 0), "north1", 4),
+                                        ("pentominoe12", (10, 14), "southwest4", 2), ("monomino1", (19, 19), "west0", 1)):
+        b = Board()
+        b.update_board(color, piece, index, orient, 3, True)
+        placed.append(b.board_contents.astype(np.int8).copy())
+        spec.append([PIECES.index(piece), index[0], index[1], ORIENT.index(orient[:-1]), int(orient[-1]), color])
+    # update_player: the whole inventory played in two orders (monomino last: +20, otherwise +15)
+    scores = []
+    for order in (PIECES[::-1], PIECES):
+        a = AI(None, 1)
+        trace = []
+        for p in order:
+            a.update_player(p)
+            trace.append(a.player_score)
+        scores.append(trace)
+    # calculate_winner, incl. ties and all-zero
+    winners = []
+    for sc in ([10, 20, 5, 7], [9, 9, 3, 9], [0, 0, 0, 0], [4, 4, 4, 4], [89, 104, 104, 60]):
+        ps = [AI(None, c) for c in (1, 2, 3, 4)]
+        for p, v in zip(ps, sc):
+            p.player_score = v
+        winners.append(sc + ["RBGYN".index(Board().calculate_winner(ps, 20)[0])])
+    np.savez_compressed(os.path.join(out_dir, "blokus_records.npz"), **{k: np.array(v) for k, v in rec.items()},
+                        placed=np.array(placed), placed_spec=np.array(spec, np.int32), update_scores=np.array(scores, np.int32),
+                        winner_cases=np.array(winners, np.int32))
+    print("blokus record fixtures", len(rec["color"]), "states; max moves", max(rec["n_moves"]), "max corners", max(rec["n_corners"]))
+
+
 def gen(R, out_dir, n_games=8):
     with Pool(min(8, n_games)) as pool:
         games = pool.map(play_game, list(range(1, n_games + 1)))
@@ -207,6 +279,7 @@ def gen(R, out_dir, n_games=8):
                         **{k: np.array([c[k] for c in cases]) for k in cases[0]})
     gen_observe(R, out_dir)
     gen_lattice(out_dir)
+    gen_records(R, out_dir)
 
 
 def gen_observe(R, out_dir, n_steps=28):
@@ -260,5 +333,7 @@ if __name__ == "__main__":
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     if "lattice" in sys.argv[1:]:
         gen_lattice(out)
+    elif "records" in sys.argv[1:]:
+        gen_records(ref_loader.load(), out)
     else:
         gen_observe(ref_loader.load(), out)

@@ -237,6 +237,65 @@ def test_blokus_lattice_boards_reference_golden(golden):
         assert np.array_equal(ok, want), j
 
 
+def test_blokus_record_methods_reference_golden(golden):
+    """The methods of the state RECORDS a reference agent may call -- Board.get_all_valid_moves (inventory order and a
+    caller-chosen piece order), gather_empty_corner_indexes, check_valid_corner, AI.collect_moves / check_moves -- against the
+    reference's own records on 24 (state, colour) pairs of a game it played (tests/golden/blokus_records.npz)."""
+    from colosseumrl_amd.envs.blokus.actions import PIECE_NAMES, encode, ORIENTATIONS
+    from colosseumrl_amd.envs.blokus.ai import AI
+    from colosseumrl_amd.envs.blokus.board import Board
+    g = golden("blokus_records")
+
+    def flatten(moves):
+        return [encode(PIECE_NAMES.index(p), x, y, ORIENTATIONS.index(name[:-1]), int(name[-1]))
+                for p, by_index in moves.items() for (x, y), names in by_index.items() for name in names]
+
+    assert len(g["color"]) == 24 and g["n_moves"].max() > 1000
+    for k in range(len(g["color"])):
+        board = Board()
+        board.board_contents[:] = g["board"][k]
+        color, rnd = int(g["color"][k]), int(g["round"][k])
+        ai = AI(board, color)
+        ai.current_pieces = [PIECE_NAMES[i] for i in range(21) if (int(g["inv"][k]) >> i) & 1]
+        moves = ai.collect_moves(board, rnd)
+        assert flatten(moves) == g["moves"][k, :g["n_moves"][k]].tolist(), k
+        assert all(isinstance(x, int) and isinstance(y, int) for by_index in moves.values() for (x, y) in by_index)
+        sub = [PIECE_NAMES[i] for i in g["sub_pieces"][k] if i >= 0]
+        assert flatten(board.get_all_valid_moves(rnd, color, sub)) == g["sub_moves"][k, :g["n_sub"][k]].tolist(), k
+        corners = board.gather_empty_corner_indexes(color)
+        assert corners == [tuple(c) for c in g["corners"][k, :g["n_corners"][k]].tolist()], k
+        assert ai.check_moves(board, rnd) == bool(g["has_move"][k]) and (ai.all_valid_moves == moves)
+        if corners:
+            x, y = corners[len(corners) // 2]
+            assert board.check_valid_corner(board.board_contents, color, y, x)
+            assert not board.check_valid_corner(board.board_contents, color, 0, 0) or (0, 0) in corners
+
+
+def test_blokus_dropin_list_grows_past_its_first_capacity(golden):
+    """A hand-made board with 12,952 legal actions through the drop-in class: the mapped id list starts at 4,096 entries and
+    grows (one more launch) instead of raising; strings in reference order, is_valid_action on both ends."""
+    from colosseumrl_amd import get_environment
+    from colosseumrl_amd.envs.blokus import actions as A
+    from colosseumrl_amd.envs.blokus.ai import AI
+    from colosseumrl_amd.envs.blokus.board import Board
+    g = golden("blokus_lattice")
+    env = get_environment("blokus")()
+    for k in (8, 0, 6):                                          # 12,952 ids, 4,616 ids, 58 ids (back to a short list)
+        board = Board()
+        board.board_contents[:] = g["board"][k]
+        ais = [AI(board, c) for c in (1, 2, 3, 4)]
+        for q in range(4):
+            ais[q].current_pieces = [A.PIECE_NAMES[i] for i in range(21) if (int(g["inv"][k, q]) >> i) & 1]
+        state = (board, int(g["round"][k]), ais)
+        pl = int(g["player"][k])
+        va = env.valid_actions(state, pl)
+        n = int(g["count"][k])
+        assert len(va) == n and [A.string_to_id(s) for s in va] == g["ids"][k, :n].tolist(), k
+        assert env.is_valid_action(state, pl, va[0]) and env.is_valid_action(state, pl, va[-1])
+        d = env.valid_actions_dict(state, pl)
+        assert sum(len(v) for by_index in d.values() for v in by_index.values()) == n
+
+
 def test_blokus_valid_list_more_than_128_anchors():
     """Boards no game reaches but set_board accepts: a lattice of single cells gives a player ~170 anchors, more than one
     chunk (128) of the list kernel's window table -- count and ordered ids vs the oracle, uncut and cut by `cap`; plus

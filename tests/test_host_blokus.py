@@ -1,5 +1,6 @@
 """CPU-only checks of the Blokus host layer against fixtures captured from the reference."""
 import numpy as np
+import pytest
 
 from colosseumrl_amd.envs.blokus import actions as A
 from colosseumrl_amd.envs.blokus.BlokusEnvironment import BlokusEnvironment
@@ -49,3 +50,39 @@ def test_new_state_shape():
     blob = env.serialize_state((board, rnd, players))
     b2, r2, p2 = env.deserialize_state(blob)
     assert np.array_equal(b2.board_contents, board.board_contents) and p2[3].current_pieces == A.PIECE_NAMES
+
+
+def test_record_methods_without_gpu_work_match_reference(golden):
+    """Board.update_board / place_piece / decode_color / calculate_winner and AI.update_player against the reference's own
+    records (tests/golden/blokus_records.npz): pure host bookkeeping, no GPU."""
+    from colosseumrl_amd.envs.blokus.actions import ORIENTATIONS, PIECE_NAMES
+    from colosseumrl_amd.envs.blokus.ai import AI
+    from colosseumrl_amd.envs.blokus.board import Board
+    g = golden("blokus_records")
+    for spec, want in zip(g["placed_spec"], g["placed"]):
+        piece, x, y, o, k, color = [int(v) for v in spec]
+        b = Board()
+        b.update_board(color, PIECE_NAMES[piece], (x, y), ORIENTATIONS[o] + str(k), 3, True)
+        assert np.array_equal(b.board_contents, want), spec
+        assert b.board_contents.dtype == np.int64 and b.player_color == color
+    for order, want in zip((PIECE_NAMES[::-1], PIECE_NAMES), g["update_scores"]):
+        a = AI(None, 1)
+        got = []
+        for p in order:
+            a.update_player(p)
+            got.append(a.player_score)
+        assert got == want.tolist() and a.current_pieces == []
+    assert g["update_scores"][0][-1] == 109 and g["update_scores"][1][-1] == 104           # +20 / +15
+    for case in g["winner_cases"]:
+        ps = [AI(None, c) for c in (1, 2, 3, 4)]
+        for p, v in zip(ps, case[:4]):
+            p.player_score = int(v)
+        assert Board().calculate_winner(ps, 20) == ["R", "B", "G", "Y", "NONE"][int(case[4])], case
+    copy = Board(Board())
+    copy.board_contents[3, 4] = 2
+    again = Board(copy)
+    assert again.board_contents[3, 4] == 2 and again.board_contents is not copy.board_contents
+    again.reset_board()
+    assert not again.board_contents.any()
+    with pytest.raises(ValueError):
+        AI(None, 2).update_player("no such piece")
