@@ -83,7 +83,7 @@ class Board:
         """``[(x, y), ...]`` row-major: empty cells diagonal to a cell of `player_color` and not orthogonally next to one.
         They are the cells where the monomino is legal from round 1 on -- which is how the GPU is asked."""
         ids = _legal_ids(self.board_contents, 1, player_color, ["monomino1"])
-        return [decode(int(i))[1:3] for i in ids]
+        return [decode(int(i))[1:3] for i in ids[::8]]            # eight orientations of the one-cell piece per anchor
 
     def check_valid_corner(self, board_contents, player_color, row_num, col_num):
         probe = Board()
