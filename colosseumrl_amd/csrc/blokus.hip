@@ -1695,7 +1695,7 @@ int crl_blokus_valid_list(const crl_ctx *ctx, int64_t B, const uint32_t *occ, co
     BLK_CTX_CHECK("crl_blokus_valid_list");
     CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_valid_list: NULL state pointer");
     CRL_REQUIRE(ids || count, "crl_blokus_valid_list: nothing to compute (ids and count are NULL)");
-    CRL_REQUIRE(ids == nullptr || cap > 0, "crl_blokus_valid_list: cap must be positive");
+    CRL_REQUIRE(ids == nullptr || (cap > 0 && cap <= (1 << 28)), "crl_blokus_valid_list: cap=%d out of range 1..2^28", cap);
     hipLaunchKernelGGL(blokus_list_kernel, dim3((unsigned)((B + BLK_LIST_WAVES - 1) / BLK_LIST_WAVES)), dim3(64 * BLK_LIST_WAVES), 0, (hipStream_t)stream,
                        (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, ids, count, cap);
     CRL_LAUNCH_CHECK();

@@ -332,8 +332,9 @@ int crl_blokus_observe(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const
  * board.py:170-193) in a form a policy can consume for a whole batch.  count int32 [B] = number of legal actions of `player`
  * (int8 [B]; NULL = the player to move); ids int32 [B][cap]: ids[b][0 .. min(count[b], cap)) = their dense ids in
  * ascending order = the reference's order (piece -> anchor row-major -> orientation -> shift); entries beyond are left
- * untouched.  Either output may be NULL.  (Observed maximum in reference-played games: 1,693 actions; cap = 2048 is safe
- * for play from the empty board, and count tells when a list was cut.) */
+ * untouched.  Either output may be NULL; cap in 1..2^28 when ids is given.  (Observed maximum in reference-played games:
+ * 1,693 actions; cap = 2048 is safe for play from the empty board; hand-made boards reach 12,952; count tells when a list
+ * was cut -- the kernel counts the whole list whatever cap is.) */
 int crl_blokus_valid_list(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                           const int32_t *round, const int32_t *to_move, const int8_t *player, int32_t *ids, int32_t *count,
                           int cap, void *stream);
