@@ -132,3 +132,46 @@ def test_ttt_and_blokus_random_configurations():
         for k in ("occ", "inv", "score", "round", "to_move", "tcount", "tstep", "n_episodes", "win_count", "len_sum", "score_sum"):
             want = getattr(ost, k)
             assert np.array_equal(getattr(bb, k).cpu().numpy().view(want.dtype), want), (case, B, chunks, k)
+
+
+def test_blokus_lists_on_arbitrary_boards():
+    """valid_list / valid / select / is_valid on boards no game produces (random cells of random colours at densities from
+    1 % to 70 %, random inventories, round 0 and later, every player) against the oracle: the window x pattern list kernel
+    and the row-bitboard count / select kernels answer for ANY board `set_board` accepts, not only reachable ones."""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch
+    rng = np.random.default_rng(41)
+    B, cap = 192, 16384
+    for trial in range(6):
+        density = rng.choice([0.01, 0.05, 0.15, 0.3, 0.5, 0.7], size=B)
+        board = ((rng.random((B, 20, 20)) < density[:, None, None]) * rng.integers(1, 5, (B, 20, 20))).astype(np.int8)
+        if trial == 0:
+            board[: B // 2] = 0                                   # empty boards: round 0 openings and anchorless later rounds
+        inv = rng.integers(0, 1 << 21, size=(B, 4)).astype(np.uint32)
+        inv[rng.random((B, 4)) < 0.15] = (1 << 21) - 1
+        inv[rng.random((B, 4)) < 0.05] = 0
+        rnd = np.where(rng.random(B) < 0.25, 0, rng.integers(1, 20, B)).astype(np.int32)
+        player = rng.integers(0, 4, B).astype(np.int8)
+        bb = BlokusBatch(B)
+        bb.set_board(torch.from_numpy(board).cuda())
+        bb.inv.copy_(torch.from_numpy(inv.view(np.int32)).cuda().view(bb.inv.dtype))
+        bb.round.copy_(torch.from_numpy(rnd).cuda())
+        st = O.BlokusState(B)
+        st.set_board(board)
+        st.inv[:] = inv
+        st.round[:] = rnd
+        c2, ids2 = O.blokus_valid(st, player=player, cap=cap, n_threads=16)
+        assert c2.max() <= cap
+        pl = torch.from_numpy(player).cuda()
+        count, ids = bb.valid_list(cap, player=pl)
+        assert np.array_equal(count.cpu().numpy(), c2), trial
+        assert np.array_equal(ids.cpu().numpy(), ids2), trial
+        assert np.array_equal(bb.valid(player=pl).cpu().numpy(), c2), trial
+        rank = np.where(c2 > 0, rng.integers(0, np.maximum(c2, 1)), 0).astype(np.int32)
+        act, _ = bb.select(torch.from_numpy(rank).cuda(), player=pl)
+        want = np.where(c2 > 0, ids2[np.arange(B), rank], -1)
+        assert np.array_equal(act.cpu().numpy(), want), trial
+        probe = np.where(rng.random(B) < 0.5, np.maximum(want, 0), rng.integers(0, 336000, B)).astype(np.int32)
+        ok = bb.is_valid(torch.from_numpy(probe).cuda(), player=pl).cpu().numpy()
+        member = np.array([int(probe[e] in set(ids2[e, :c2[e]].tolist())) for e in range(B)], np.uint8)
+        assert np.array_equal(ok, member), trial
