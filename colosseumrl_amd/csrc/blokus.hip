@@ -1401,10 +1401,11 @@ __device__ __forceinline__ uint32_t blk_list_units(const ListLds &S, const uint4
     int ln = lane;
     asm volatile("" : "+v"(ln));
 #pragma unroll
-    for (int s = 0; s < N; ++s) {
-        const int item = s * 64 + ln;
-        slot[s] = item / (8 * N);
-        pat[s] = Pp[item - slot[s] * (8 * N)];
+    for (int s = 0; s < N; ++s) {                                // (unsigned: a shift / one v_mul_hi per quotient; signed division
+        const uint32_t item = (uint32_t)(s * 64) + (uint32_t)ln;  // by 32 alone was five instructions)
+        const uint32_t a = item / (uint32_t)(8 * N);
+        slot[s] = (int)a;
+        pat[s] = Pp[item - a * (uint32_t)(8 * N)];
     }
     for (int u = 0; u < n_c; u += 8) {
         uint4 w[N];                                              // the unit's window reads go out together
