@@ -1,6 +1,8 @@
 // capi.hip -- context lifetime, error reporting and the RNG test entry point of libcolosseum_hip.so.
 #include "crl_common.hpp"
 #include <stdarg.h>
+#include <atomic>
+#include <chrono>
 
 static thread_local char g_err[512] = "";
 
@@ -23,6 +25,11 @@ philox_kernel(const uint32_t *__restrict__ ctr, const uint32_t k0, const uint32_
     const uint4 c = reinterpret_cast<const uint4 *>(ctr)[i];
     const philox_out r = philox4x32_10(c.x, c.y, c.z, c.w, k0, k1);
     reinterpret_cast<uint4 *>(out)[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+}
+// publishes `seq` in host-mapped memory behind everything the stream ran before it (crl_stream_wait_mapped)
+__global__ void __launch_bounds__(64) signal_kernel(uint32_t *flag, const uint32_t seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 } // namespace
 
@@ -95,6 +102,28 @@ int crl_stream_destroy(void *stream)
 int crl_stream_synchronize(void *stream)
 {
     CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return CRL_OK;
+}
+
+int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile uint32_t *flag_host, uint32_t seq, double timeout_s)
+{
+    CRL_REQUIRE(flag_device != nullptr && flag_host != nullptr, "crl_stream_wait_mapped: NULL flag pointer");
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag_device, seq);
+    CRL_LAUNCH_CHECK();
+    // spin on the mapped word: 3.5 us less than hipStreamSynchronize for a short launch chain (tools/ubench/mailbox_rtt.hip).
+    // The clock is read every 256 polls only; a stream that faulted never delivers -> the runtime's own wait reports it.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; ++spins) {
+        if (*flag_host == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return CRL_OK;
+        }
+        if ((spins & 255u) == 0u &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            break;
+    }
+    CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    CRL_REQUIRE(*flag_host == seq, "crl_stream_wait_mapped: the stream drained but the flag reads %u, not %u", (unsigned)*flag_host, (unsigned)seq);
     return CRL_OK;
 }
 

@@ -57,13 +57,23 @@ class _Single:
         self._handle = C.c_void_p()
         self._stream = C.c_void_p()
 
+    WAIT_TIMEOUT_S = 5.0     # after this long without the flag the wait falls back to hipStreamSynchronize (and its error)
+
     def _open_stream(self):
         check(self._lib.crl_stream_create(C.byref(self._stream)), "crl_stream_create")
+        # the word the end-of-call wait spins on: a block of its own, so that re-binding the data block never moves it
+        self._flag = HostBlob(self._lib, [("seq", np.uint32, 1)])
+        self._flag_args = (self._stream, self._flag.d["seq"], C.c_void_p(self._flag.v["seq"].ctypes.data))
+        self._seq = 0
 
     def sync(self):
-        rc = self._lib.crl_stream_synchronize(self._stream)
+        """End of a call: everything queued on this instance's stream has run and its results are in the mapped block.
+        The wait is on mapped memory (``crl_stream_wait_mapped``: a one-thread kernel behind the chain publishes a sequence
+        number, the host spins on it) -- ~3.5 us less than ``hipStreamSynchronize`` for these one-to-three-launch chains."""
+        self._seq = seq = (self._seq + 1) & 0xFFFFFFFF or 1
+        rc = self._lib.crl_stream_wait_mapped(*self._flag_args, seq, self.WAIT_TIMEOUT_S)
         if rc:
-            check(rc, "crl_stream_synchronize")
+            check(rc, "crl_stream_wait_mapped")
 
     def __del__(self):
         try:

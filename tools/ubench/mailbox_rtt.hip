@@ -54,12 +54,23 @@ __global__ void __launch_bounds__(64) server_kernel(Mailbox *mb, int words, uint
     if (threadIdx.x == 0) __hip_atomic_store(&mb->exited, why, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void __launch_bounds__(64) oneshot_kernel(Mailbox *mb, int words)
+// `seq` != 0: the kernel also publishes `seq` in the mailbox's ack word behind its result (system-scope release), so that the host can
+// spin on mapped memory instead of calling hipStreamSynchronize
+__global__ void __launch_bounds__(64) oneshot_kernel(Mailbox *mb, int words, uint32_t seq)
 {
     uint32_t sum = 0;
     for (int i = threadIdx.x; i < words; i += 64) sum += mb->payload[i];
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    if (threadIdx.x == 0) mb->result = sum;
+    if (threadIdx.x == 0) {
+        mb->result = sum;
+        if (seq) __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// a kernel of its own that only publishes the sequence number: what a generic "signal" call behind ANY launch chain would be
+__global__ void __launch_bounds__(64) signal_kernel(Mailbox *mb, uint32_t seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static double now_us()
@@ -103,15 +114,43 @@ int main()
         std::vector<double> ls;
         for (int k = 0; k < 500; ++k) {
             const double t0 = now_us();
-            hipLaunchKernelGGL(oneshot_kernel, dim3(1), dim3(64), 0, stream, dev, words);
+            hipLaunchKernelGGL(oneshot_kernel, dim3(1), dim3(64), 0, stream, dev, words, 0u);
             CHECK(hipStreamSynchronize(stream));
             ls.push_back(now_us() - t0);
         }
         std::sort(ls.begin(), ls.end());
+        // ... and as a launch whose kernel publishes a sequence number in mapped memory, the host spinning on it
+        std::vector<double> lf;
+        host->ack = 0;
+        for (uint32_t k = 1; k <= 500; ++k) {
+            const double t0 = now_us();
+            hipLaunchKernelGGL(oneshot_kernel, dim3(1), dim3(64), 0, stream, dev, words, k);
+            while (host->ack != k) {
+                if (now_us() - t0 > 20000.0) { fprintf(stderr, "flag never came\n"); return 1; }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            lf.push_back(now_us() - t0);
+        }
+        CHECK(hipStreamSynchronize(stream));
+        std::sort(lf.begin(), lf.end());
+        std::vector<double> l2;
+        host->ack = 0;
+        for (uint32_t k = 1; k <= 500; ++k) {
+            const double t0 = now_us();
+            hipLaunchKernelGGL(oneshot_kernel, dim3(1), dim3(64), 0, stream, dev, words, 0u);
+            hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, stream, dev, k);
+            while (host->ack != k) {
+                if (now_us() - t0 > 20000.0) { fprintf(stderr, "flag never came\n"); return 1; }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            l2.push_back(now_us() - t0);
+        }
+        CHECK(hipStreamSynchronize(stream));
+        std::sort(l2.begin(), l2.end());
         printf("  {\"payload_dwords\": %d, \"mailbox_round_trip_us\": {\"median\": %.2f, \"p10\": %.2f, \"p90\": %.2f}, \"served\": %zu, \"exit_reason\": %u, "
-               "\"launch_plus_sync_us\": {\"median\": %.2f, \"p10\": %.2f}}%s\n",
+               "\"launch_plus_sync_us\": {\"median\": %.2f, \"p10\": %.2f}, \"launch_plus_spin_on_mapped_flag_us\": {\"median\": %.2f, \"p10\": %.2f}, \"launch_plus_signal_kernel_plus_spin_us\": {\"median\": %.2f, \"p10\": %.2f}}%s\n",
                words, rt[rt.size() / 2], rt[rt.size() / 10], rt[rt.size() * 9 / 10], rt.size(), host->exited, ls[ls.size() / 2], ls[ls.size() / 10],
-               words == 512 ? "" : ",");
+               lf[lf.size() / 2], lf[lf.size() / 10], l2[l2.size() / 2], l2[l2.size() / 10], words == 512 ? "" : ",");
     }
     printf(" ]}\n");
     CHECK(hipStreamDestroy(stream));
