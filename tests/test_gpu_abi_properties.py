@@ -203,8 +203,8 @@ def test_rollout_with_events_attached_to_the_dispatches(N, P, T, kernel):
 
 def test_stream_wait_mapped_orders_behind_the_stream_and_falls_back():
     """crl_stream_wait_mapped: the flag arrives behind everything queued on the stream (a long rollout's results are
-    complete when the call returns, with NO other synchronisation), a fresh sequence number per call, and with a zero
-    time-out the call takes its fallback (hipStreamSynchronize + flag check) and still succeeds."""
+    complete when the call returns, with NO other synchronisation of that stream), a fresh sequence number per call, and with
+    a zero time-out the call takes its fallback (hipStreamSynchronize + flag check) and still succeeds."""
     import ctypes as C
     import torch
     from colosseumrl_amd import _native
@@ -212,26 +212,24 @@ def test_stream_wait_mapped_orders_behind_the_stream_and_falls_back():
     from colosseumrl_amd.batched import TronBatch
     from colosseumrl_amd.single import HostBlob
     lib = _native.lib()
-    stream = C.c_void_p()
-    check(lib.crl_stream_create(C.byref(stream)), "crl_stream_create")
-    flag = HostBlob(lib, [("seq", np.uint32, 1), ("out", np.uint32, 4)])
+    side = torch.cuda.Stream()                                    # torch owns the stream; the C ABI sees its handle
+    stream = C.c_void_p(side.cuda_stream)
+    flag = HostBlob(lib, [("seq", np.uint32, 1)])
     host_ptr = C.c_void_p(flag.v["seq"].ctypes.data)
-    tb = TronBatch(20, 4, 4096)
     ref = TronBatch(20, 4, 4096)
     ref.rollout(3000, 9)
+    want = ref.len_sum.cpu()
+    tb = TronBatch(20, 4, 4096)
     torch.cuda.synchronize()
-    want = ref.len_sum.clone()
-    torch.cuda.synchronize()
-    s = torch.cuda.ExternalStream(stream.value)
-    with torch.cuda.stream(s):
-        tb.rollout(3000, 9)                                       # ~1 ms of work queued on the private stream
-        got = tb.len_sum.to("cpu", non_blocking=True)             # ... and a copy behind it, all asynchronous
-    for seq, timeout in ((1, 5.0), (2, 5.0), (7, 0.0), (0xFFFFFFFF, 5.0), (3, 0.0)):
+    with torch.cuda.stream(side):
+        tb.rollout(3000, 9)                                       # ~1 ms of work queued on the side stream, asynchronous
+    check(lib.crl_stream_wait_mapped(stream, flag.d["seq"], host_ptr, 1, 5.0), "crl_stream_wait_mapped")
+    assert int(flag.v["seq"][0]) == 1
+    # the copy below runs on the DEFAULT stream, which never waited for the side stream: it sees the finished rollout only
+    # because the wait above really covered it
+    assert torch.equal(tb.len_sum.cpu(), want)
+    for seq, timeout in ((2, 5.0), (7, 0.0), (0xFFFFFFFF, 5.0), (3, 0.0)):
         check(lib.crl_stream_wait_mapped(stream, flag.d["seq"], host_ptr, seq, timeout), "crl_stream_wait_mapped")
         assert int(flag.v["seq"][0]) == seq
-        if seq == 1:
-            assert torch.equal(got, want.cpu())                   # no torch synchronise has happened in between
     assert lib.crl_stream_wait_mapped(stream, None, host_ptr, 4, 1.0) != 0 and b"NULL" in lib.crl_last_error()
     torch.cuda.synchronize()
-    del tb, ref
-    check(lib.crl_stream_destroy(stream), "crl_stream_destroy")
