@@ -426,7 +426,7 @@ def mean_episode_len(gathered):
 
 def contract_record(workload, batch, world, steps, warmup, chunk, meas, launch_s, launch_source, copy_gbs, gather_desc):
     """The contract fields + `roofline` of one measured region (`meas` = contract_region's result on rank 0)."""
-    game, kw = WORKLOADS[workload][:2]
+    game = WORKLOADS[workload][0]
     mean_len, n_ep = mean_episode_len(meas["rows"])
     steps_per_launch = min(chunk, steps)
     elapsed = meas["elapsed"]
@@ -472,7 +472,7 @@ def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
     res = st.results(copy=False)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    mean_len, n_ep = mean_episode_len(res)
+    mean_len = mean_episode_len(res)[0]
     launch_s = e0.elapsed_time(e1) * 1e-3 / n
     out = {"value": batch * chunk * n / elapsed, "unit": "env-steps/s", "games": batch, "steps_per_launch": chunk,
            "launches": n, "ms_per_env_step": elapsed * 1e3 / (chunk * n), "mean_episode_len": round(mean_len, 3),
