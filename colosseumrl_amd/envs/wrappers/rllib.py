@@ -16,24 +16,31 @@ except ImportError:
 
 
 class RllibWrapper(_Base):
-    # ---- what a concrete wrapper provides
+    # ---- what a concrete wrapper provides (the constructor's arguments are handed to all three factories)
     def create_env(self, *args, **kwargs) -> BaseEnvironment:
-        raise NotImplementedError
+        """The drop-in environment instance to wrap."""
+        raise NotImplementedError("create_env")
 
     def create_observation_space(self, *args, **kwargs):
-        raise NotImplementedError
+        """Space of ONE player's observation (``self.env`` exists when this is called)."""
+        raise NotImplementedError("create_observation_space")
 
     def create_action_space(self, *args, **kwargs):
-        raise NotImplementedError
+        """Space of ONE player's action."""
+        raise NotImplementedError("create_action_space")
+
+    # ---- optional hooks
+    def action_map(self, action):
+        """Library action -> the environment's action string; identity unless overridden."""
+        return action
 
     def create_done_dict(self, state, players, rewards, terminal, action_dict) -> Dict[str, bool]:
+        """Per-player done flags of the players that acted (``'__all__'`` is added by ``step``): the game's terminal flag."""
         return dict.fromkeys(action_dict, terminal)
 
     def create_info_dict(self, state, players, rewards, terminal, action_dict) -> Dict:
+        """The info dict of a step; empty unless overridden."""
         return {}
-
-    def action_map(self, action):
-        return action
 
     # ---- the episode loop
     def __init__(self, *args, **kwargs):
