@@ -325,6 +325,39 @@ def measure_copy_bandwidth(torch, device, nbytes=1 << 30, reps=5):
 
 
 # ---------------------------------------------------------------------------------------------- measurements
+def box_issue_probe(torch, device, waves_per_simd=4, target_s=3e-4):
+    """What THIS box issues right now (crl_diag_issue_probe: independent integer VALU instructions on every SIMD, 4 waves
+    each) and at which shader clock: {valu_wave_insts_per_s, clock_mhz, vs_calibration}.  The rollout kernels are bound by
+    instruction issue, so a box whose clocks are capped runs them proportionally slower; `vs_calibration` = this box's rate /
+    the committed calibration's at the same occupancy says so in the record."""
+    from colosseumrl_amd import _native
+    lib = _native.lib()
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    blocks = cus * waves_per_simd
+    out = torch.empty((blocks * 256,), dtype=torch.int32, device=device)
+    clk = torch.zeros((2,), dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    iters = 256
+    rate = None
+    for _ in range(3):                                     # first pass sizes the run, the last one is reported
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.crl_diag_issue_probe(out.data_ptr(), clk.data_ptr(), blocks, iters, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        if rc:
+            _native.check(rc, "crl_diag_issue_probe")
+        secs = e0.elapsed_time(e1) * 1e-3
+        rate = blocks * 4 * iters * 64 / max(secs, 1e-9)
+        iters = int(max(64, min(1 << 20, iters * target_s / max(secs, 1e-6))))
+    ticks = clk.cpu().tolist()
+    rec = {"valu_wave_insts_per_s": rate, "clock_mhz": round(100.0 * ticks[0] / max(ticks[1], 1), 1), "waves_per_simd": waves_per_simd}
+    _, peak_occ, _ = valu_peaks(waves_per_simd)
+    if peak_occ:
+        rec["vs_calibration"] = rate / peak_occ
+    return rec
+
+
 class Plumbing:
     """Device + process-group plumbing of the contract region, so that the same region runs on `cuda` over RCCL (the
     product) and on `cpu` over gloo (tests/test_bench_contract.py drives it with a CPU stepper in a world of two)."""
@@ -792,7 +825,8 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
 CONFIG_KEYS = ("workload", "games_per_gpu", "global_games", "steps_per_launch", "launches", "mean_episode_len", "episodes",
                "parallelism", "gather", "device_warmup")
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_env_step",
-                 "physical_frac", "frac_of_copy", "valu_frac", "steady_value", "steady_frac", "steady_valu_frac", "note")
+                 "physical_frac", "frac_of_copy", "valu_frac", "steady_value", "steady_frac", "steady_valu_frac",
+                 "box_clock_mhz", "box_issue_vs_calibration", "box_clock_mhz_warm", "box_issue_vs_calibration_warm", "note")
 LINE_LIMIT = 4096
 
 
@@ -1026,6 +1060,7 @@ def main(argv=None):
             launch_s = kernel_dispatch_s
             launch_source = ("HIP events attached to the dispatch (hipExtLaunchKernel start / stop), median of 20 isolated regions of the "
                              "timed shape; marker events recorded around such a launch: %.2f us" % (kernel_s * 1e6))
+        box_cold = box_issue_probe(torch, device)          # the box as it is right behind the contract region
         row_bytes = int(meas["rows"].shape[-1] * meas["rows"].element_size())
         gather_desc = ("rccl gather to rank 0 (torch.distributed.gather), %d-byte rows" % row_bytes) if pl.use_dist \
             else "none (single process, no process group)"
@@ -1035,6 +1070,12 @@ def main(argv=None):
                     "kernel_ms_source": ("HIP marker events around the launches of the timed region" if region_events else
                                          "HIP marker events around the launches of one more region of the same shape, right after the timed "
                                          "one (two event records cost 3.6 us of the region, ~10 us next to a collective: not recorded inside it)")})
+        out["box"] = {"after_contract_region": box_cold,
+                      "what": "crl_diag_issue_probe: independent integer VALU instructions at 4 waves per SIMD on every CU; clock_mhz = "
+                              "shader clock under that load; vs_calibration = rate / profiles/%s at the same occupancy"
+                              % (os.path.basename(CALIBRATION) if CALIBRATION else "(no calibration file)")}
+        out["roofline"]["box_clock_mhz"] = box_cold["clock_mhz"]
+        out["roofline"]["box_issue_vs_calibration"] = box_cold.get("vs_calibration")
         full_run = world == 1 and not args.only_headline
         if world == 1 and (full_run or args.device_warmup):
             ms = device_warmup(torch, lambda: make_stepper(game, kw, batch, device, 0), steps_per_launch, args.seed)
@@ -1066,6 +1107,9 @@ def main(argv=None):
                 if wl != args.workload:
                     others[wl] = steady_state(torch, wl, device, args.seed, copy_gbs)
             out["others"] = others
+            out["box"]["after_steady_state"] = warm = box_issue_probe(torch, device)      # the box behind ~2 s of rollouts
+            out["roofline"]["box_clock_mhz_warm"] = warm["clock_mhz"]
+            out["roofline"]["box_issue_vs_calibration_warm"] = warm.get("vs_calibration")
             out["step_api"] = step_api_rates(torch, device, copy_gbs, write_gbs)
             out["stream_peaks"] = {"copy_GBs": copy_gbs, "write_GBs": write_gbs,
                                    "what": "measured in this run over 1 GiB: best read+write copy, pure write stream"}

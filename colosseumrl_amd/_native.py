@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
-CRL_ABI_VERSION = 105
+CRL_ABI_VERSION = 106
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
@@ -72,6 +72,7 @@ PROTOTYPES = {
     "crl_stream_destroy": (_I, [_VP]),
     "crl_stream_synchronize": (_I, [_VP]),
     "crl_stream_wait_mapped": (_I, [_VP, _VP, _VP, _U32, C.c_double]),
+    "crl_diag_issue_probe": (_I, [_VP, _VP, _I, _I, _VP]),
     "crl_philox4x32": (_I, [_VP, _U32, _U32, _VP, _I64, _VP]),
     "crl_tron_create": (_I, [_I, _I, _VP, _VP, C.POINTER(_VP)]),
     "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -26,6 +26,32 @@ philox_kernel(const uint32_t *__restrict__ ctr, const uint32_t k0, const uint32_
     const philox_out r = philox4x32_10(c.x, c.y, c.z, c.w, k0, k1);
     reinterpret_cast<uint4 *>(out)[i] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
 }
+// crl_diag_issue_probe: 64 independent integer VALU instructions per loop trip on eight chains (the "valu" mix of
+// tools/ubench/valu_rate.hip); wave 0 of block 0 stamps the shader clock counter and the 100 MHz wall clock around its loop
+__global__ void __launch_bounds__(256) issue_probe_kernel(uint32_t *out, uint64_t *clk, const int iters)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const uint32_t c = blockIdx.x | 1u;
+    uint64_t t0 = 0, r0 = 0;
+    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+    if (stamp) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(
+            ".rept 4\n"
+            "v_add_u32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+            "v_add_u32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+            "v_xor_b32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+            "v_xor_b32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+            ".endr\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));
+    }
+    if (stamp) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
 // publishes `seq` in host-mapped memory behind everything the stream ran before it (crl_stream_wait_mapped)
 __global__ void __launch_bounds__(64) signal_kernel(uint32_t *flag, const uint32_t seq)
 {
@@ -124,6 +150,15 @@ int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile u
     }
     CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
     CRL_REQUIRE(*flag_host == seq, "crl_stream_wait_mapped: the stream drained but the flag reads %u, not %u", (unsigned)*flag_host, (unsigned)seq);
+    return CRL_OK;
+}
+
+int crl_diag_issue_probe(uint32_t *out, uint64_t *clk, int blocks, int iters, void *stream)
+{
+    CRL_REQUIRE(out != nullptr && clk != nullptr, "crl_diag_issue_probe: NULL pointer");
+    CRL_REQUIRE(blocks > 0 && blocks <= (1 << 16) && iters > 0 && iters <= (1 << 24), "crl_diag_issue_probe: blocks / iters out of range");
+    hipLaunchKernelGGL(issue_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, clk, iters);
+    CRL_LAUNCH_CHECK();
     return CRL_OK;
 }
 

@@ -64,8 +64,8 @@ const char *crl_last_error(void);
  * contract of the sampled agents changes.  crl_version() returns the revision the LIBRARY was built from; a binding must
  * refuse a library whose revision differs from the header it was written against (colosseumrl_amd/_native.py does).
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
- * 104: round 4.  105: crl_stream_wait_mapped (this header). */
-#define CRL_ABI_VERSION 105
+ * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe (this header). */
+#define CRL_ABI_VERSION 106
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -94,6 +94,15 @@ int crl_stream_synchronize(void *stream);
  * than the word's current one).  After `timeout_s` seconds without the flag the call falls back to hipStreamSynchronize and
  * reports what that reports (a faulted stream never delivers). */
 int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile uint32_t *flag_host, uint32_t seq, double timeout_s);
+
+/* ------------------------------------------------------------------ diagnostics
+ * How fast does THIS device, as it runs now, issue vector instructions?  `blocks` workgroups of 256 threads (4 waves: one
+ * per SIMD of a CU) each run `iters` loop trips of 64 independent 32-bit integer VALU instructions; out (DEVICE, blocks x 256
+ * dwords) keeps the work alive, clk (DEVICE, 2 x uint64) receives what wave 0 counted around its loop: shader-clock ticks
+ * and 100 MHz wall-clock ticks (ratio x 100 = MHz under this load).  Asynchronous; time the launch with events: wave64
+ * instructions per second = blocks x 4 x iters x 64 / time.  bench.py runs it at 4 waves per SIMD next to the rollouts, so
+ * that a box whose clocks are capped shows in the record (the rollout kernels are bound by instruction issue). */
+int crl_diag_issue_probe(uint32_t *out, uint64_t *clk, int blocks, int iters, void *stream);
 
 /* ------------------------------------------------------------------ RNG (exposed for parity tests) */
 /* out[i*4..i*4+3] = Philox-4x32-10(ctr[i*4..], key); n counters; DEVICE pointers */

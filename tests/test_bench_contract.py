@@ -42,7 +42,8 @@ def _canned_full():
             "valu_issue": {"achieved": 5.43e11, "peak": 1.08e12, "unit": "wave-instr/s", "frac": 0.50277777, "peak_source": long,
                            "waves_per_simd": 4, "peak_at_occupancy": 1.0e12, "frac_at_occupancy": 0.543},
             "steady_value": 2.136e11, "steady_launch_ms": 2.5131234, "steady_frac": 2.53123, "steady_physical_frac": 0.00328123,
-            "steady_valu_frac": 0.516123}
+            "steady_valu_frac": 0.516123, "box_clock_mhz": 2391.3, "box_issue_vs_calibration": 0.98765432,
+            "box_clock_mhz_warm": 2377.7, "box_issue_vs_calibration_warm": 1.0123456}
     wl = {"value": 6.98123456e11, "unit": "env-steps/s", "games": 262144, "steps_per_launch": 2048, "launches": 64,
           "ms_per_env_step": 0.000375123, "mean_episode_len": 18.123, "dtype": "u32", "roofline": dict(roof),
           "cpu_baseline": {"value": 1.23456e8, "unit": "env-steps/s", "cores": 16, "kind": "port", "sample": long, "nproc": 256,
