@@ -106,6 +106,7 @@ def test_bench_driver_style_line(run_fresh):
     r = rec["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] == "tron_rollout_quad_kernel" and 0.3 < r["frac"] < 1.2
     assert r["achieved"] == pytest.approx(r["bytes_per_env_step"] * 65536 * 20 / (r["launch_ms"] * 1e-3) / 1e9, rel=1e-3)
+    assert 300 < r["box_clock_mhz"] < 4000 and 0.1 < r["box_issue_vs_calibration"] < 1.5        # the box's own issue probe
     assert "RCCL" not in err and "NCCL version" not in err      # the contract run creates no process group
 
 
