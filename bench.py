@@ -45,6 +45,7 @@ script (and gpurun_out/bench_detail.json when that directory exists) and, as one
   gather        (--gather-probe) the cost of the end-of-rollout collective in a one-rank RCCL group
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -398,15 +399,21 @@ def timed_rollout(pl, sr, steps, seed, chunk, events=None, dst=None):
     of the region; ~10 us next to a collective: tools/debug/gather_latency.py); None leaves them out, and the launches
     are timed in a separate pass (`launch_time_pass`, `dispatch_time_pass`)."""
     pl.barrier()
-    t0 = time.perf_counter()
-    if events:
-        events[0].record()                                 # same stream the kernels are launched on
-    launches = sr.rollout(steps, seed, chunk)
-    if events:
-        events[1].record()
-    gathered = sr.gather(dst=dst, copy=False)              # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
-    pl.sync()
-    elapsed = time.perf_counter() - t0
+    gc_on = gc.isenabled()
+    gc.disable()                                           # as timeit does: a young-generation collection inside a ~35 us region is ~10 us of noise
+    try:
+        t0 = time.perf_counter()
+        if events:
+            events[0].record()                             # same stream the kernels are launched on
+        launches = sr.rollout(steps, seed, chunk)
+        if events:
+            events[1].record()
+        gathered = sr.gather(dst=dst, copy=False)          # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
+        pl.sync()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_on:
+            gc.enable()
     if gathered is not None:
         gathered = gathered.clone()                        # outside the clock
     pl.barrier()
