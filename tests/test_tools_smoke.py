@@ -63,3 +63,18 @@ def test_diagnostic_script_runs_on_the_gpu(run_fresh, argv, expect):
     rc, out = run_fresh([sys.executable] + argv, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT, timeout=600)
     assert rc == 0, out[-3000:]
     assert expect in out, out[-2000:]
+
+
+UBENCH = sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.hip")))
+
+
+@pytest.mark.parametrize("path", UBENCH, ids=os.path.basename)
+def test_ubench_source_compiles_for_gfx950(path, tmp_path):
+    """The calibration / latency micro-benchmarks are stand-alone HIP programs built on the GPU box; here: they still compile."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    p = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-c", path, "-o", str(tmp_path / "ubench.o")], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(open(path).read().split("Build + run on the GPU box")) == 2        # the usage line every ubench carries
