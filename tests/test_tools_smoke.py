@@ -52,6 +52,8 @@ GPU_RUNS = [
     (["tools/debug/batch_sweep.py", "ttt_p3_3x5_k3_b262144", "64", "4096,8192"], "8192"),
     (["tools/debug/list_ab.py", "colosseumrl_amd/libcolosseum_hip.so"], "mean legal"),
     (["tools/kernel_ab.py", "20", "64"], "quad"),
+    (["tools/debug/dropin_stress.py", "3", "1500"], "0 errors"),
+    (["tools/debug/host_latency.py"], "region raw"),
     (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "@FREE_PORT@",
       "tools/debug/gather_latency.py"], "region median"),
 ]
