@@ -636,12 +636,14 @@ class BlokusBatch:
         return {"board": ob, "pieces": op, "score": osc, "player": player.view(self.B, 1)}
 
     def step_observe(self, action: Optional[torch.Tensor] = None, seed: int = 0, auto_reset: bool = True,
-                     out: Optional[dict] = None):
+                     out: Optional[dict] = None, list_cap: int = 0):
         """One ply of every game in ONE launch: plays `action` (int32 [B] dense ids; None = the rollout's random agent
         at each game's step counter, which then advances) and returns what the next mover needs:
         {'board' int8 [B, 20, 20], 'pieces' uint8 [B, 4, 21], 'score' int32 [B, 4], 'player' int8 [B, 1] (its observation),
         'n_valid' int32 [B] (its number of legal actions), 'reward', 'terminal', 'winners'}.
-        Equals ``step(...); valid(); observe(to_move)``."""
+        Equals ``step(...); valid(); observe(to_move)``.
+        ``list_cap`` > 0 queues ``valid_list(list_cap)`` for the next mover right behind it (same stream, no synchronise in
+        between) and adds 'ids' int32 [B, list_cap]: the ordered legal ids a policy picks from (-1 beyond 'n_valid')."""
         if action is not None:
             _want(action, torch.int32, (self.B,), self.device, "action")
         if out is None:
@@ -658,6 +660,12 @@ class BlokusBatch:
                                                     _ptr(out["player"]), CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()),
                   "crl_blokus_step_observe")
         out["reward"], out["terminal"], out["winners"] = self.reward, self.terminal, self.winners
+        if list_cap > 0:
+            ids = out.get("ids")
+            if ids is None or tuple(ids.shape) != (self.B, int(list_cap)):
+                ids = torch.empty((self.B, int(list_cap)), dtype=torch.int32, device=self.device)
+            ids.fill_(-1)
+            out["ids"] = self.valid_list(int(list_cap), out=ids)[1]
         return out
 
     def board(self):

@@ -98,10 +98,14 @@ class BlokusVectorEnv:
         """A uniformly drawn legal action id per game (-1 where the mover must pass)."""
         return self.batch.sample(seed)
 
-    def step(self, action: torch.Tensor):
+    def step(self, action: torch.Tensor, list_cap: int = 0):
         """-> (obs for the next mover, next mover int8 [B], its number of legal actions int32 [B], reward int8 [B] of the
         player who just moved, done uint8 [B], info); finished games restart (obs / mover / counts are of the new game).
-        One launch (``BlokusBatch.step_observe``)."""
-        o = self.batch.step_observe(action, auto_reset=True)
+        One launch (``BlokusBatch.step_observe``); with ``list_cap`` > 0 a second one right behind it leaves the next mover's
+        ordered legal ids in ``info['ids']`` (int32 [B, list_cap], -1 beyond the count)."""
+        o = self.batch.step_observe(action, auto_reset=True, list_cap=list_cap)
         obs = {"board": o["board"], "pieces": o["pieces"], "score": o["score"], "player": o["player"]}
-        return obs, o["player"].view(-1), o["n_valid"], o["reward"].clone(), o["terminal"].clone(), {"winners": o["winners"].clone()}
+        info = {"winners": o["winners"].clone()}
+        if list_cap > 0:
+            info["ids"] = o["ids"]
+        return obs, o["player"].view(-1), o["n_valid"], o["reward"].clone(), o["terminal"].clone(), info

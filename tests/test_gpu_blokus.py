@@ -233,7 +233,7 @@ def test_vector_env_adapter_vs_oracle():
                 act[e] = ids2[e, int(c2[e] - 1 - rng.integers(0, max(1, c2[e] // 3)))]
         if t == 0:
             assert np.array_equal(env.sample_valid(3).cpu().numpy() >= 0, c2 > 0)
-        obs, mover, n_valid, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        obs, mover, n_valid, rew, done, info = env.step(torch.from_numpy(act).cuda(), list_cap=2048 if t % 3 == 0 else 0)
         r2, t2, w2 = orc.step(act)
         assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(done.cpu().numpy(), t2) and np.array_equal(info["winners"].cpu().numpy(), w2), t
         if t2.any():
@@ -244,6 +244,11 @@ def test_vector_env_adapter_vs_oracle():
         ob, op, osc = O.blokus_observe(orc.st, s2["to_move"].astype(np.int8))
         assert np.array_equal(obs["board"].cpu().numpy(), ob) and np.array_equal(obs["pieces"].cpu().numpy(), op)
         assert np.array_equal(obs["score"].cpu().numpy(), osc)
+        if t % 3 == 0:                                          # the next mover's ordered ids, queued behind the step
+            c3, ids3 = orc.valid(2048)
+            assert np.array_equal(n_valid.cpu().numpy(), c3) and np.array_equal(info["ids"].cpu().numpy(), ids3), t
+        else:
+            assert "ids" not in info
     assert finished > 0
 
 
