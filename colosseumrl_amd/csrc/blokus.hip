@@ -1294,7 +1294,7 @@ blokus_observe_kernel(const int64_t B, const uint32_t *__restrict__ occ, const u
 //     bits each), plus the anchor's part of the dense id -- 16 bytes per anchor in LDS (WaveLds::u.sh, free here);
 //   * a table built at context creation holds, for every (piece, o, j), the 81-bit pattern of the cells relative to cell j
 //     and the (piece, o, j) part of the id -- 16 bytes each, 13 KB, staged in LDS per workgroup;
-//   * a candidate is legal iff (window & pattern) == 0: v_and + 2 v_and_or + v_cmp.
+//   * a candidate is legal iff (window & pattern) == 0: three v_and, one v_or3, one v_cmp.
 // The candidates of a piece are enumerated in output order -- anchor, o, j -- 64 at a time: a unit of n passes (n = cells of
 // the piece) covers 8 anchors x 8 orientations x n shifts, so a lane's (o, j) and its anchor slot are fixed per (piece, pass
 // of the unit) and its pattern sits in registers for the whole piece.  A legal lane's place in the list is the running
