@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
-CRL_ABI_VERSION = 106
+CRL_ABI_VERSION = 107
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
@@ -105,6 +105,7 @@ PROTOTYPES = {
     "crl_blokus_valid_list": (_I, [_VP, _I64] + [_VP] * 8 + [_I, _VP]),
     "crl_blokus_select": (_I, [_VP, _I64] + [_VP] * 9 + [_VP]),
     "crl_blokus_is_valid": (_I, [_VP, _I64] + [_VP] * 8 + [_VP]),
+    "crl_blokus_fits": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP]),
     "crl_blokus_pack": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_blokus_board": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_blokus_observe": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -608,6 +608,18 @@ class BlokusBatch:
                                                 _stream()), "crl_blokus_is_valid")
         return ok
 
+    def fits(self, action: torch.Tensor, player: torch.Tensor):
+        """uint8 [B]: 1 iff every cell of the placement action[b] lies on the board, is empty and has no orthogonal neighbour
+        of player[b]'s colour -- ``is_valid`` without the anchor and inventory conditions (one shift of the reference's
+        ``Board.check_orientation_shifts``)."""
+        _want(action, torch.int32, (self.B,), self.device, "action")
+        _want(player, torch.int8, (self.B,), self.device, "player")
+        ok = torch.empty((self.B,), dtype=torch.uint8, device=self.device)
+        with _DevGuard(self.device):
+            check(self._lib.crl_blokus_fits(self._ctx.handle, self.B, _ptr(self.occ), _ptr(player), _ptr(action), _ptr(ok),
+                                            _stream()), "crl_blokus_fits")
+        return ok
+
     def set_board(self, board: torch.Tensor):
         """Loads ``Board.board_contents`` (int8 [B, 20, 20], 0 empty else colour) into the row bitboards."""
         _want(board, torch.int8, (self.B, 20, 20), self.device, "board")

@@ -1519,28 +1519,28 @@ blokus_select_kernel(const BlkTables *__restrict__ tables, const int64_t B, cons
 }
 
 // is_valid_action (BlokusEnvironment.py:667-719: membership in valid_actions) without the enumeration: the piece is held,
-// `shift` names one of its cells, that cell's target is an anchor of the player, and every cell lands on an allowed cell
+// `shift` names one of its cells, that cell's target is an anchor of the player, and every cell lands on an allowed cell.
+// FIT_ONLY: only the last condition (and the shift naming a cell) -- what Board.check_orientation_shifts asks of ONE shift
+// (board.py:156-168, computation.py:144-180 check_shifted): the index need not be an anchor, the piece need not be held;
+// inv_g / round_g / to_move_g are not read then.
+template <bool FIT_ONLY>
 __global__ void __launch_bounds__(256, BLK_WAVES_PER_SIMD)
 blokus_is_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, const uint32_t *__restrict__ occ,
-                       const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ score_g,
-                       const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
+                       const uint32_t *__restrict__ inv_g, const int32_t *__restrict__ round_g, const int32_t *__restrict__ to_move_g,
                        const int8_t *__restrict__ player, const int32_t *__restrict__ action, uint8_t *__restrict__ ok)
 {
     BLK_SHARED_SETUP();
-    uint32_t inv[4];
-    int score[4];
-    blk_load_state(L, b, lane, occ, inv_g, score_g, inv, score);
+    for (int i = lane; i < 4 * BN; i += 64) L.occ[i / BN][i % BN] = occ[b * 4 * BN + i];
+    wave_sync();
     const int q = __builtin_amdgcn_readfirstlane(player ? (int)player[b] : to_move_g[b]) & 3;
-    blk_prep(L, lane, __builtin_amdgcn_readfirstlane(round_g[b]));
-    uint32_t iq = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+    blk_prep(L, lane, FIT_ONLY ? 1 : __builtin_amdgcn_readfirstlane(round_g[b]), q);
+    const uint32_t iq = FIT_ONLY ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)inv_g[b * 4 + q]);
     const int id = __builtin_amdgcn_readfirstlane(action[b]);
     bool good = false;
     if (id >= 0 && id < ACTION_IDS) {
         const BlkMove mv = blk_decode(id);
         const ShapeRegs s = blk_load_shape(T, mv.piece, mv.orient);
-        if (((iq >> mv.piece) & 1u) && mv.shift < s.n) {
+        if ((FIT_ONLY || ((iq >> mv.piece) & 1u)) && mv.shift < s.n) {
             int ox = 0, oy = 0;
 #pragma unroll
             for (int j = 0; j < 5; ++j) { ox = (j == mv.shift) ? s.sh(j) : ox; oy = (j == mv.shift) ? s.ro(j) : oy; }
@@ -1552,7 +1552,7 @@ blokus_is_valid_kernel(const BlkTables *__restrict__ tables, const int64_t B, co
                 const int x = mv.x + cx - ox, y = mv.y + cy - oy;
                 cell_ok = x >= 0 && x < BN && y >= 0 && y < BN && ((L.ac[q][y + 4].x >> (x + 8)) & 1u);
             }
-            const bool anchor = (L.ac[q][mv.y + 4].y >> (mv.x + 8)) & 1u;
+            const bool anchor = FIT_ONLY || ((L.ac[q][mv.y + 4].y >> (mv.x + 8)) & 1u);
             good = anchor && __ballot(!cell_ok) == 0ull;
         }
     }
@@ -1723,8 +1723,21 @@ int crl_blokus_is_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, cons
     BLK_CTX_CHECK("crl_blokus_is_valid");
     CRL_REQUIRE(occ && inv && score && round && to_move, "crl_blokus_is_valid: NULL state pointer");
     CRL_REQUIRE(action && ok, "crl_blokus_is_valid: NULL action / ok pointer");
-    hipLaunchKernelGGL(blokus_is_valid_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const BlkTables *)ctx->blokus, B, occ, inv, score, round, to_move, player, action, ok);
+    (void)score;
+    hipLaunchKernelGGL(blokus_is_valid_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, inv, round, to_move, player, action, ok);
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_blokus_fits(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, const int32_t *action, uint8_t *ok,
+                    void *stream)
+{
+    BLK_CTX_CHECK("crl_blokus_fits");
+    CRL_REQUIRE(occ && player && action && ok, "crl_blokus_fits: NULL pointer");
+    hipLaunchKernelGGL(blokus_is_valid_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const BlkTables *)ctx->blokus, B, occ, (const uint32_t *)nullptr, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, player, action, ok);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

@@ -3,16 +3,14 @@
 ``board_contents`` is what agents and renderers read.  The methods a reference agent may call on the record it is handed
 -- ``get_all_valid_moves``, ``gather_empty_corner_indexes``, ``check_valid_corner``, ``update_board``, ``calculate_winner``
 ... -- are kept with the reference's signatures and return formats; move generation itself runs in the HIP kernels
-(``crl_blokus_valid_list`` on host-mapped memory, one launch per call), never on the CPU.  Not provided:
-``check_orientation_shifts`` (board.py:156-168), an internal step of the reference's enumeration loop that also answers
-for cells that are no anchors; ``get_all_valid_moves`` returns what that loop builds.
+(``crl_blokus_valid_list`` / ``crl_blokus_fits`` on host-mapped memory, one launch per call), never on the CPU.
 """
 import threading
 from collections import defaultdict
 
 import numpy as np
 
-from .actions import ORIENTATIONS, PIECE_INDEX, PIECE_NAMES, decode  # noqa: F401  (re-exported like the reference module)
+from .actions import ORIENTATIONS, PIECE_INDEX, PIECE_NAMES, PIECE_VALUES, decode, encode  # noqa: F401  (re-exported like the reference module)
 
 PLAYER_DEFAULT_CORNERS = [(0, 0), (19, 0), (0, 19), (19, 19)]      # (x, y) per player, reference board.py:50
 
@@ -89,6 +87,18 @@ class Board:
         probe = Board()
         probe.board_contents = np.asarray(board_contents)
         return board_contents[row_num][col_num] == 0 and (col_num, row_num) in probe.gather_empty_corner_indexes(player_color)
+
+    def check_orientation_shifts(self, player_color, piece_type, index, orientation):
+        """Shift ids k (ascending, int64 array) for which `piece_type` in `orientation` fits with its cell k on `index`:
+        every cell on the board, empty, no orthogonal neighbour of the player's colour -- whether or not `index` is an anchor
+        (reference :156-168, computation.py:144-180).  One ``crl_blokus_fits`` launch per shift."""
+        x, y = int(index[0]), int(index[1])
+        if not (0 <= x < 20 and 0 <= y < 20):
+            return np.zeros(0, dtype=np.int64)
+        q, piece, o = int(player_color) - 1, PIECE_INDEX[piece_type], ORIENTATIONS.index(orientation)
+        st = _stager()
+        st.load(self.board_contents, [0, 0, 0, 0], [0, 0, 0, 0], 1, q)
+        return np.array([k for k in range(PIECE_VALUES[piece]) if st.fits(q, encode(piece, x, y, o, k))], dtype=np.int64)
 
     # ---- move generation (reference :170-193)
     def get_all_valid_moves(self, round_count, player_color, player_pieces):

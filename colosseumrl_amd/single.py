@@ -240,6 +240,7 @@ class SingleBlokus(_Single):
                                             d["obs_board"], d["obs_pieces"], d["obs_score"], d["obs_player"], 0, s)
         self._bind_list(self.CAP)
         self._a_is_valid = (h, 1) + st + (d["player"], d["action"], d["ok"], s)
+        self._a_fits = (h, 1, d["occ"], d["player"], d["action"], d["ok"], s)
         self._a_observe = (h, 1, d["occ"], d["inv"], d["score"], d["player"], d["obs_board"], d["obs_pieces"],
                            d["obs_score"], s)
         self._listed = None                                      # whose list is on the block: None = the mover's
@@ -313,6 +314,17 @@ class SingleBlokus(_Single):
         rc = self._lib.crl_blokus_is_valid(*self._a_is_valid)
         if rc:
             check(rc, "crl_blokus_is_valid")
+        self.sync()
+        return bool(self.v["ok"][0])
+
+    def fits(self, player: int, action_id: int) -> bool:
+        """Every cell of the placement on the board, empty and not orthogonally next to `player`'s colour (anchor and
+        inventory not asked: ``crl_blokus_fits``)."""
+        self.v["player"][0] = player
+        self.v["action"][0] = action_id
+        rc = self._lib.crl_blokus_fits(*self._a_fits)
+        if rc:
+            check(rc, "crl_blokus_fits")
         self.sync()
         return bool(self.v["ok"][0])
 

@@ -64,8 +64,8 @@ const char *crl_last_error(void);
  * contract of the sampled agents changes.  crl_version() returns the revision the LIBRARY was built from; a binding must
  * refuse a library whose revision differs from the header it was written against (colosseumrl_amd/_native.py does).
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
- * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe (this header). */
-#define CRL_ABI_VERSION 106
+ * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits (this header). */
+#define CRL_ABI_VERSION 107
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -367,6 +367,12 @@ int crl_blokus_select(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const 
 int crl_blokus_is_valid(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const uint32_t *inv, const int32_t *score,
                         const int32_t *round, const int32_t *to_move, const int8_t *player, const int32_t *action,
                         uint8_t *ok, void *stream);
+/* One step of Board.check_orientation_shifts (board.py:156-168 -> computation.py:144-180 check_shifted): ok uint8 [B] = 1 iff
+ * every cell of the placement action[b] names lies on the board, is empty and has no orthogonal neighbour of colour player[b] + 1
+ * -- whether or not the index is an anchor and whether or not the piece is held (so: crl_blokus_is_valid minus those two
+ * conditions; it needs the row bitboards only). */
+int crl_blokus_fits(const crl_ctx *ctx, int64_t B, const uint32_t *occ, const int8_t *player, const int32_t *action, uint8_t *ok,
+                    void *stream);
 /* occ rows from Board.board_contents as int8 [B][20][20] (0 empty, else colour): the inverse of crl_blokus_board, for
  * callers that hold reference-layout boards */
 int crl_blokus_pack(const crl_ctx *ctx, int64_t B, const int8_t *board, uint32_t *occ, void *stream);

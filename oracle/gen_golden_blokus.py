@@ -205,7 +205,8 @@ def gen_records(R, out_dir, steps=(1, 5, 9, 17, 30, 45)):
     env = R["blokus"]()
     state, players = env.new_state()
     rec = dict(board=[], round=[], color=[], inv=[], moves=[], n_moves=[], sub_pieces=[], sub_moves=[], n_sub=[],
-               corners=[], n_corners=[], has_move=[])
+               corners=[], n_corners=[], has_move=[], shift_spec=[], shift_mask=[])
+    rng = np.random.default_rng(77)
     cap = 4096
     for t in range(max(steps) + 1):
         aid = int(g["action"][t])
@@ -227,6 +228,17 @@ def gen_records(R, out_dir, steps=(1, 5, 9, 17, 30, 45)):
             rec["sub_pieces"].append([PIECES.index(p) for p in sub] + [-1] * (6 - len(sub)))
             rec["sub_moves"].append(row2); rec["n_sub"].append(len(ids2))
             rec["corners"].append(crow); rec["n_corners"].append(len(corners)); rec["has_move"].append(bool(ai.check_moves(board, rnd)))
+            # check_orientation_shifts on anchors, on random cells (mostly no anchors, some occupied) and next to the edges
+            specs, masks = [], []
+            cells = [tuple(c) for c in corners[:3]] + [(int(rng.integers(0, 20)), int(rng.integers(0, 20))) for _ in range(7)] + [(0, 19), (19, 0)]
+            for cell in cells:
+                piece, o = int(rng.integers(0, 21)), int(rng.integers(0, 8))
+                got = board.check_orientation_shifts(c, PIECES[piece], cell, ORIENT[o])
+                specs.append([piece, cell[0], cell[1], o])
+                masks.append(sum(1 << int(k) for k in got))
+            while len(specs) < 12:
+                specs.append([-1, 0, 0, 0]); masks.append(0)
+            rec["shift_spec"].append(specs); rec["shift_mask"].append(masks)
     # update_board / place_piece on an empty board, incl. pieces hanging over the left / top edge (numpy wraps negative indices)
     Board, AI = state[0].__class__, state[2][0].__class__
     placed, spec = [], []

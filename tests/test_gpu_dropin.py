@@ -269,6 +269,13 @@ def test_blokus_record_methods_reference_golden(golden):
             x, y = corners[len(corners) // 2]
             assert board.check_valid_corner(board.board_contents, color, y, x)
             assert not board.check_valid_corner(board.board_contents, color, 0, 0) or (0, 0) in corners
+        for (piece, x, y, o), mask in zip(g["shift_spec"][k], g["shift_mask"][k]):        # anchors, random cells, edges
+            if piece < 0:
+                continue
+            got = board.check_orientation_shifts(color, PIECE_NAMES[piece], (int(x), int(y)), ORIENTATIONS[o])
+            assert got.dtype == np.int64 and sum(1 << int(j) for j in got) == int(mask), (k, piece, x, y, o)
+    assert Board().check_orientation_shifts(1, "monomino1", (20, 3), "north").tolist() == []      # off the board
+    assert Board().check_orientation_shifts(1, "pentominoe3", (0, 0), "north").size < 5            # some shifts leave the board
 
 
 def test_blokus_dropin_list_grows_past_its_first_capacity(golden):

@@ -175,3 +175,8 @@ def test_blokus_lists_on_arbitrary_boards():
         ok = bb.is_valid(torch.from_numpy(probe).cuda(), player=pl).cpu().numpy()
         member = np.array([int(probe[e] in set(ids2[e, :c2[e]].tolist())) for e in range(B)], np.uint8)
         assert np.array_equal(ok, member), trial
+        # fits = is_valid without the anchor / inventory conditions: every legal action fits; a legal action of a FULL
+        # inventory on this board that is not legal for the real one still fits
+        legal = np.where(c2 > 0, want, -1).astype(np.int32)
+        fits = bb.fits(torch.from_numpy(np.maximum(legal, 0)).cuda(), pl).cpu().numpy()
+        assert (fits[c2 > 0] == 1).all(), trial
