@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
-CRL_ABI_VERSION = 107
+CRL_ABI_VERSION = 108
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "crl_stream_synchronize": (_I, [_VP]),
     "crl_stream_wait_mapped": (_I, [_VP, _VP, _VP, _U32, C.c_double]),
     "crl_diag_issue_probe": (_I, [_VP, _VP, _I, _I, _VP]),
+    "crl_diag_bounds": (_I, [_VP]),
     "crl_philox4x32": (_I, [_VP, _U32, _U32, _VP, _I64, _VP]),
     "crl_tron_create": (_I, [_I, _I, _VP, _VP, C.POINTER(_VP)]),
     "crl_tron_reset": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -150,6 +151,20 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().crl_last_error()
         raise NativeError("%s failed (code %d): %s" % (what or "native call", rc, msg.decode() if msg else "?"))
+
+
+def bounds_report():
+    """{'compiled': bool, 'tron' | 'ttt' | 'blokus': {'failures', 'code', 'value', 'limit'}} of the loaded library's bounds
+    asserts (``crl_diag_bounds``): all zero for the shipped build, which compiles none (tools/lib_bounds.sh builds the variant
+    that does; tools/gpu_bounds.sh runs the suite on it)."""
+    out = (C.c_uint32 * 12)()
+    rc = lib().crl_diag_bounds(out)
+    if rc < 0:
+        check(rc, "crl_diag_bounds")
+    rep = {"compiled": rc == 1}
+    for i, name in enumerate(("tron", "ttt", "blokus")):
+        rep[name] = dict(zip(("failures", "code", "value", "limit"), [int(v) for v in out[4 * i:4 * i + 4]]))
+    return rep
 
 
 def require_gpu():

@@ -337,7 +337,12 @@ __device__ __forceinline__ uint32_t blk_shape_count(const WaveLds &L, const Dist
     auto one_row = [&](const int y) {
         uint2 v[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) v[j] = *reinterpret_cast<const uint2 *>(cellrow[j] + y * BLK_SH_ROW_BYTES);
+        for (int j = 0; j < 5; ++j) {
+            // the read stays inside the wave's pre-shifted table (rows 28..30 are there for the lanes that overshoot)
+            CRL_BOUNDS_IN(cellrow[j] + y * BLK_SH_ROW_BYTES - reinterpret_cast<const char *>(&L), offsetof(WaveLds, u),
+                          offsetof(WaveLds, u) + sizeof(L.u) - sizeof(uint2) + 1, 315);
+            v[j] = *reinterpret_cast<const uint2 *>(cellrow[j] + y * BLK_SH_ROW_BYTES);
+        }
         const uint32_t F = v[0].x & v[1].x & v[2].x & v[3].x & v[4].x;   // bit x+4: the shape fits at origin (x, y)
         // bit x+4 of v[j].y: cell j of the shape at origin (x, y) is an anchor.  (v_bcnt_u32_b32 adds its second operand:
         // accumulate in the instruction itself; left to the compiler the five counts go through a tree of v_add3)
@@ -425,6 +430,8 @@ __device__ __forceinline__ bool blk_exists(const BlkTables &T, WaveLds &L, const
     for (int base = 0; base < items; base += 64) {
         const int i = base + lane;
         const bool active = i < items;
+        CRL_BOUNDS_LT(active ? i : 0, NSHAPE, 311);
+        CRL_BOUNDS_LT(active ? (int)L.items[i] : 0, NDISTINCT, 312);
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
         const uint32_t c = blk_shape_count<true>(L, e, active, y0, y1 - y0 + 1);
         if (__ballot(c > 0)) return true;
@@ -467,6 +474,8 @@ __device__ __forceinline__ uint32_t blk_count_batches(const BlkTables &T, WaveLd
         const int split_log = left <= 16 ? 2 : (left <= 48 ? 1 : 0);         // wave-uniform
         const int i = base + (lane >> split_log), part = lane & ((1 << split_log) - 1);
         const bool active = i < items;
+        CRL_BOUNDS_LT(active ? i : 0, NSHAPE, 313);
+        CRL_BOUNDS_LT(active ? (int)L.items[i] : 0, NDISTINCT, 314);
         const DistinctRegs e = blk_load_distinct(T, active ? (int)L.items[i] : 0);
         // the batch runs as many rows as its widest shape can need: the anchor rows' span plus that shape's extent, at most
         // the whole board -- the work list is ordered by extent, so the widest shape of a batch is its last (one v_readlane;
@@ -1362,6 +1371,7 @@ __device__ __forceinline__ void blk_list_windows(ListLds &S, const int lane, con
             m &= m - 1u;
             const uint32_t k = idx - (uint32_t)lo;
             if (k < (uint32_t)BLK_WT) Ww[k * 4 + 3] = (uint32_t)ax | ((uint32_t)lane << 8);
+            CRL_BOUNDS_LT(ax, BN, 301);
             idx += 1u;
         }
     }
@@ -1376,6 +1386,8 @@ __device__ __forceinline__ void blk_list_windows(ListLds &S, const int lane, con
             uint32_t w[3] = {0u, 0u, 0u};
 #pragma unroll
             for (int dy = 0; dy < 9; ++dy) {             // acq[y + 4] holds row y << 8: window column dx is bit ax + dx + 8
+                CRL_BOUNDS_LT(ay + dy, 32, 302);                 // padded rows -4 .. 27
+                CRL_BOUNDS_LT(ax + 4 + 9, 33, 303);              // the nine window columns lie inside the 32-bit row word
                 const uint32_t row = S.acq[ay + dy].x;
                 w[dy / 3] |= ((row >> (ax + 4)) & 0x1ffu) << (9 * (dy % 3));
             }
@@ -1405,12 +1417,17 @@ __device__ __forceinline__ uint32_t blk_list_units(const ListLds &S, const uint4
         const uint32_t item = (uint32_t)(s * 64) + (uint32_t)ln;  // by 32 alone was five instructions)
         const uint32_t a = item / (uint32_t)(8 * N);
         slot[s] = (int)a;
+        CRL_BOUNDS_LT(a, 8u, 304);
+        CRL_BOUNDS_LT(item - a * (uint32_t)(8 * N), 40u, 305);   // a piece's 8 N <= 40 patterns
         pat[s] = Pp[item - a * (uint32_t)(8 * N)];
     }
     for (int u = 0; u < n_c; u += 8) {
         uint4 w[N];                                              // the unit's window reads go out together
 #pragma unroll
-        for (int s = 0; s < N; ++s) w[s] = S.wt[u + slot[s]];
+        for (int s = 0; s < N; ++s) {
+            CRL_BOUNDS_LT(u + slot[s], BLK_WT, 306);             // inside the (padded) chunk of the window table
+            w[s] = S.wt[u + slot[s]];
+        }
 #pragma unroll
         for (int s = 0; s < N; ++s) {
             const bool legal = ((w[s].x & pat[s].x) | (w[s].y & pat[s].y) | (w[s].z & pat[s].z)) == 0u;
@@ -1583,6 +1600,12 @@ void crl_blokus_free(void *tables)
 #define BLK_CTX_CHECK(fn)                                                                       \
     CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_BLOKUS && ctx->blokus, fn ": ctx is not a blokus context"); \
     CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 28), fn ": B=%lld out of range", (long long)B)
+
+int crl_blokus_bounds(unsigned int *out4)
+{
+    CRL_BOUNDS_READBACK(out4);
+    return CRL_OK;
+}
 
 extern "C" {
 

@@ -52,6 +52,15 @@ __global__ void __launch_bounds__(256) issue_probe_kernel(uint32_t *out, uint64_
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+#ifdef CRL_BOUNDS
+// self-test of the bounds asserts (this translation unit's own counters): one check that must fail
+__global__ void bounds_selftest_kernel()
+{
+    CRL_BOUNDS_LT(5, 3, 999);
+    CRL_BOUNDS_IN(7, 4, 8, 998);                                // ... and one that must hold
+}
+#endif
+
 // publishes `seq` in host-mapped memory behind everything the stream ran before it (crl_stream_wait_mapped)
 __global__ void __launch_bounds__(64) signal_kernel(uint32_t *flag, const uint32_t seq)
 {
@@ -151,6 +160,31 @@ int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile u
     CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
     CRL_REQUIRE(*flag_host == seq, "crl_stream_wait_mapped: the stream drained but the flag reads %u, not %u", (unsigned)*flag_host, (unsigned)seq);
     return CRL_OK;
+}
+
+int crl_diag_bounds(uint32_t *out12)
+{
+    CRL_REQUIRE(out12 != nullptr, "crl_diag_bounds: out12 is NULL");
+#ifdef CRL_BOUNDS
+    {   // a build with asserts proves on every call that a failing assert is recorded
+        unsigned int st[4] = {0, 0, 0, 0};
+        CRL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_crl_bounds), st, sizeof(st)));
+        hipLaunchKernelGGL(bounds_selftest_kernel, dim3(1), dim3(1), 0, 0);
+        CRL_LAUNCH_CHECK();
+        CRL_BOUNDS_READBACK(st);
+        CRL_REQUIRE(st[0] == 1u && st[1] == 999u && st[2] == 5u && st[3] == 3u,
+                    "crl_diag_bounds: self-test failed (%u failures, first code %u value %u limit %u)", st[0], st[1], st[2], st[3]);
+    }
+#endif
+    int rc = crl_tron_bounds(out12);
+    if (rc == CRL_OK) rc = crl_ttt_bounds(out12 + 4);
+    if (rc == CRL_OK) rc = crl_blokus_bounds(out12 + 8);
+    if (rc != CRL_OK) return rc;
+#ifdef CRL_BOUNDS
+    return 1;                                                    // the asserts are compiled in
+#else
+    return 0;
+#endif
 }
 
 int crl_diag_issue_probe(uint32_t *out, uint64_t *clk, int blocks, int iters, void *stream)

@@ -59,6 +59,36 @@ void crl_set_error(const char *fmt, ...);
 
 #define CRL_LAUNCH_CHECK() CRL_HIP(hipGetLastError())
 
+// ---------------------------------------------------------------- bounds asserts (diagnostic build: -DCRL_BOUNDS)
+// GPU AddressSanitizer is not available on this pool, so the data-dependent LDS / table accesses of the kernels carry
+// explicit range checks in a build of their own (tools/gpu_bounds.sh): a failing check does not fault, it counts itself
+// and keeps the first offender -- {failures, code, value, limit} per translation unit, read by crl_diag_bounds().  The
+// shipped build compiles none of it (the macros expand to nothing).  Codes: 1xx tron.hip, 2xx ttt.hip, 3xx blokus.hip.
+#ifdef CRL_BOUNDS
+namespace {
+__device__ unsigned int g_crl_bounds[4];
+__device__ __forceinline__ void crl_bounds_fail(const unsigned code, const unsigned v, const unsigned lim)
+{
+    if (atomicAdd(&g_crl_bounds[0], 1u) == 0u) { g_crl_bounds[1] = code; g_crl_bounds[2] = v; g_crl_bounds[3] = lim; }
+}
+} // namespace
+#define CRL_BOUNDS_LT(v, lim, code) do { if (!((unsigned)(v) < (unsigned)(lim))) crl_bounds_fail((code), (unsigned)(v), (unsigned)(lim)); } while (0)
+#define CRL_BOUNDS_IN(a, lo, hi, code) CRL_BOUNDS_LT((unsigned)(a) - (unsigned)(lo), (unsigned)(hi) - (unsigned)(lo), (code))
+#define CRL_BOUNDS_READBACK(out4)                                                                       \
+    do {                                                                                                \
+        CRL_HIP(hipDeviceSynchronize());                                                                \
+        CRL_HIP(hipMemcpyFromSymbol((out4), HIP_SYMBOL(g_crl_bounds), 4 * sizeof(unsigned int)));       \
+    } while (0)
+#else
+#define CRL_BOUNDS_LT(v, lim, code) do { } while (0)
+#define CRL_BOUNDS_IN(a, lo, hi, code) do { } while (0)
+#define CRL_BOUNDS_READBACK(out4) do { (out4)[0] = (out4)[1] = (out4)[2] = (out4)[3] = 0u; } while (0)
+#endif
+// {failures, first code, first value, first limit} of one translation unit (zeros in the shipped build)
+int crl_tron_bounds(unsigned int *out4);
+int crl_ttt_bounds(unsigned int *out4);
+int crl_blokus_bounds(unsigned int *out4);
+
 // ---------------------------------------------------------------- Philox-4x32-10
 // Salmon et al., SC'11 (Random123 constants). 10 rounds of two 32 x 32 -> 64-bit products.
 // WIDE: each product is ONE v_mad_u64_u32 instead of the v_mul_lo_u32 + v_mul_hi_u32 pair the compiler picks (it splits

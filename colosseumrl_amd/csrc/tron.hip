@@ -1197,6 +1197,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         // (the probe as inline asm: the compiler would mask the byte it loads with 0xff once more; its own waitcnts stay
         //  correct, LDS operations retire in order and an extra one in flight only makes them conservative)
         uint32_t raw;
+        CRL_BOUNDS_IN(tq, mine, mine + pad.stride, 101);       // the probe stays inside my game's slab (junk byte included)
         asm volatile("ds_read_u8 %0, %1" : "=v"(raw) : "v"(tq) : "memory");
         // does anything in this wave need the reference's sequential order?  my target against the other players'
         // heads (head-on, CyTronGrid.pyx:51-57) and targets (two players entering one cell; every pair is seen from
@@ -1221,6 +1222,7 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
         h = moved ? tgt : h;
         // the trail: a head cell already holds its player's stamp (new_state / every earlier move put it there), so a
         // player that stays where it is restamps its own head and the store needs no condition
+        CRL_BOUNDS_IN(h, mine, mine + pad.stride, 102);        // ... and so does the trail store
         *(lds_u8 *)(uintptr_t)(uint32_t)h = (uint8_t)stamp;
         bool alive_now = moved;
 #if defined(CRL_DIAG_NO_SLOW)      /* diagnostic builds only (WRONG results): what the interaction path costs the common one */
@@ -2090,6 +2092,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     int a = (pvalid && k_in == 0) ? 1 : 0;
     auto store_group = [&](const int grp) {                     // my 16 bytes of group grp of the spare slab
 #ifndef CRL_DIAG_NO_REWRITE     /* diagnostic builds only (WRONG results): what the rolling rewrite of the spare slab costs */
+        CRL_BOUNDS_IN(spare_p + 64 * grp, mine, mine + bits.stride - 15, 112);   // the rolling rewrite's 16 bytes
         *(lds_u128 *)(uintptr_t)(uint32_t)(spare_p + 64 * grp) = fresh[grp];
 #endif
     };
@@ -2118,6 +2121,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         // one; the LDS array is what this kernel waits for.)  Two players of a game entering one cell in one step see each
         // other's bit, whichever the LDS serves first: that is an interaction, and the fix-up below sorts it out.
         uint32_t word;
+        CRL_BOUNDS_IN(wa, mine, mine + bits.stride, 111);       // the probed word lies in my game's two slabs + junk words
 #ifdef CRL_QBITS_PROBE_THEN_OR     /* the round-2 form, kept for A/B builds */
         asm volatile("ds_read_b32 %0, %1" : "=v"(word) : "v"(wa) : "memory");
 #else
@@ -2944,6 +2948,12 @@ constexpr int kLdsDynamic = 160 * 1024 - 1024;  // dynamic part; the kernels als
         case 4: { constexpr int PP = 4; CALL; } break; \
         default: crl_set_error("tron: P=%d out of range 1..4", P_); return CRL_EINVAL; \
     }
+
+int crl_tron_bounds(unsigned int *out4)
+{
+    CRL_BOUNDS_READBACK(out4);
+    return CRL_OK;
+}
 
 extern "C" {
 

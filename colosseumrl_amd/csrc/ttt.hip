@@ -141,6 +141,7 @@ __device__ __forceinline__ uint32_t nth_set_bit_tab(const uint8_t (&tab)[256 * 8
     uint32_t rr = r, pos = 0, c;
     if (!SMALL) { c = (uint32_t)__popc(m & 0xffffu);                pos = (rr >= c) ? 16u : 0u;          rr = min(rr, rr - c); }
     c = (uint32_t)__popc(__builtin_amdgcn_ubfe(m, pos, 8u));        pos = (rr >= c) ? pos + 8u : pos;    rr = min(rr, rr - c);
+    CRL_BOUNDS_LT(rr, 8u, 201);                                  // the rank left for the byte table is a rank INSIDE that byte
     return pos + tab[__builtin_amdgcn_ubfe(m, pos, 8u) * 8u + rr];
 }
 
@@ -281,7 +282,10 @@ ttt_rollout_kernel(const ttt_dirs dd, const int64_t B, const uint32_t seed_lo, c
         const uint32_t bit = 1u << nth_set_bit_tab<SMALL>(rank_tab, empty, __umulhi(word, n_empty));
         const uint32_t mine = r[0] | bit;                                              // :295
         bool won;                                                                      // :296-300
-        if constexpr (TABLE) won = ((win_bits[mine >> 5] >> (mine & 31u)) & 1u) != 0u;
+        if constexpr (TABLE) {
+            CRL_BOUNDS_LT(mine >> 5, 2048u, 202);               // masks of boards with at most 16 cells
+            won = ((win_bits[mine >> 5] >> (mine & 31u)) & 1u) != 0u;
+        }
         else won = ttt_has_line<ND, KC>(dd, mine);
         all_run |= bit;
         const bool term = won | (all_run == dd.full);                                  // :302-311
@@ -726,6 +730,12 @@ inline const ttt_dirs &dirs_of(const crl_ctx *ctx) { return ctx->ttt_dd; }     /
 #define TTT_CTX_CHECK(fn)                                                                  \
     CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TTT, fn ": ctx is not a tictactoe context"); \
     CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 31), fn ": B=%lld out of range", (long long)B)
+
+int crl_ttt_bounds(unsigned int *out4)
+{
+    CRL_BOUNDS_READBACK(out4);
+    return CRL_OK;
+}
 
 extern "C" {
 

@@ -64,8 +64,8 @@ const char *crl_last_error(void);
  * contract of the sampled agents changes.  crl_version() returns the revision the LIBRARY was built from; a binding must
  * refuse a library whose revision differs from the header it was written against (colosseumrl_amd/_native.py does).
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
- * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits (this header). */
-#define CRL_ABI_VERSION 107
+ * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits.  108: crl_diag_bounds. */
+#define CRL_ABI_VERSION 108
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -103,6 +103,12 @@ int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile u
  * instructions per second = blocks x 4 x iters x 64 / time.  bench.py runs it at 4 waves per SIMD next to the rollouts, so
  * that a box whose clocks are capped shows in the record (the rollout kernels are bound by instruction issue). */
 int crl_diag_issue_probe(uint32_t *out, uint64_t *clk, int blocks, int iters, void *stream);
+/* The bounds asserts of a -DCRL_BOUNDS build (tools/gpu_bounds.sh; GPU AddressSanitizer is not available on the pool): out12
+ * (HOST) = {failed checks, code of the first, its value, its limit} for tron.hip, ttt.hip and blokus.hip -- the range checks
+ * on the kernels' data-dependent LDS / table accesses.  Synchronises the device.  Returns 1 from a build with the asserts
+ * (after a self-test: a check that must fail is run and must be recorded), 0 from the shipped build, which compiles no
+ * check and reports zeros; negative on error. */
+int crl_diag_bounds(uint32_t *out12);
 
 /* ------------------------------------------------------------------ RNG (exposed for parity tests) */
 /* out[i*4..i*4+3] = Philox-4x32-10(ctr[i*4..], key); n counters; DEVICE pointers */

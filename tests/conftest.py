@@ -36,6 +36,13 @@ _launcher = None
 
 def pytest_sessionfinish(session, exitstatus):
     global _launcher
+    if os.environ.get("CRL_EXPECT_BOUNDS_BUILD") == "1":        # tools/gpu_bounds.sh: the suite ran on the bounds-assert build
+        from colosseumrl_amd import _native
+        rep = _native.bounds_report()
+        bad = (not rep["compiled"]) or any(rep[k]["failures"] for k in ("tron", "ttt", "blokus"))
+        print("\nbounds asserts: %s %s" % ("FAILED" if bad else "clean", rep))
+        if bad:
+            session.exitstatus = 1
     if _launcher is not None:
         try:
             _launcher.stdin.close()

@@ -64,4 +64,10 @@ for case in range(n_cases):
     if case % 20 == 19:
         print("case %d done, %.0f s, mismatches %d" % (case + 1, time.time() - t0, bad), flush=True)
 print("fuzz: %d cases, %d mismatches" % (n_cases, bad))
+if os.environ.get("CRL_EXPECT_BOUNDS_BUILD") == "1":         # tools/gpu_bounds.sh: this run is on the bounds-assert build
+    from colosseumrl_amd import _native
+    rep = _native.bounds_report()
+    wrong = (not rep["compiled"]) or any(rep[k]["failures"] for k in ("tron", "ttt", "blokus"))
+    print("bounds asserts: %s %s" % ("FAILED" if wrong else "clean", rep))
+    bad += 1 if wrong else 0
 sys.exit(1 if bad else 0)
