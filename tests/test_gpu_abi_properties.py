@@ -233,3 +233,14 @@ def test_stream_wait_mapped_orders_behind_the_stream_and_falls_back():
         assert int(flag.v["seq"][0]) == seq
     assert lib.crl_stream_wait_mapped(stream, None, host_ptr, 4, 1.0) != 0 and b"NULL" in lib.crl_last_error()
     torch.cuda.synchronize()
+
+
+def test_shipped_build_compiles_no_bounds_asserts():
+    """crl_diag_bounds on the library the suite runs on: the shipped build has no asserts (zeros, 'compiled' False); under
+    tools/gpu_bounds.sh (CRL_EXPECT_BOUNDS_BUILD=1) it is the assert build, whose self-test has then just passed."""
+    import os
+    from colosseumrl_amd import _native
+    rep = _native.bounds_report()
+    assert rep["compiled"] == (os.environ.get("CRL_EXPECT_BOUNDS_BUILD") == "1")
+    if not rep["compiled"]:
+        assert all(v == 0 for k in ("tron", "ttt", "blokus") for v in rep[k].values())
