@@ -220,6 +220,9 @@ __device__ __forceinline__ void tron_resolve_lds(const BOARD &bd, TronRegs<P> &s
         for (int q = 0; q < P; ++q)
             if (q != i) s.k[q] = (run & on_head[q]) ? i + 1 : s.k[q];                 // :56-57
         s.h[i] = moved ? pr.tgt[i] : s.h[i];
+#ifdef CRL_BOUNDS
+        CRL_BOUNDS_IN(moved ? pr.tgt[i] : junk, bd.lo, bd.hi, 123);
+#endif
         *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? pr.tgt[i] : junk) = (uint8_t)stamp[i];
     }
 }
@@ -668,13 +671,26 @@ struct TronPad {
 template <int OB>
 struct LdsBoard {
     uint32_t tagbits;               // tag << OB
+#ifdef CRL_BOUNDS                   /* the bounds-assert build: [lo, hi) = the slab (junk byte included) every access must hit */
+    int lo = 0, hi = 0x7fffffff;
+    __device__ __forceinline__ void within(const int lo_, const int hi_) { lo = lo_; hi = hi_; }
+    __device__ __forceinline__ int raw(const int a) const { CRL_BOUNDS_IN(a, lo, hi, 121); return *(const lds_u8 *)(uintptr_t)(uint32_t)a; }
+#else
+    __device__ __forceinline__ void within(const int, const int) {}
     __device__ __forceinline__ int raw(const int a) const { return *(const lds_u8 *)(uintptr_t)(uint32_t)a; }
+#endif
     __device__ __forceinline__ int owner(const int r) const
     {
         const uint32_t x = (uint32_t)r ^ tagbits;
         return x < (1u << OB) ? (int)x : 0;
     }
-    __device__ __forceinline__ void put(const int a, const int who) const { *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)(tagbits | (uint32_t)who); }
+    __device__ __forceinline__ void put(const int a, const int who) const
+    {
+#ifdef CRL_BOUNDS
+        CRL_BOUNDS_IN(a, lo, hi, 122);
+#endif
+        *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)(tagbits | (uint32_t)who);
+    }
 };
 
 // Slab byte offsets (relative to the slab start) of the four dwords of a 16-byte piece of a board whose first cell
@@ -819,6 +835,7 @@ tron_rollout_lds_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad 
     TronRng<P> rng;
     rng.start(gid, acc.tc, seed_lo, seed_hi);
     LdsBoard<OB> bd{0u};
+    bd.within(mine, mine + pad.stride);
     uint32_t stamp[P];                                          // the byte a trail cell of player p gets: tag | p + 1
 #pragma unroll
     for (int p = 0; p < P; ++p) stamp[p] = (uint32_t)(p + 1);
@@ -1255,7 +1272,8 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             pr.ndir[0] = tron_quad<0x00>(dir); pr.ndir[1] = tron_quad<0x55>(dir); pr.ndir[2] = tron_quad<0xAA>(dir); pr.ndir[3] = tron_quad<0xFF>(dir);
 #pragma unroll
             for (int q = 0; q < 4; ++q) stamp4[q] = tagbits | (uint32_t)(q + 1);
-            const LdsBoard<OB> bd{tagbits};
+            LdsBoard<OB> bd{tagbits};
+            bd.within(mine, mine + pad.stride);
             tron_resolve_lds<4>(bd, s, pr, stamp4, junk);       // trail writes of all four players from every lane: identical
             int hS = s.h[0], dS = s.d[0], kS = s.k[0];
             hS = (p == 1) ? s.h[1] : hS; dS = (p == 1) ? s.d[1] : dS; kS = (p == 1) ? s.k[1] : kS;
@@ -1559,6 +1577,7 @@ __device__ __forceinline__ void tron_replay_lane(const crl_tron_cfg &cfg, const 
     }
     const int junk = bmine + pad.junk;
     LdsBoard<(P <= 7) ? 3 : 4> bd{0u};                          // single episode: tag 0, cells hold the plain owner
+    bd.within(bmine, bmine + pad.stride);
     TronRng<P> rr;
     int act[P];
     rr.start(gid, c_r, seed_lo, seed_hi);
