@@ -645,7 +645,11 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
             uint32_t fr = pair ? 0xffffffffu : 0u;
             const char *rowp = acq + ay * (int)sizeof(uint2);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
+            for (int k = 0; k < 5; ++k) {
+                // the cell's padded row of player q: one of ac[q][0 .. 31]
+                CRL_BOUNDS_IN(rowp + rowoff[k] - reinterpret_cast<const char *>(&L.ac[q][0]), 0, 32 * (int)sizeof(uint2) - (int)sizeof(uint2) + 1, 321);
+                fr &= reinterpret_cast<const uint2 *>(rowp + rowoff[k])->x >> colsh[k];
+            }
             m = fr & cr;
             row_total = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl((uint32_t)__popc(m), lane), 63);
             if (rr < row_total) break;
