@@ -9,7 +9,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCRIPTS = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "debug", "*.py")))
+SCRIPTS = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "debug", "*.py"))
+                 + glob.glob(os.path.join(ROOT, "examples", "*.py")))
 
 
 def test_there_are_scripts_to_check():
@@ -54,6 +55,10 @@ GPU_RUNS = [
     (["tools/kernel_ab.py", "20", "64"], "quad"),
     (["tools/debug/dropin_stress.py", "3", "1500"], "0 errors"),
     (["tools/debug/host_latency.py"], "region raw"),
+    (["examples/dropin_game.py", "tron", "1"], "ranking"),
+    (["examples/dropin_game.py", "blokus", "2"], "ranking"),
+    (["examples/dropin_game.py", "tictactoe_4p", "3"], "ranking"),
+    (["examples/batched_rollout.py", "8192"], "BlokusVectorEnv: 20 plies"),
     (["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "@FREE_PORT@",
       "tools/debug/gather_latency.py"], "region median"),
 ]
