@@ -682,32 +682,38 @@ __device__ __forceinline__ BlkMove blk_select(const BlkTables &T, WaveLds &L, co
     return back ? walk(std::true_type{}) : walk(std::false_type{});
 }
 
-// place the piece (board.py:87-103; no legality check there) and update inventory / score (ai.py:44-54)
-// LEGAL: the move is known to be legal (the rollout plays what blk_select found), so its cells are empty and only the
-// mover's colour changes; otherwise an (illegal) overlap overwrites the other colours, like the reference.
-template <bool LEGAL = false>
-__device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv,
-                                          uint32_t (&inv)[4], int (&score)[4], const int lane)
+// Board.update_board + AI.update_player as next_state runs them (BlokusEnvironment.py:417-420), for ANY action a caller
+// hands over -- the reference does not test legality here (match_server.py:193 does, before the call):
+//   * board.py:87-103 writes board_contents[y][x] = colour cell by cell under numpy's index rules: -20..-1 wrap around,
+//     anything else outside 0..19 raises IndexError; a cell of another colour is overwritten;
+//   * a shift id that names no cell of the piece raises IndexError (computation.py:218, offsets[offset_id]);
+//   * ai.py:47 raises ValueError for a piece the mover does not hold -- after the board update, so the IndexError wins.
+// next_state works on copies (:408-409): a raise leaves the state as it was.  Returns 0, CRL_BLOKUS_INDEX_ERROR or
+// CRL_BLOKUS_VALUE_ERROR (wave-uniform); LDS rows, inventories and scores are touched only when it returns 0.
+__device__ __forceinline__ int blk_apply(const BlkTables &T, WaveLds &L, const int q, const BlkMove &mv,
+                                         uint32_t (&inv)[4], int (&score)[4], const int lane)
 {
-    // the cell bytes straight out of the table: lane j its own cell, everybody the anchored one (round 2 picked both out
-    // of the packed shape registers with two chains of five selects)
+    // the cell bytes straight out of the table: lane j its own cell, everybody the anchored one
     const int n = __builtin_amdgcn_readfirstlane((int)T.ncell[mv.piece]);
+    if (mv.shift >= n) return CRL_BLOKUS_INDEX_ERROR;
     const uint8_t *cells = &T.cells[mv.piece * 8 + mv.orient][0];
     const uint32_t oc = cells[mv.shift];
     const int ox = (int)(oc & 15u), oy = (int)(oc >> 4);
-    if (lane < n) {
-        const uint32_t cc = cells[lane];
-        const int cx = (int)(cc & 15u), cy = (int)(cc >> 4);
-        const int x = mv.x + cx - ox, y = mv.y + cy - oy;
-        if (x >= 0 && x < BN && y >= 0 && y < BN) {
-            if (LEGAL) {
-                atomicOr(&L.occ[q][y], 1u << x);
-            } else {
-                for (int c = 0; c < 4; ++c) {
-                    if (c == q) atomicOr(&L.occ[c][y], 1u << x);
-                    else atomicAnd(&L.occ[c][y], ~(1u << x));
-                }
-            }
+    const uint32_t cc = cells[lane < n ? lane : 0];
+    int x = mv.x + (int)(cc & 15u) - ox, y = mv.y + (int)(cc >> 4) - oy;
+    const bool mine = lane < n;
+    if (__ballot(mine && (x < -BN || x >= BN || y < -BN || y >= BN)) != 0ull) return CRL_BLOKUS_INDEX_ERROR;
+    uint32_t held = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) held = (c == q) ? inv[c] : held;
+    if (!((held >> mv.piece) & 1u)) return CRL_BLOKUS_VALUE_ERROR;
+    x += x < 0 ? BN : 0;                                   // numpy's negative indices
+    y += y < 0 ? BN : 0;
+    if (mine) {
+        CRL_BOUNDS_IN(y * 32 + x, 0, BN * 32, 330);
+        for (int c = 0; c < 4; ++c) {
+            if (c == q) atomicOr(&L.occ[c][y], 1u << x);
+            else atomicAnd(&L.occ[c][y], ~(1u << x));
         }
     }
 #pragma unroll
@@ -718,6 +724,7 @@ __device__ __forceinline__ void blk_apply(const BlkTables &T, WaveLds &L, const 
         }
     }
     wave_sync();
+    return 0;
 }
 
 // the board part of blk_apply for a move known to be legal (its cells are empty: only the mover's colour changes)
@@ -801,6 +808,31 @@ __device__ __forceinline__ BlkMove blk_decode(const int id)
     return mv;
 }
 
+// what the step entries accept: the dense ids above and, from CRL_BLOKUS_EXT_BASE on, ids whose index lies anywhere in
+// [-20, 20) x [-20, 20) (next_state takes whatever string_to_action parsed, BlokusEnvironment.py:417); false: no such action
+__device__ __forceinline__ bool blk_decode_any(const int id, BlkMove &mv)
+{
+    if (id < ACTION_IDS) { mv = blk_decode(id); return true; }
+    const int a = id - CRL_BLOKUS_EXT_BASE;
+    if (a >= CRL_BLOKUS_EXT_IDS) return false;
+    mv.shift = a % 5;
+    mv.orient = (a / 5) & 7;
+    const int cell = (a / 40) % 1600;
+    mv.piece = a / 64000;
+    mv.x = cell % 40 - BN;
+    mv.y = cell / 40 - BN;
+    return true;
+}
+
+// the action part of next_state for an id >= 0: 0 or the code the reward slot carries
+__device__ __forceinline__ int blk_play(const BlkTables &T, WaveLds &L, const int q, const int id,
+                                        uint32_t (&inv)[4], int (&score)[4], const int lane)
+{
+    BlkMove mv;
+    if (!blk_decode_any(id, mv)) return CRL_BLOKUS_BAD_ACTION;
+    return blk_apply(T, L, q, mv, inv, score, lane);
+}
+
 #define BLK_SHARED_SETUP()                                                                        \
     __shared__ BlkTables T;                                                                       \
     __shared__ WaveLds Lw[4];                                                                     \
@@ -848,20 +880,20 @@ blokus_step_kernel(const BlkTables *__restrict__ tables, const int64_t B, uint32
     int round = __builtin_amdgcn_readfirstlane(round_g[b]), pl = __builtin_amdgcn_readfirstlane(to_move_g[b]) & 3;
     blk_prep(L, lane, round);                                    // allowed / corner rows of the PRE-move board (:424)
     const int id = __builtin_amdgcn_readfirstlane(action[b]);
-    if (id >= 0 && id < ACTION_IDS) {                            // '' (pass) otherwise (:418)
-        const BlkMove mv = blk_decode(id);
-        blk_apply(T, L, pl, mv, inv, score, lane);
-    }
-    bool any_move = false;
-    for (int q = 0; q < 4 && !any_move; ++q) {                   // old board, old round, NEW inventories (:424)
-        uint32_t iq = 0;
+    const int status = id >= 0 ? blk_play(T, L, pl, id, inv, score, lane) : 0;   // '' (pass) below 0 (:418)
+    BlkOutcome out = {status, 0, 0};                             // the reference raises: the state stays, the code goes out
+    if (status == 0) {
+        bool any_move = false;
+        for (int q = 0; q < 4 && !any_move; ++q) {               // old board, old round, NEW inventories (:424)
+            uint32_t iq = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
-        any_move = blk_exists(T, L, q, iq, lane);
+            for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+            any_move = blk_exists(T, L, q, iq, lane);
+        }
+        out = blk_outcome(any_move, pl, score);
+        round += (pl == 3) ? 1 : 0;                              // :446-447
+        pl = (pl + 1) & 3;
     }
-    const BlkOutcome out = blk_outcome(any_move, pl, score);
-    round += (pl == 3) ? 1 : 0;                                  // :446-447
-    pl = (pl + 1) & 3;
     if (lane == 0) {
         reward[b] = (int8_t)out.reward;
         terminal[b] = (uint8_t)out.terminal;
@@ -1037,20 +1069,20 @@ blokus_step_observe_kernel(const BlkTables *__restrict__ tables, const int64_t B
         }
         if (lane == 0) tcount[b] = tc + 1u;
     }
-    if (id >= 0 && id < ACTION_IDS) {                            // '' (pass) otherwise (:418)
-        const BlkMove mv = blk_decode(id);
-        blk_apply(T, L, pl, mv, inv, score, lane);
-    }
-    bool any_move = false;
-    for (int q = 0; q < 4 && !any_move; ++q) {                   // old board, old round, NEW inventories (:424)
-        uint32_t iq = 0;
+    const int status = id >= 0 ? blk_play(T, L, pl, id, inv, score, lane) : 0;   // '' (pass) below 0 (:418)
+    BlkOutcome out = {status, 0, 0};                             // the reference raises: the state stays, the code goes out
+    if (status == 0) {
+        bool any_move = false;
+        for (int q = 0; q < 4 && !any_move; ++q) {               // old board, old round, NEW inventories (:424)
+            uint32_t iq = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
-        any_move = blk_exists(T, L, q, iq, lane);
+            for (int c = 0; c < 4; ++c) iq = (c == q) ? inv[c] : iq;
+            any_move = blk_exists(T, L, q, iq, lane);
+        }
+        out = blk_outcome(any_move, pl, score);
+        round += (pl == 3) ? 1 : 0;                              // :446-447
+        pl = (pl + 1) & 3;
     }
-    const BlkOutcome out = blk_outcome(any_move, pl, score);
-    round += (pl == 3) ? 1 : 0;                                  // :446-447
-    pl = (pl + 1) & 3;
     if (lane == 0) {
         reward[b] = (int8_t)out.reward;
         terminal[b] = (uint8_t)out.terminal;

@@ -2426,9 +2426,8 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
     if (threadIdx.x < (unsigned)P) {
         uint32_t lo = 0, hi = 0;
         for (int v = 1; v < 8; ++v) {
-            int n = v - ((int)threadIdx.x + 1);                            // CyTronGrid.pyx:70-71
-            n = n < 0 ? n + P : n;
-            const uint32_t r = (v <= P) ? (uint32_t)(n + 1) : (uint32_t)v;
+            const int n = (v - ((int)threadIdx.x + 1) + P) % P;            // CyTronGrid.pyx:70-71 (every v > 0, also beyond P)
+            const uint32_t r = (uint32_t)(n + 1);
             if (v < 4) lo |= r << (8 * v); else hi |= r << (8 * (v - 4));
         }
         lut[threadIdx.x] = make_uint2(lo, hi);
@@ -2440,12 +2439,18 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (wide) {
             const int64_t off = i * 16;
+            // an observer id outside 0..P-1 is not refused by the reference: the rolled vectors use numpy's modulo
+            // (TronGridEnvironment.py:393), the board goes through C's remainder (CyTronGrid.pyx:1 cdivision=True, :71).
+            // Up to pr = P the operand v - (pr + 1) + P stays >= 0 and both agree (= observer pr mod P: the table);
+            // beyond, low trail ids come out <= 0 -- reproduced by the arithmetic branch
             const int pr = player[off / NN];
-            const int pl = ((unsigned)pr < (unsigned)P ? pr : 0) + 1;       // an id outside 0..P-1 observes as player 0
+            const int pl = pr + 1;
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
             uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
-            if (P <= 7) {
-                const uint2 t = lut[pl - 1];
+            if (P <= 7 && pr <= P) {
+                int pm = pr % P;
+                pm = pm < 0 ? pm + P : pm;
+                const uint2 t = lut[pm];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(t.y, t.x, w[q]);
             } else {
@@ -2454,9 +2459,8 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
                     uint32_t r = 0;
 #pragma unroll
                     for (int s8 = 0; s8 < 32; s8 += 8) {
-                        const int c = (int)((w[q] >> s8) & 0xffu);
-                        int n = c - pl;                                        // CyTronGrid.pyx:70-71, c in 1..P
-                        n = n < 0 ? n + P : n;
+                        const int c = (int)(int8_t)((w[q] >> s8) & 0xffu);
+                        const int n = (c - pl + P) % P;                        // CyTronGrid.pyx:70-71, C remainder
                         r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
                     }
                     o[q] = r;
@@ -2464,11 +2468,9 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
             }
             *reinterpret_cast<uint4 *>(obs + off) = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
-            const int pr = player[i / NN];
-            const int pl = ((unsigned)pr < (unsigned)P ? pr : 0) + 1;
+            const int pl = (int)player[i / NN] + 1;
             const int c = board[i];
-            int n = c - pl;
-            n = n < 0 ? n + P : n;
+            const int n = (c - pl + P) % P;                                    // C remainder, as above
             obs[i] = (int8_t)(c > 0 ? n + 1 : c);
         }
     }
@@ -2482,8 +2484,8 @@ tron_observe_players_kernel(const int64_t B, const int16_t *__restrict__ heads, 
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int pr = player[b];
-    const int pl = (unsigned)pr < (unsigned)P ? pr : 0;              // as the board kernel: out-of-range ids observe as player 0
+    int pl = (int)player[b] % P;                                     // rolled_idx = (arange + player) % P with numpy's modulo
+    pl = pl < 0 ? pl + P : pl;                                       // (TronGridEnvironment.py:393): any integer is an observer
     int h[P], d[P], k[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) { h[p] = heads[p * B + b]; d[p] = dirs[p * B + b]; k[p] = deaths[p * B + b]; }

@@ -147,17 +147,25 @@ class BlokusEnvironment(BaseEnvironment):
         host-mapped memory: pack -> step (+ the next mover's observation) -> board -> the next mover's ordered legal
         list, four launches on one stream, no copies, one synchronise.
 
-        As in the reference the action is NOT checked for legality here (callers use ``is_valid_action``);
-        a piece missing from the mover's inventory raises ``ValueError`` like ``list.remove`` does there.
+        As in the reference the action is NOT checked for legality here (callers use ``is_valid_action``): a placement
+        on occupied cells overwrites them and still scores, cells at x or y in -20..-1 wrap to the far edge (numpy's
+        negative indices, board.py:103), an orientation name that is none of the eight means 'east' (computation.py:85).
+        What raises there raises here, the same class in the same order (``A.string_to_step_id`` for what the string
+        alone decides; the kernel reports a cell outside numpy's range -> ``IndexError``, a piece missing from the
+        mover's inventory -> ``ValueError`` like ``list.remove``); the state handed in is never modified.
         """
         player_num, action = players[0], actions[0]
-        action_id = A.string_to_id(action) if len(action) > 0 else A.PASS
-        if action_id >= 0:
-            piece_name = A.PIECE_NAMES[action_id // 16000]
-            if piece_name not in state[2][player_num].current_pieces:
-                raise ValueError("list.remove(x): x not in list")
+        action_id = A.string_to_step_id(action) if len(action) > 0 else A.PASS
         st = self._load(state, player_num)
         st.step(action_id)
+        code = int(st.v["reward"][0])
+        if code < 0:                                   # the staged state is untouched and stays valid (self._staged)
+            self._seen = None
+            if code == A.INDEX_ERROR:
+                raise IndexError("index out of bounds for axis with size 20")
+            if code == A.VALUE_ERROR:
+                raise ValueError("list.remove(x): x not in list")
+            raise KeyError(action)
         v = st.v
         new_state = self._unload(st)
         self._staged = self._key(new_state)

@@ -78,6 +78,37 @@ def ids_to_strings(ids) -> list:
     return out
 
 
+EXT_BASE = 336000                     # CRL_BLOKUS_EXT_BASE: ids whose index lies anywhere in [-20, 20) x [-20, 20)
+INDEX_ERROR, VALUE_ERROR, BAD_ACTION = -1, -2, -3      # CRL_BLOKUS_*: what the step puts into the reward slot
+
+
+def string_to_step_id(action_str: str) -> int:
+    """The id ``crl_blokus_step`` takes for an action string ``next_state`` was handed -- ANY string, listed by
+    ``valid_actions`` or not -- raising what the reference raises before it touches the board, in its order: ``split`` /
+    ``int`` of string_to_action (ValueError, BlokusEnvironment.py:83-106), the piece name (KeyError, board.py:93), the shift
+    digit ``int(orientation[-1])`` (IndexError on an empty field, ValueError on a non-digit), a shift that names no cell of
+    the piece (IndexError, computation.py:218).  An orientation NAME that is none of the eight places the piece as 'east',
+    rotate_piece's default branch (computation.py:85-86).  An index outside [-20, 20) raises the IndexError numpy would
+    (board.py:103: the index cell itself is always written); cells of the piece that leave that range, and a piece the
+    mover does not hold, are found by the kernel (codes INDEX_ERROR / VALUE_ERROR in the reward slot)."""
+    parsed = string_to_action(action_str)
+    if parsed is None:
+        return PASS
+    piece_type, index, orientation = parsed
+    piece = PIECE_INDEX[piece_type]
+    shift = int(orientation[-1])
+    o = ORIENTATION_INDEX.get(orientation[:-1], 2)
+    if shift >= PIECE_VALUES[piece]:
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (shift, PIECE_VALUES[piece]))
+    x, y = index[0], index[1]
+    for v in (y, x):                                  # board_contents[y] is indexed first
+        if not -20 <= v < 20:
+            raise IndexError("index %d is out of bounds for axis 0 with size 20" % v)
+    if 0 <= x < 20 and 0 <= y < 20:
+        return encode(piece, x, y, o, shift)
+    return EXT_BASE + ((piece * 1600 + (y + 20) * 40 + (x + 20)) * 8 + o) * 5 + shift
+
+
 def string_to_id(action_str: str) -> int:
     """Action string -> dense id.  The shift is the LAST character of the orientation field, as in the
     reference's update_board (board.py:93); unknown pieces / orientations raise KeyError / ValueError."""

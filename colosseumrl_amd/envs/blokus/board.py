@@ -49,7 +49,13 @@ def placement_cells(piece_type: str, orientation: str):
     import ctypes as C
     from ... import _native
     cells = (C.c_int8 * 10)()
-    n = _native.lib().crl_blokus_placement(PIECE_INDEX[piece_type], ORIENTATIONS.index(orientation[:-1]), int(orientation[-1]), cells)
+    piece = PIECE_INDEX[piece_type]                                  # KeyError first, as PIECE_TYPES[piece_type] in board.py:93
+    shift = int(orientation[-1])
+    name = orientation[:-1]
+    o = ORIENTATIONS.index(name) if name in ORIENTATIONS else 2      # any other name: rotate_piece's default branch = east
+    if shift >= PIECE_VALUES[piece]:
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (shift, PIECE_VALUES[piece]))
+    n = _native.lib().crl_blokus_placement(piece, o, shift, cells)
     if n < 0:
         _native.check(n, "crl_blokus_placement")
     return [(int(cells[2 * j]), int(cells[2 * j + 1])) for j in range(n)]
@@ -84,9 +90,16 @@ class Board:
         return [decode(int(i))[1:3] for i in ids[::8]]            # eight orientations of the one-cell piece per anchor
 
     def check_valid_corner(self, board_contents, player_color, row_num, col_num):
-        probe = Board()
-        probe.board_contents = np.asarray(board_contents)
-        return board_contents[row_num][col_num] == 0 and (col_num, row_num) in probe.gather_empty_corner_indexes(player_color)
+        """No orthogonal neighbour of `player_color` and at least one diagonal one (reference :127-154).  As there, the cell
+        ITSELF is not looked at -- gather_empty_corner_indexes tests emptiness before it calls this (:121) -- so an occupied
+        cell can answer True.  Eight array reads on the record the caller holds: a host-side record method, no launch."""
+        b = board_contents
+        r, c = row_num, col_num
+        if (r != 0 and b[r - 1][c] == player_color) or (c != 0 and b[r][c - 1] == player_color) \
+                or (r != 19 and b[r + 1][c] == player_color) or (c != 19 and b[r][c + 1] == player_color):
+            return False
+        return bool((r != 0 and c != 19 and b[r - 1][c + 1] == player_color) or (r != 0 and c != 0 and b[r - 1][c - 1] == player_color)
+                    or (r != 19 and c != 19 and b[r + 1][c + 1] == player_color) or (r != 19 and c != 0 and b[r + 1][c - 1] == player_color))
 
     def check_orientation_shifts(self, player_color, piece_type, index, orientation):
         """Shift ids k (ascending, int64 array) for which `piece_type` in `orientation` fits with its cell k on `index`:
@@ -116,7 +129,7 @@ class Board:
 
     def calculate_winner(self, players, round_count):
         """Colour letter of the best score; with a tie, of the tied player the reference's stable sort by score visits
-        last; ``"NONE"`` when nobody has scored."""
+        last (so with nobody on the score sheet yet: the last player's, never the initial ``"NONE"``; reference :195-214)."""
         best = max([p.player_score for p in players] + [0])
         winner = "NONE"
         for p in sorted(players, key=lambda p: p.player_score):

@@ -189,8 +189,17 @@ class TronGridEnvironment(BaseEnvironment):
         P, N = self.num_players, self.N
         NN = N * N
         seen = self._observed
-        pl = player if 0 <= player < P else 0         # ids outside 0..P-1 observe as player 0 (crl_tron_observe)
-        if seen is not None and seen[0] == self._key(state):
+        # Any integer is an observer in the reference: the vectors roll by (arange + player) % P (:393) and the board goes
+        # through C's remainder (CyTronGrid.pyx:71, cdivision=True) -- up to player == P that is observer `player % P`,
+        # beyond P low trail ids come out <= 0; crl_tron_observe reproduces both.  int8 on the wire: fold the id into range
+        # without changing either result (2P + player % P keeps the sign of every v - (player + 1) + P and the class mod P).
+        player = int(player)
+        if player < 0:
+            player %= P
+        elif player >= 2 * P:
+            player = 2 * P + player % P
+        pl = player % P
+        if player <= P and seen is not None and seen[0] == self._key(state):
             board = seen[1][pl * NN:(pl + 1) * NN].astype(np.int64).reshape(N, N)
             heads = seen[2][pl * P:(pl + 1) * P].astype(np.int64)
             directions = seen[3][pl * P:(pl + 1) * P].astype(np.int64)

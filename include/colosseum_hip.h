@@ -64,8 +64,10 @@ const char *crl_last_error(void);
  * contract of the sampled agents changes.  crl_version() returns the revision the LIBRARY was built from; a binding must
  * refuse a library whose revision differs from the header it was written against (colosseumrl_amd/_native.py does).
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
- * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits.  108: crl_diag_bounds. */
-#define CRL_ABI_VERSION 108
+ * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits.  108: crl_diag_bounds.
+ * 109: crl_blokus_step / _step_observe place ANY action as the reference's next_state does (numpy index rules, extended ids,
+ *      CRL_BLOKUS_*_ERROR codes in the reward slot). */
+#define CRL_ABI_VERSION 109
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -207,8 +209,9 @@ int crl_tron_sample(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
 
 /* replaces CyTronGrid.relative_player_inplace (CyTronGrid.pyx:65-71) + the rolls of
  * TronGridEnvironment.state_to_observation (TronGridEnvironment.py:385-405), fully observable branch.
- * player int8 [B]: observer of env b (an id outside 0..P-1 observes as player 0).  Outputs have the shapes of the
- * state arrays. */
+ * player int8 [B]: observer of env b.  ANY id is an observer, as in the reference (ABI 109): the rolled vectors use numpy's
+ * modulo ((arange + player) % P, :393), the board C's remainder (CyTronGrid.pyx:1 cdivision=True) -- ids -128..P observe as
+ * player mod P, beyond P low trail ids come out <= 0 exactly as there.  Outputs have the shapes of the state arrays. */
 int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const int16_t *heads,
                      const int8_t *dirs, const int8_t *deaths, const int8_t *player,
                      int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths, void *stream);
@@ -316,9 +319,22 @@ int crl_ttt_rollout(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first
  *   to_move int32  [B]
  * Action id = ((piece*400 + y*20 + x)*8 + orientation)*5 + shift for the reference string
  * "{piece};({x}, {y});{orientation}{shift}" (BlokusEnvironment.py:55-80; orientation order board.py:47);
- * ascending ids are exactly the order of BlokusEnvironment.valid_actions; -1 = '' (pass).            */
+ * ascending ids are exactly the order of BlokusEnvironment.valid_actions; -1 = '' (pass).
+ * The step entries also take EXTENDED ids, for indices valid_actions never emits but next_state accepts (it places whatever
+ * string_to_action parsed, BlokusEnvironment.py:417-419, and numpy wraps negative indices, board.py:103):
+ *   CRL_BLOKUS_EXT_BASE + ((piece*1600 + (y+20)*40 + (x+20))*8 + orientation)*5 + shift,   x, y in [-20, 20).       */
 #define CRL_BLOKUS_ACTION_IDS 336000
 #define CRL_BLOKUS_MASK_WORDS 10500
+#define CRL_BLOKUS_EXT_BASE   336000
+#define CRL_BLOKUS_EXT_IDS    1344000                 /* 21 * 1600 * 8 * 5 */
+/* per-game codes crl_blokus_step / crl_blokus_step_observe put into reward[b] where the reference's next_state RAISES; the
+ * game is left exactly as it was (next_state works on copies, BlokusEnvironment.py:408-409), terminal[b] = winners[b] = 0 */
+#define CRL_BLOKUS_INDEX_ERROR -1   /* IndexError: a cell outside numpy's index range [-20, 20) (board.py:103), or a shift id
+                                     * that names no cell of the piece (computation.py:218) */
+#define CRL_BLOKUS_VALUE_ERROR -2   /* ValueError: piece not in the mover's inventory (ai.py:47 list.remove); the board update
+                                     * runs first in the reference, so an IndexError takes precedence */
+#define CRL_BLOKUS_BAD_ACTION  -3   /* the id is neither a dense nor an extended id (the reference's KeyError for an unknown
+                                     * piece name is the closest relative) */
 int crl_blokus_create(crl_ctx **out);
 /* The random agent of crl_ttt_rollout as a stand-alone call: action[b] = the r-th empty cell (flat index, row-major
  * np.where order) with r as crl_ttt_rollout's RNG contract defines it for step counter tcount[b], -1 on a full board; advance != 0
@@ -336,7 +352,10 @@ int crl_blokus_placement(int piece, int orient, int shift, int8_t *cells_xy);
 int crl_blokus_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask, uint32_t *occ, uint32_t *inv, int32_t *score,
                      int32_t *round, int32_t *to_move, void *stream);
 /* replaces BlokusEnvironment.next_state (BlokusEnvironment.py:357-451).  No legality check (the reference
- * leaves that to its caller, match_server.py:193).  reward int8 [B]: the mover's rank in the ascending score
+ * leaves that to its caller, match_server.py:193): as there, a placement on occupied cells OVERWRITES them (other colours
+ * included) and still scores, cells at x or y in -20..-1 WRAP to the far edge (numpy), and where the reference raises the
+ * game stays untouched and reward[b] carries CRL_BLOKUS_INDEX_ERROR / _VALUE_ERROR / _BAD_ACTION (see above).
+ * action int32 [B]: dense or extended id, < 0 = '' (pass).  reward int8 [B]: the mover's rank in the ascending score
  * order at terminal, else 0; terminal uint8 [B]: no player has a move on the PRE-move board with the
  * post-move inventories; winners uint8 [B]: bitmask of players whose score equals max(0, best), 0 unless terminal */
 int crl_blokus_step(const crl_ctx *ctx, int64_t B, uint32_t *occ, uint32_t *inv, int32_t *score, int32_t *round, int32_t *to_move,

@@ -194,19 +194,49 @@ static void reset_env(blk_env *e)
     for (int c = 0; c < 4; ++c) e->inv[c] = (1u << NP) - 1u;      /* ai.py:29 all 21 pieces */
 }
 
-/* BlokusEnvironment.next_state (:357-451); action < 0 is '' */
-static void step_env(blk_env *e, int action, int *reward, int *terminal, int *winners)
+/* An action id -> (piece, index x, index y, orientation, shift).  Ids below ORC_BLOKUS_ACTION_IDS are the dense ids of the
+ * action strings valid_actions can emit (index on the board); ids from ORC_BLOKUS_EXT_BASE on name an index anywhere in
+ * [-20, 20) x [-20, 20) -- next_state takes whatever string_to_action parsed (BlokusEnvironment.py:83-106, :417-419).
+ * Returns 0 when the id names no action at all. */
+#define ORC_BLOKUS_ACTION_IDS 336000
+#define ORC_BLOKUS_EXT_BASE   336000
+#define ORC_BLOKUS_EXT_IDS    (21 * 1600 * 40)
+static int decode_action(int action, int *piece, int *x, int *y, int *o, int *shift)
+{
+    if (action < 0 || action >= ORC_BLOKUS_EXT_BASE + ORC_BLOKUS_EXT_IDS) return 0;
+    if (action < ORC_BLOKUS_ACTION_IDS) {
+        int cell = (action / 40) % 400;
+        *shift = action % 5; *o = (action / 5) % 8; *piece = action / 16000; *x = cell % BN; *y = cell / BN;
+    } else {
+        int a = action - ORC_BLOKUS_EXT_BASE, cell = (a / 40) % 1600;
+        *shift = a % 5; *o = (a / 5) % 8; *piece = a / 64000; *x = cell % 40 - 20; *y = cell / 40 - 20;
+    }
+    return 1;
+}
+
+/* BlokusEnvironment.next_state (:357-451); action < 0 is ''.  No legality test (:417-420): Board.update_board writes
+ * board_contents[y][x] = colour cell by cell under numpy's index rules (board.py:87-103: -20..-1 wrap, anything else outside
+ * 0..19 raises IndexError; a shift id that names no cell of the piece raises IndexError in shift_offsets, computation.py:218),
+ * other colours' cells are overwritten; then AI.update_player (ai.py:44-54) raises ValueError for a piece not held.
+ * next_state works on copies (:408-409), so a raise leaves the state as it was.  Here: *status = 0 fine, -1 IndexError,
+ * -2 ValueError, -3 the id names no action; on a non-zero status the state is untouched and reward / terminal / winners are 0. */
+static void step_env(blk_env *e, int action, int *reward, int *terminal, int *winners, int *status)
 {
     int pl = e->to_move, color = pl + 1;
     blk_env old = *e;                                              /* :424 checks the PRE-move board */
+    *reward = 0; *terminal = 0; *winners = 0; *status = 0;
     if (action >= 0) {
-        int shift = action % 5, o = (action / 5) % 8, cell = (action / 40) % 400, piece = action / 16000;
+        int shift, o, piece, ax, ay;
+        if (!decode_action(action, &piece, &ax, &ay, &o, &shift)) { *status = -3; return; }
+        if (shift >= PIECE_CELLS[piece]) { *status = -1; return; }  /* computation.py:218 offsets[offset_id] */
         int8_t cells[5][2];
         orc_blokus_placement(piece, o, shift, cells);
         for (int j = 0; j < PIECE_CELLS[piece]; ++j) {             /* board.py:87-103, no legality check */
-            int x = cell % BN + cells[j][0], y = cell / BN + cells[j][1];
-            if (x >= 0 && x < BN && y >= 0 && y < BN) e->board[y][x] = (int8_t)color;
+            int x = ax + cells[j][0], y = ay + cells[j][1];
+            if (x < -BN || x >= BN || y < -BN || y >= BN) { *e = old; *status = -1; return; }   /* numpy IndexError */
+            e->board[y < 0 ? y + BN : y][x < 0 ? x + BN : x] = (int8_t)color;
         }
+        if (!((e->inv[pl] >> piece) & 1u)) { *e = old; *status = -2; return; }   /* ai.py:47 list.remove */
         e->inv[pl] &= ~(1u << piece);                              /* ai.py:47 */
         if (e->inv[pl] == 0) e->score[pl] += (piece == 0) ? 20 : 15;   /* ai.py:49-52 */
         e->score[pl] += PIECE_CELLS[piece];                        /* ai.py:54 */
@@ -214,7 +244,6 @@ static void step_env(blk_env *e, int action, int *reward, int *terminal, int *wi
     int any = 0;
     for (int q = 0; q < 4 && !any; ++q)                            /* :424 old board, old round, NEW inventories */
         any = enumerate_moves(&old, q, old.round, e->inv[q], NULL, 0, 1) > 0;
-    *reward = 0; *terminal = 0; *winners = 0;
     if (!any) {
         *terminal = 1;
         int max_score = 0;                                         /* :426-437 */
@@ -265,10 +294,25 @@ void orc_blokus_step(int64_t B, uint32_t *occ, uint32_t *inv, int32_t *score, in
     for (int64_t b = 0; b < B; ++b) {
         blk_env e;
         load_env(&e, occ + b * 4 * BN, inv + b * 4, score + b * 4, round[b], to_move[b]);
-        int r, t, w;
-        step_env(&e, action[b], &r, &t, &w);
+        int r, t, w, st;
+        step_env(&e, action[b], &r, &t, &w, &st);
         store_env(&e, occ + b * 4 * BN, inv + b * 4, score + b * 4, round + b, to_move + b);
-        reward[b] = (int8_t)r; terminal[b] = (uint8_t)t; winners[b] = (uint8_t)w;
+        reward[b] = (int8_t)(st ? st : r); terminal[b] = (uint8_t)t; winners[b] = (uint8_t)w;   /* the reward slot carries the code */
+    }
+}
+
+/* Board.check_valid_corner (board.py:127-154) for every cell and colour of reference-layout boards int8 [K][20][20]:
+ * grid uint8 [K][4][20][20].  The method does not test the cell itself (gather_empty_corner_indexes does, :121). */
+void orc_blokus_valid_corner_grid(int64_t K, const int8_t *board, uint8_t *grid)
+{
+    for (int64_t k = 0; k < K; ++k) {
+        blk_env e;
+        memset(&e, 0, sizeof(e));
+        memcpy(e.board, board + k * BN * BN, BN * BN);
+        for (int c = 1; c <= 4; ++c)
+            for (int row = 0; row < BN; ++row)
+                for (int col = 0; col < BN; ++col)
+                    grid[((k * 4 + c - 1) * BN + row) * BN + col] = (uint8_t)valid_corner(&e, c, row, col);
     }
 }
 
@@ -340,8 +384,8 @@ void orc_blokus_rollout(int64_t B, uint64_t seed, uint64_t first_env_id, int T,
             orc_philox4x32(ctr, key, w);
             int action = n > 0 ? ids[mulhi32b(w[tc & 3u], (uint32_t)n)] : -1;
             tc += 1;
-            int r, term, wm;
-            step_env(&e, action, &r, &term, &wm);
+            int r, term, wm, status;
+            step_env(&e, action, &r, &term, &wm, &status);                     /* a listed action: status is 0 */
             ts += 1;
             if (term) {
                 st.n_episodes[b] += 1;

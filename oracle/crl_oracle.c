@@ -233,7 +233,8 @@ void orc_tron_rollout(int N, int P, int64_t B, uint64_t seed, uint64_t first_env
 }
 
 /* TronGridEnvironment.py:385-405 + CyTronGrid.pyx:65-71 (fully observable branch).
- * relabel v>0 -> ((v-(pl+1)+P)%P)+1; roll heads/dirs/deaths so index 0 is the observer;
+ * relabel v>0 -> ((v-(pl+1)+P)%P)+1 with C's remainder (CyTronGrid.pyx:1 cdivision=True: for an observer id beyond P low
+ * trail ids come out <= 0); roll heads/dirs/deaths with numpy's modulo so index 0 is the observer (any integer id);
  * killer ids stored inside deaths stay absolute. */
 void orc_tron_observe(int N, int P, int64_t B, const int8_t *board, const int16_t *heads,
                       const int8_t *dirs, const int8_t *deaths, const int8_t *player,
@@ -247,7 +248,7 @@ void orc_tron_observe(int N, int P, int64_t B, const int8_t *board, const int16_
             obs_board[b * NN + c] = (int8_t)(v > 0 ? ((v - (pl + 1) + P) % P) + 1 : v);
         }
         for (int i = 0; i < P; ++i) {
-            int src = (i + pl) % P;
+            int src = (((i + pl) % P) + P) % P;                   /* numpy's modulo (:393): negative observer ids wrap */
             obs_heads[i * B + b] = heads[src * B + b];
             obs_dirs[i * B + b] = dirs[src * B + b];
             obs_deaths[i * B + b] = deaths[src * B + b];

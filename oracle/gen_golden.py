@@ -140,7 +140,10 @@ def tron_edge_cases(R):
     return out
 
 
-def tron_observe_cases(R, N, P, E, seed):
+def tron_observe_cases(R, N, P, E, seed, player_ids=None):
+    """state_to_observation on random mid-game states; `player_ids`: draw the observer from this list instead of 0..P-1 (ids
+    outside the range: heads / directions / deaths roll by (arange + player) % P, TronGridEnvironment.py:393, the board goes
+    through relative_player_inplace's C remainder, CyTronGrid.pyx:1,65-71 -- cdivision=True)."""
     rng = np.random.default_rng(seed)
     env = R["tron"]("%d;%d" % (N, P))
     boards, heads, dirs, deaths, players = [], [], [], [], []
@@ -149,7 +152,7 @@ def tron_observe_cases(R, N, P, E, seed):
         s, _ = env.new_state()
         for t in range(int(rng.integers(0, 14))):
             s, _, _, term, _ = env.next_state(s, list(range(P)), [TRON_ACT[i] for i in rng.integers(0, 3, size=P)])
-        pl = int(rng.integers(0, P))
+        pl = int(rng.integers(0, P)) if player_ids is None else int(player_ids[e % len(player_ids)])
         o = env.state_to_observation(s, pl)
         boards.append(s[0].ravel()); heads.append(s[1]); dirs.append(s[2]); deaths.append(s[3]); players.append(pl)
         ob.append(o["board"].ravel()); oh.append(o["heads"]); od.append(o["directions"]); ok.append(o["deaths"])
@@ -215,6 +218,15 @@ def gen_tron(R):
     np.savez_compressed(os.path.join(OUT, "tron_edge.npz"), **tron_edge_cases(R))
     np.savez_compressed(os.path.join(OUT, "tron_observe_n20p4.npz"), **tron_observe_cases(R, 20, 4, 64, 11))
     np.savez_compressed(os.path.join(OUT, "tron_observe_n9p6.npz"), **tron_observe_cases(R, 9, 6, 64, 12))
+    gen_tron_observe_wrap(R)
+
+
+def gen_tron_observe_wrap(R):
+    """Observer ids outside 0..P-1 (negative, P, beyond)."""
+    np.savez_compressed(os.path.join(OUT, "tron_observe_wrap_n20p4.npz"),
+                        **tron_observe_cases(R, 20, 4, 48, 13, player_ids=[-1, -2, -4, -5, -9, 4, 5, 6, 7, 8, 11, 13]))
+    np.savez_compressed(os.path.join(OUT, "tron_observe_wrap_n9p6.npz"),
+                        **tron_observe_cases(R, 9, 6, 48, 14, player_ids=[-1, -6, -7, -13, 6, 7, 8, 11, 12, 17, 23, 40]))
 
 
 # --------------------------------------------------------------------------- TicTacToe
@@ -348,6 +360,8 @@ def main(argv):
     what = argv or ["tron", "ttt", "blokus"]
     if "tron" in what:
         gen_tron(R)
+    if "tron_observe_wrap" in what:
+        gen_tron_observe_wrap(R)
     if "ttt" in what:
         gen_ttt(R)
     if "ttt" in what or "ttt_rewards" in what:

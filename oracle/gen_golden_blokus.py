@@ -271,6 +271,150 @@ def gen_records(R, out_dir, steps=(1, 5, 9, 17, 30, 45)):
     print("blokus record fixtures", len(rec["color"]), "states; max moves", max(rec["n_moves"]), "max corners", max(rec["n_corners"]))
 
 
+EXC_KINDS = {None: 0, "IndexError": 1, "ValueError": 2, "KeyError": 3}
+
+
+def _illegal_base_states(R, out_dir):
+    """Three states the not-listed actions are played on: after the four scripted openers of SURVEY Appendix B, and golden
+    game 1 after 21 and 42 plies (replayed through the reference)."""
+    env = R["blokus"]()
+    state, players = env.new_state()
+    for a in ("trominoe1;(0, 0);east0", "domino1;(19, 0);south0", "monomino1;(0, 19);east0", "tetrominoes3;(19, 19);west0"):
+        state, players, *_ = env.next_state(state, players, [a])
+    out = [(state, players[0])]
+    g = np.load(os.path.join(out_dir, "blokus_game_1.npz"))
+    state, players = env.new_state()
+    for t in range(42):
+        aid = int(g["action"][t])
+        state, players, *_ = env.next_state(state, players, [decode_str(aid) if aid >= 0 else ""])
+        if t in (20, 41):
+            out.append((state, players[0]))
+    return env, out
+
+
+def _illegal_actions(k, state, mover, rng):
+    """(player, action string) pairs next_state accepts or raises on although valid_actions would not list them."""
+    board = state[0].board_contents
+    held = state[2][mover].current_pieces
+    gone = [p for p in PIECES if p not in held]
+    own = [(int(x), int(y)) for y, x in zip(*np.where(board == mover + 1))]
+    foreign = [(int(x), int(y)) for y, x in zip(*np.where((board > 0) & (board != mover + 1)))]
+    acts = [""]                                                     # a pass by a player who has moves
+    big = [p for p in held if p.startswith("pent")][:3] + [p for p in held if p.startswith("tetr")][:2] + held[:2]
+    for (x, y) in own[:3] + foreign[:4]:                            # overlaps on own and foreign cells
+        for p in big[:3]:
+            acts.append("%s;(%d, %d);%s%d" % (p, x, y, ORIENT[int(rng.integers(0, 8))], int(rng.integers(0, 2))))
+    acts.append("monomino1;(0, 0);east0" if "monomino1" in held else "%s;(0, 0);east0" % held[0])
+    for p in big:                                                   # cells at x or y = -1 .. -4 (numpy wraps), >= 20 (IndexError)
+        for (x, y) in ((0, 7), (7, 0), (0, 0), (1, 1), (19, 7), (7, 19), (19, 19), (18, 18), (0, 19), (19, 0)):
+            acts.append("%s;(%d, %d);%s%d" % (p, x, y, ORIENT[int(rng.integers(0, 8))], int(rng.integers(0, 5 if p.startswith("pent") else 2))))
+    for idx in ((-1, 5), (5, -3), (-20, -20), (-21, 0), (0, -21), (20, 0), (0, 20), (25, 5), (-4, -4), (-17, 3), (3, -18), (-19, -1)):
+        p = big[int(rng.integers(0, len(big)))]                     # index cells off the board
+        acts.append("%s;(%d, %d);%s%d" % (p, idx[0], idx[1], ORIENT[int(rng.integers(0, 8))], 0))
+    for p in gone[:3]:                                              # piece not held: ValueError (ai.py:47), after the board update
+        acts.append("%s;(9, 9);east0" % p)
+        acts.append("%s;(19, 19);east0" % p)                        # ... unless a cell leaves numpy's range first
+    for p in ("monomino1", "domino1", "trominoe2", "tetrominoes1"):  # shift ids that name no cell of the piece
+        for s in (1, 2, 3, 4, 7, 9):
+            if s >= {"m": 1, "d": 2, "t": 3}.get(p[0], 4) + (1 if p.startswith("tetr") else 0):
+                acts.append("%s;(9, 9);south%d" % (p, s))
+    acts += ["%s;(8, 8);foo1" % big[0], "%s;(8, 8);1" % big[0], "%s;(8, 8);Northeast0" % big[0],       # unknown names are 'east'
+             "zzz;(0, 0);east0", "zzz;(0, 0);", "zzz;(99, 0);eastx", "%s;(3, 3);" % big[0], "%s;(3,3);eastx" % big[0],
+             "%s;(3, 3)" % big[0], "%s;(a, 3);east0" % big[0], "%s;3, 4;east0" % big[0], "%s;((4), 5);north1" % big[0]]
+    for _ in range(24):                                             # arbitrary
+        p = PIECES[int(rng.integers(0, 21))]
+        acts.append("%s;(%d, %d);%s%d" % (p, int(rng.integers(-6, 26)), int(rng.integers(-6, 26)), ORIENT[int(rng.integers(0, 8))],
+                                          int(rng.integers(0, 5))))
+    out = [(mover, a) for a in acts]
+    other = (mover + 2) % 4                                          # next_state takes any player as the mover
+    out += [(other, "%s;(6, 6);west0" % state[2][other].current_pieces[-1]), (other, "")]
+    return [(k, pl, a) for pl, a in out]
+
+
+_BASES = []
+
+
+def _illegal_case(args):
+    k, pl, action = args
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_loader
+    R = ref_loader.load()
+    if not _BASES:                                                  # once per worker process
+        _BASES.extend(_illegal_base_states(R, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")))
+    env, bases = _BASES
+    state = bases[k][0]
+    before = state[0].board_contents.copy()
+    res = dict(exc=0, board=before.astype(np.int8), inv=[inv_mask(p) for p in state[2]], score=[p.player_score for p in state[2]],
+               round=state[1], next_player=pl, reward=0, terminal=0, winners=0)
+    try:
+        ns, npl, rew, term, win = env.next_state(state, [pl], [action])
+        res.update(board=ns[0].board_contents.astype(np.int8).copy(), inv=[inv_mask(p) for p in ns[2]],
+                   score=[p.player_score for p in ns[2]], round=ns[1], next_player=npl[0], reward=rew[0], terminal=int(bool(term)),
+                   winners=0 if win is None else sum(1 << w for w in win))
+    except (IndexError, ValueError, KeyError) as e:
+        res["exc"] = EXC_KINDS[type(e).__name__]
+    assert np.array_equal(state[0].board_contents, before), "next_state left its input alone"
+    return k, pl, action, res
+
+
+def gen_illegal(R, out_dir):
+    """next_state / Board.update_board on actions valid_actions would not list (BlokusEnvironment.py:412-422 places without a
+    check; board.py:87-103 indexes board_contents[y][x] with numpy's rules; ai.py:47 raises for a piece not held), and
+    Board.check_valid_corner on every cell (board.py:127-154).  The REFERENCE's answers, exception kind included."""
+    env, bases = _illegal_base_states(R, out_dir)
+    rng = np.random.default_rng(2026)
+    todo = []
+    for k, (state, mover) in enumerate(bases):
+        todo += _illegal_actions(k, state, mover, rng)
+    with Pool(8) as pool:
+        res = pool.map(_illegal_case, todo, chunksize=4)
+    rec = dict(base=[], player=[], action=[], exc=[], board=[], inv=[], score=[], round=[], next_player=[], reward=[], terminal=[], winners=[])
+    for k, pl, action, r in res:
+        rec["base"].append(k); rec["player"].append(pl); rec["action"].append(action.encode())
+        for key in ("exc", "board", "inv", "score", "round", "next_player", "reward", "terminal", "winners"):
+            rec[key].append(r[key])
+    # Board.update_board called directly on the record: cells are placed one by one, so an IndexError leaves the earlier ones
+    Board = bases[0][0][0].__class__
+    ub_spec, ub_exc, ub_board = [], [], []
+    for piece, index, orient, color in (("pentominoe1", (17, 4), "east0", 2), ("pentominoe1", (4, 17), "south0", 3),
+                                        ("pentominoe9", (0, 0), "west2", 1), ("tetrominoes2", (19, 19), "northeast1", 4),
+                                        ("pentominoe5", (-2, 18), "southeast3", 1), ("pentominoe12", (18, -2), "north4", 2),
+                                        ("trominoe1", (1, 1), "bogus2", 3), ("pentominoe7", (22, 3), "west0", 4)):
+        b = Board(bases[1][0][0])
+        try:
+            b.update_board(color, piece, index, orient, 3, True)
+            exc = 0
+        except (IndexError, ValueError, KeyError) as e:
+            exc = EXC_KINDS[type(e).__name__]
+        ub_spec.append([PIECES.index(piece), index[0], index[1], ORIENT.index(orient[:-1]) if orient[:-1] in ORIENT else -1, int(orient[-1]), color])
+        ub_exc.append(exc); ub_board.append(b.board_contents.astype(np.int8).copy())
+    # check_valid_corner on EVERY cell, occupied ones included (the method itself does not test emptiness)
+    grids = np.zeros((len(bases), 4, 20, 20), np.uint8)
+    for k, (state, _) in enumerate(bases):
+        bc = state[0].board_contents
+        for c in (1, 2, 3, 4):
+            for y in range(20):
+                for x in range(20):
+                    grids[k, c - 1, y, x] = bool(state[0].check_valid_corner(bc, c, y, x))
+    np.savez_compressed(os.path.join(out_dir, "blokus_illegal.npz"),
+                        base_board=np.array([s[0].board_contents for s, _ in bases], np.int8),
+                        base_inv=np.array([[inv_mask(p) for p in s[2]] for s, _ in bases], np.uint32),
+                        base_score=np.array([[p.player_score for p in s[2]] for s, _ in bases], np.int32),
+                        base_round=np.array([s[1] for s, _ in bases], np.int32), base_mover=np.array([m for _, m in bases], np.int32),
+                        base=np.array(rec["base"], np.int32), player=np.array(rec["player"], np.int32),
+                        action=np.array(rec["action"], dtype="S48"), exc=np.array(rec["exc"], np.int8),
+                        board=np.array(rec["board"], np.int8), inv=np.array(rec["inv"], np.uint32), score=np.array(rec["score"], np.int32),
+                        round=np.array(rec["round"], np.int32), next_player=np.array(rec["next_player"], np.int32),
+                        reward=np.array(rec["reward"], np.int8), terminal=np.array(rec["terminal"], np.uint8),
+                        winners=np.array(rec["winners"], np.uint8),
+                        ub_spec=np.array(ub_spec, np.int32), ub_exc=np.array(ub_exc, np.int8), ub_board=np.array(ub_board),
+                        corner_grid=grids)
+    ex = np.array(rec["exc"])
+    print("blokus illegal fixtures", len(ex), "cases: ok", int((ex == 0).sum()), "IndexError", int((ex == 1).sum()),
+          "ValueError", int((ex == 2).sum()), "KeyError", int((ex == 3).sum()), "| update_board exc", ub_exc,
+          "| corner cells true", int(grids.sum()), "of them occupied", int(sum((grids[k, c] & (bases[k][0][0].board_contents != 0)).sum() for k in range(len(bases)) for c in range(4))))
+
+
 def gen(R, out_dir, n_games=8):
     with Pool(min(8, n_games)) as pool:
         games = pool.map(play_game, list(range(1, n_games + 1)))
@@ -292,6 +436,7 @@ def gen(R, out_dir, n_games=8):
     gen_observe(R, out_dir)
     gen_lattice(out_dir)
     gen_records(R, out_dir)
+    gen_illegal(R, out_dir)
 
 
 def gen_observe(R, out_dir, n_steps=28):
@@ -347,5 +492,7 @@ if __name__ == "__main__":
         gen_lattice(out)
     elif "records" in sys.argv[1:]:
         gen_records(ref_loader.load(), out)
+    elif "illegal" in sys.argv[1:]:
+        gen_illegal(ref_loader.load(), out)
     else:
         gen_observe(ref_loader.load(), out)

@@ -240,6 +240,33 @@ def blokus_action_id(s):
     return blokus_encode(BLOKUS_PIECES.index(name), x, y, BLOKUS_ORIENTATIONS.index(orient[:-1]), int(orient[-1]))
 
 
+BLOKUS_EXT_BASE = 336000          # ids from here on: index anywhere in [-20, 20) x [-20, 20) (blokus_oracle.c decode_action)
+BLOKUS_STATUS = {0: None, -1: IndexError, -2: ValueError, -3: KeyError}
+
+
+def blokus_step_action_id(s):
+    """What the reference's next_state does with an action string BEFORE it touches the board, exceptions in its order:
+    string_to_action (BlokusEnvironment.py:83-106: split / int -> ValueError), PIECE_TYPES[piece] (board.py:93: KeyError),
+    int(orientation[-1]) (IndexError on '', ValueError on a non-digit), an orientation name that is none of the eight falls
+    to rotate_piece's default branch = east (computation.py:85-86).  Returns the id orc_blokus_step takes; an index outside
+    [-20, 20) cannot be encoded and raises the IndexError numpy would (the piece's index cell itself is always written)."""
+    if s == "":
+        return -1
+    name, idx, orient = s.split(";")
+    xy = tuple(map(int, idx.replace("(", "").replace(")", "").split(",")))
+    piece = {n: i for i, n in enumerate(BLOKUS_PIECES)}[name]
+    shift = int(orient[-1])
+    o = BLOKUS_ORIENTATIONS.index(orient[:-1]) if orient[:-1] in BLOKUS_ORIENTATIONS else 2
+    if shift >= lib().orc_blokus_piece_cells(C.c_int(piece)):
+        raise IndexError("shift id names no cell of the piece")
+    x, y = xy[0], xy[1]
+    if not (-20 <= x < 20 and -20 <= y < 20):
+        raise IndexError("index out of bounds")
+    if 0 <= x < 20 and 0 <= y < 20:
+        return blokus_encode(piece, x, y, o, shift)
+    return BLOKUS_EXT_BASE + ((piece * 1600 + (y + 20) * 40 + (x + 20)) * 8 + o) * 5 + shift
+
+
 def blokus_placement(piece, orient, shift):
     cells = np.zeros((5, 2), dtype=np.int8)
     lib().orc_blokus_placement(C.c_int(piece), C.c_int(orient), C.c_int(shift), _p(cells))
@@ -313,6 +340,14 @@ def blokus_step(st, action, n_threads=1):
     lib().orc_blokus_step(C.c_int64(st.B), _p(st.occ), _p(st.inv), _p(st.score), _p(st.round), _p(st.to_move),
                           _p(a), _p(reward), _p(terminal), _p(winners), C.c_int(n_threads))
     return reward, terminal, winners
+
+
+def blokus_valid_corner_grid(board):
+    """Board.check_valid_corner on every (colour, row, col) of int8 boards [K][20][20] -> uint8 [K][4][20][20]."""
+    b = np.ascontiguousarray(board, dtype=np.int8).reshape(-1, 20, 20)
+    grid = np.zeros((b.shape[0], 4, 20, 20), dtype=np.uint8)
+    lib().orc_blokus_valid_corner_grid(C.c_int64(b.shape[0]), _p(b), _p(grid))
+    return grid
 
 
 def blokus_placement_tests(reset=False):

@@ -59,3 +59,52 @@ def check_bonus(golden, make_backend):
     assert np.array_equal(s["score"], g["score"]) and s["score"][0, 0] == 101 and s["score"][1, 0] == 97   # +20 / +15
     assert np.array_equal(r, g["reward"]) and np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
     assert np.array_equal(s["round"], g["next_round"]) and np.array_equal(s["to_move"], g["next_player"])
+
+
+EXC_OF = {0: None, 1: IndexError, 2: ValueError, 3: KeyError}      # blokus_illegal.npz `exc`
+STATUS_OF = {0: 0, 1: -1, 2: -2}                                   # ... as the code the step's reward slot carries
+
+
+def illegal_ids(golden, to_id):
+    """Fixture cases of blokus_illegal.npz -> (case indices that reach the stepper, their ids).  Strings the reference
+    rejects before it touches the board must make `to_id` raise the same exception class."""
+    g = golden("blokus_illegal")
+    keep, ids = [], []
+    for i, raw in enumerate(g["action"]):
+        want = EXC_OF[int(g["exc"][i])]
+        try:
+            aid = to_id(raw.decode())
+        except (IndexError, ValueError, KeyError) as e:
+            assert want is not None and type(e) is want, (raw, type(e).__name__, want)
+            continue
+        assert want is not KeyError, raw
+        keep.append(i)
+        ids.append(aid)
+    return g, np.array(keep), np.array(ids, np.int32)
+
+
+def check_illegal(golden, make_backend, to_id):
+    """next_state on actions valid_actions would not list -- overlaps, cells wrapped by numpy's negative indices, IndexError /
+    ValueError cases -- against the REFERENCE's answers (oracle/gen_golden_blokus.py gen_illegal)."""
+    g, keep, ids = illegal_ids(golden, to_id)
+    n = len(keep)
+    assert n > 300 and (ids >= 336000).sum() >= 30
+    base = g["base"][keep]
+    be = make_backend(n)
+    be.set_state(g["base_board"][base], g["base_inv"][base], g["base_score"][base], g["base_round"][base], g["player"][keep])
+    r, term, win = be.step(ids)
+    s = be.state()
+    status = np.array([STATUS_OF[int(e)] for e in g["exc"][keep]])
+    ok = status == 0
+    assert ok.sum() > 200 and (status == -1).sum() > 50 and (status == -2).sum() > 10, (ok.sum(), (status == -1).sum(), (status == -2).sum())
+    assert np.array_equal(np.asarray(r)[~ok], status[~ok]), "IndexError / ValueError codes"
+    assert np.array_equal(np.asarray(r)[ok], g["reward"][keep][ok])
+    assert np.array_equal(np.asarray(term), g["terminal"][keep]) and np.array_equal(np.asarray(win), g["winners"][keep])
+    # a raise leaves the reference's state as it was (next_state works on copies): the fixture stores the input state then,
+    # with next_player = the mover
+    for key, fx in (("board", "board"), ("inv", "inv"), ("score", "score"), ("round", "round"), ("to_move", "next_player")):
+        assert np.array_equal(np.asarray(s[key]), g[fx][keep]), key
+    changed = (g["board"][keep] != g["base_board"][base]).reshape(n, -1).any(axis=1)
+    overwrote = ((g["base_board"][base] != 0) & (g["board"][keep] != g["base_board"][base])).reshape(n, -1).any(axis=1)
+    assert changed.sum() > 150 and overwrote.sum() > 20            # the cases do place, and do overwrite other colours
+    return n

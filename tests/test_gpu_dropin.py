@@ -278,6 +278,69 @@ def test_blokus_record_methods_reference_golden(golden):
     assert Board().check_orientation_shifts(1, "pentominoe3", (0, 0), "north").size < 5            # some shifts leave the board
 
 
+def test_blokus_dropin_not_listed_actions_reference_golden(golden):
+    """BlokusEnvironment.next_state on all 497 strings of blokus_illegal.npz -- actions valid_actions would not list: what the
+    reference raises is raised (IndexError / ValueError / KeyError, same class), what it places is placed the same way
+    (overwrites, numpy wrap, unknown orientation names = east), the state handed in is never modified, and the returned
+    state is usable (valid_actions of the next mover equals the oracle's list on that board)."""
+    from colosseumrl_amd import get_environment
+    from colosseumrl_amd.envs.blokus import actions as A
+    from colosseumrl_amd.envs.blokus.ai import AI
+    from colosseumrl_amd.envs.blokus.board import Board
+    from blokus_replay import EXC_OF
+    g = golden("blokus_illegal")
+    env = get_environment("blokus")()
+
+    def state_of(k):
+        board = Board()
+        board.board_contents[:] = g["base_board"][k]
+        ais = [AI(board, c) for c in (1, 2, 3, 4)]
+        for q in range(4):
+            ais[q].current_pieces = [A.PIECE_NAMES[i] for i in range(21) if (int(g["base_inv"][k, q]) >> i) & 1]
+            ais[q].player_score = int(g["base_score"][k, q])
+        return board, int(g["base_round"][k]), ais
+
+    kinds = {None: 0, IndexError: 0, ValueError: 0, KeyError: 0}
+    checked_lists = 0
+    for i, raw in enumerate(g["action"]):
+        k, pl, want = int(g["base"][i]), int(g["player"][i]), EXC_OF[int(g["exc"][i])]
+        state = state_of(k)
+        try:
+            ns, npl, rew, term, win = env.next_state(state, [pl], [raw.decode()])
+            got = None
+        except (IndexError, ValueError, KeyError) as e:
+            got = type(e)
+        assert got is want, (raw, got, want)
+        kinds[got] += 1
+        assert np.array_equal(state[0].board_contents, g["base_board"][k]) and state[1] == int(g["base_round"][k])
+        assert [p.player_score for p in state[2]] == g["base_score"][k].tolist()
+        if got is not None:
+            continue
+        assert np.array_equal(ns[0].board_contents, g["board"][i]) and ns[1] == int(g["round"][i]), raw
+        assert [p.player_score for p in ns[2]] == g["score"][i].tolist(), raw
+        assert [sum(1 << A.PIECE_INDEX[n] for n in p.current_pieces) for p in ns[2]] == g["inv"][i].tolist(), raw
+        assert npl == [int(g["next_player"][i])] and rew == [int(g["reward"][i])] and term == bool(g["terminal"][i]), raw
+        assert (win is None and g["winners"][i] == 0 and not term) or \
+            (win is not None and sum(1 << w for w in win) == int(g["winners"][i])), raw
+        if i % 16 == 0:                                          # the legal list of the next mover on the board that came out
+            ob = O.BlokusState(1)
+            ob.set_board(g["board"][i][None])
+            ob.inv[0] = g["inv"][i]
+            ob.round[0] = g["round"][i]
+            ob.to_move[0] = g["next_player"][i]
+            cnt, ids = O.blokus_valid(ob, cap=8192)
+            va = env.valid_actions(ns, npl[0])
+            assert (va == [""] and cnt[0] == 0) or [A.string_to_id(s) for s in va] == ids[0, :cnt[0]].tolist(), raw
+            checked_lists += 1
+    assert kinds[None] == 260 and kinds[IndexError] == 199 and kinds[ValueError] == 29 and kinds[KeyError] == 9 and checked_lists > 10
+    # the error path leaves the instance usable: the next ordinary call on the same env
+    s, pl = env.new_state()
+    with pytest.raises(IndexError):
+        env.next_state(s, pl, ["pentominoe6;(18, 0);east0"])
+    s2, pl2, *_ = env.next_state(s, pl, ["trominoe1;(0, 0);east0"])
+    assert pl2 == [1] and s2[0].board_contents[0, 1] == 1 and len(env.valid_actions(s2, 1)) == 116
+
+
 def test_blokus_dropin_list_grows_past_its_first_capacity(golden):
     """A hand-made board with 12,952 legal actions through the drop-in class: the mapped id list starts at 4,096 entries and
     grows (one more launch) instead of raising; strings in reference order, is_valid_action on both ends."""

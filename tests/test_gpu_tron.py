@@ -35,8 +35,9 @@ def test_edge_cases_golden(golden):
     assert np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
 
 
-@pytest.mark.parametrize("name", ["n20p4", "n9p6"])
+@pytest.mark.parametrize("name", ["n20p4", "n9p6", "wrap_n20p4", "wrap_n9p6"])
 def test_observe_golden(golden, name):
+    # wrap_*: observer ids outside 0..P-1 (negative, P, beyond P) as the reference answers them
     g = golden("tron_observe_" + name)
     N, P = int(g["N"]), int(g["P"])
     E = len(g["player"])
@@ -234,6 +235,19 @@ def test_dropin_env_golden(golden):
     assert all(np.array_equal(a, b) for a, b in zip(s2, s2b))
     obs = env.state_to_observation(s2, 2)
     assert obs["board"].shape == (20, 20) and obs["heads"][0] == s2[1][2]
+    # observer ids outside 0..P-1: the reference's answers (numpy modulo for the vectors, C remainder for the board); ids that
+    # do not fit int8 fold on the host; the state next_state just returned is served from the fused launch up to id == P
+    gw = golden("tron_observe_wrap_n20p4")
+    for i in range(len(gw["player"])):
+        st = (gw["board"][i].reshape(20, 20).astype(np.int64), gw["heads"][i].astype(np.int64), gw["dirs"][i].astype(np.int64),
+              gw["deaths"][i].astype(np.int64))
+        for pid in (int(gw["player"][i]), int(gw["player"][i]) + (400 if gw["player"][i] >= 8 else -400 if gw["player"][i] < 0 else 0)):
+            ob = env.state_to_observation(st, pid)
+            assert np.array_equal(ob["board"].reshape(-1), gw["obs_board"][i]) and np.array_equal(ob["heads"], gw["obs_heads"][i]), pid
+            assert np.array_equal(ob["directions"], gw["obs_dirs"][i]) and np.array_equal(ob["deaths"], gw["obs_deaths"][i]), pid
+    for pid, same_as in ((-1, 3), (4, 0), (-6, 2)):
+        a, b = env.state_to_observation(s2, pid), env.state_to_observation(s2, same_as)
+        assert all(np.array_equal(a[k], b[k]) for k in a)
     g2 = golden("tron_ranking_n20p4")
     for i in range(12):
         st = (g2["board"][i].reshape(20, 20).astype(np.int64), np.zeros(4, np.int64), np.zeros(4, np.int64), g2["deaths"][i].astype(np.int64))

@@ -86,3 +86,56 @@ def test_record_methods_without_gpu_work_match_reference(golden):
     assert not again.board_contents.any()
     with pytest.raises(ValueError):
         AI(None, 2).update_player("no such piece")
+
+
+def test_step_id_of_any_action_string_reference_golden(golden):
+    """A.string_to_step_id on the 497 strings of blokus_illegal.npz: where the reference's next_state raises before it touches
+    the board (split / int / piece name / shift digit / shift without a cell / index outside numpy's range) the same class is
+    raised; otherwise the id equals the oracle's own reading of the string (dense, or extended for an index off the board)."""
+    from oracle import oracle as O
+    from blokus_replay import illegal_ids
+    g, keep, ids = illegal_ids(golden, A.string_to_step_id)
+    g2, keep2, ids2 = illegal_ids(golden, O.blokus_step_action_id)
+    assert np.array_equal(keep, keep2) and np.array_equal(ids, ids2) and len(keep) == 364
+    assert A.string_to_step_id("") == A.PASS == -1
+    assert A.string_to_step_id("domino1;(5, 5);foo1") == A.encode(1, 5, 5, 2, 1)                  # unknown name = east
+    assert A.string_to_step_id("domino1;(-1, 5);east0") == A.EXT_BASE + ((1 * 1600 + 25 * 40 + 19) * 8 + 2) * 5
+    for s, exc in (("zzz;(0, 0);", KeyError), ("domino1;(3, 3);", IndexError), ("domino1;(3,3);eastx", ValueError),
+                   ("domino1;(3, 3)", ValueError), ("domino1;(5, 5);east3", IndexError), ("monomino1;(25, 5);east0", IndexError),
+                   ("monomino1;(5, -21);east0", IndexError)):
+        with pytest.raises(exc):
+            A.string_to_step_id(s)
+
+
+def test_update_board_numpy_rules_and_check_valid_corner_reference_golden(golden):
+    """Board.update_board called on the record itself: cells go down one by one under numpy's index rules, so a piece hanging
+    over the left / top edge wraps, one over the right / bottom edge raises IndexError AFTER its earlier cells were written,
+    an unknown orientation name places 'east' (board.py:87-103).  Board.check_valid_corner on all 1,600 (colour, cell) pairs
+    of three states, occupied cells included (board.py:127-154 does not look at the cell)."""
+    g = golden("blokus_illegal")
+    seen = set()
+    for spec, exc, want in zip(g["ub_spec"], g["ub_exc"], g["ub_board"]):
+        piece, x, y, o, k, color = [int(v) for v in spec]
+        b = Board()
+        b.board_contents[:] = g["base_board"][1]
+        name = (A.ORIENTATIONS[o] if o >= 0 else "bogus") + str(k)
+        try:
+            b.update_board(color, A.PIECE_NAMES[piece], (x, y), name, 3, True)
+            got = 0
+        except IndexError:
+            got = 1
+        seen.add(got)
+        assert got == int(exc) and np.array_equal(b.board_contents, want), spec
+    assert seen == {0, 1}
+    probe = Board()
+    n_true = n_occupied = 0
+    for k in range(len(g["base_board"])):
+        bc = g["base_board"][k].astype(np.int64)
+        for c in (1, 2, 3, 4):
+            for y in range(20):
+                for x in range(20):
+                    got = probe.check_valid_corner(bc, c, y, x)
+                    assert got == bool(g["corner_grid"][k, c - 1, y, x]), (k, c, y, x)
+                    n_true += got
+                    n_occupied += got and bc[y, x] != 0
+    assert n_true == 134 and n_occupied == 31

@@ -3,7 +3,7 @@ import numpy as np
 
 from oracle import oracle as O
 from backends import OracleBlokus
-from blokus_replay import GAMES, check_bonus, replay_games
+from blokus_replay import GAMES, check_bonus, check_illegal, replay_games
 
 
 def test_piece_table_kat():
@@ -71,6 +71,18 @@ def test_lattice_boards_reference_lists(golden):
 
 def test_last_piece_bonus(golden):
     check_bonus(golden, OracleBlokus)
+
+
+def test_not_listed_actions_reference_golden(golden):
+    # overlaps overwrite, negative cells wrap, cells >= 20 / shift ids without a cell / pieces not held raise and leave the state
+    check_illegal(golden, OracleBlokus, O.blokus_step_action_id)
+
+
+def test_check_valid_corner_every_cell_reference_golden(golden):
+    # board.py:127-154 does not look at the cell itself: occupied cells answer True too (31 of the fixture's 134)
+    g = golden("blokus_illegal")
+    grid = O.blokus_valid_corner_grid(g["base_board"])
+    assert np.array_equal(grid, g["corner_grid"]) and (grid & (g["base_board"][:, None] != 0)).sum() == 31
 
 
 def test_rollout_equals_stepwise():

@@ -84,8 +84,9 @@ def test_all_forward_trace_kat():
     assert r[:, 0].tolist() == [-1, -1, -1, -1] and s["heads"][:, 0].tolist() == [391, 220, 10, 179]
 
 
-@pytest.mark.parametrize("name", ["n20p4", "n9p6"])
+@pytest.mark.parametrize("name", ["n20p4", "n9p6", "wrap_n20p4", "wrap_n9p6"])
 def test_observe(golden, name):
+    # wrap_*: observer ids outside 0..P-1 (negative, P, beyond: numpy's modulo for the vectors, C's remainder for the board)
     g = golden("tron_observe_" + name)
     N, P = int(g["N"]), int(g["P"])
     E = len(g["player"])
