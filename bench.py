@@ -62,6 +62,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec (6.29 
 VALU_PEAK_MODEL = 256 * 4 * 2.4e9 / 2
 
 
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def newest_calibration():
     """profiles/r<N>_*issue_calibration.json of the highest round (tools/ubench/valu_rate.hip), or None."""
     import glob
@@ -86,12 +94,21 @@ WORKLOADS = {
     "blokus_p4_b16384": ("blokus", dict(), 16384, 2048, 8),
 }
 HEADLINE = "tron_p4_n20_b65536"
-# the reference's own CPU path (Python + Cython / scipy), one core, timed in the build container with the reference
-# imported from /root/reference; it cannot travel to the GPU box
-REFERENCE_PYTHON = {
-    "tron_p4_n20_b65536": 4.4e4, "tron_p4_n40_b65536": 4.3e4, "ttt_p3_3x5_k3_b262144": 2.4e4,
-    "ttt_p4_3x3x3_b262144": 2.0e3, "blokus_p4_b16384": 1.9,
-}
+
+
+def reference_python(workload):
+    """The reference's own CPU path (Python + Cython / scipy, one core) on this workload's game, as timed in the build
+    container by tools/time_reference_rollout.py -> profiles/reference_python.json (it cannot travel to the GPU box).  The
+    record of that file for the workload + where / jit / versions / script, or None when the file or the workload is
+    absent -- there are no constants to fall back to."""
+    rj = _load_json(os.path.join(ROOT, "profiles", "reference_python.json"))
+    rec = ((rj or {}).get("workloads") or {}).get(workload)
+    if not rec:
+        return None
+    return {"value": rec["value"], "unit": "env-steps/s", "cores": rj.get("cores_used", 1), "nproc": rj.get("nproc"),
+            "mean_episode_len": rec.get("mean_episode_len"), "sample": "%d env-steps in %.1f s" % (rec["steps"], rec["seconds"]),
+            "where": rj.get("where"), "jit": rj.get("jit"), "versions": rj.get("versions"),
+            "source": "profiles/reference_python.json (%s)" % rj.get("script", "tools/time_reference_rollout.py")}
 
 
 def algorithmic_bytes_per_step(game, kw, mean_len):
@@ -221,24 +238,12 @@ def cpu_baseline(workload, seconds=6.0, quick=False):
            "nproc": nproc}
     for c, r in runs.items():
         out["threads_%d" % c] = r
-    if workload in REFERENCE_PYTHON:
-        out["reference_python"] = {"value": REFERENCE_PYTHON[workload], "unit": "env-steps/s", "cores": 1,
-                                   "where": "build container (the Python reference cannot travel to the GPU box)",
-                                   "source": "SURVEY.md section 6: the reference envs imported from /root/reference, random agent incl. new_state resets"
-                                             + ("; numba absent, so un-jitted" if game == "blokus" else "")}
+    out["reference_python"] = reference_python(workload) or "absent (profiles/reference_python.json has no record for this workload)"
     out.update(extra)
     return out
 
 
 # ---------------------------------------------------------------------------------------------- roofline
-def _load_json(path):
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return None
-
-
 def pmc_for(workload, steps_per_launch):
     """PMC record of this workload's dominant kernel for EXACTLY this launch shape, or None."""
     tj = _load_json(os.path.join(ROOT, "profiles", "traffic_%s.json" % workload))
@@ -677,14 +682,10 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     return out
 
 
-# the reference's own per-call latency (us), one core, build container: tools/time_reference_dropin.py
-REFERENCE_DROPIN_US = {
-    "tron": {"new_state": 98.8, "next_state": 11.0, "valid_actions": 0.4, "state_to_observation": 6.0},
-    "tictactoe": {"new_state": 1.3, "next_state": 33.5, "valid_actions": 8.5, "state_to_observation": 4.9},
-    "tictactoe_3p": {"new_state": 1.0, "next_state": 38.4, "valid_actions": 11.9, "state_to_observation": 5.1},
-    "tictactoe_4p": {"new_state": 1.2, "next_state": 584.1, "valid_actions": 30.4, "state_to_observation": 9.0},
-    "blokus": {"new_state": 15.2, "next_state": 171456.2, "valid_actions": 86101.3, "state_to_observation": 264.6},
-}
+def reference_dropin_us():
+    """The reference's own per-call latency (us), one core, build container: tools/time_reference_dropin.py ->
+    profiles/reference_dropin.json ({} when absent: no constants)."""
+    return _load_json(os.path.join(ROOT, "profiles", "reference_dropin.json")) or {}
 
 
 def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p", "blokus")):
@@ -696,6 +697,8 @@ def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p",
     from colosseumrl_amd.config import get_environment
     rng = random.Random(0)
     out = {}
+    ref_us = reference_dropin_us()
+
     def one_pass(name):
         env = get_environment(name)() if name != "tron" else get_environment(name)("20;4")
         n_next, n_other = (300, 300) if name == "blokus" else (2000, 1000)
@@ -738,7 +741,7 @@ def dropin_latencies(names=("tron", "tictactoe", "tictactoe_3p", "tictactoe_4p",
         # tools/debug/stream_latency.py), and a latency is what the call CAN do
         (a, calls), (b, _) = one_pass(name), one_pass(name)
         rec = {m: round(min(a[m], b[m]), 1) for m in a}
-        rec["reference_us"] = REFERENCE_DROPIN_US.get(name)
+        rec["reference_us"] = ref_us.get(name)
         rec["calls"] = calls
         out[name] = rec
     out["what"] = ("us per call of the BaseEnvironment single-state API on one state (B = 1), random play, mean over a pass, the lower "
@@ -858,8 +861,8 @@ def compact_line(full):
         for k, v in cb.items():
             if k.startswith("threads_") and isinstance(v, dict):
                 c[k] = _sig(v["value"], 4)
-        if cb.get("reference_python"):
-            c["reference_python"] = cb["reference_python"]["value"]
+        if isinstance(cb.get("reference_python"), dict):
+            c["reference_python"] = _sig(cb["reference_python"]["value"], 4)
         line["cpu_baseline"] = c
     for k in ("value_warmed", "placement_tests_per_s", "detail"):
         if full.get(k) is not None:
@@ -935,15 +938,40 @@ def launcher_env():
     return under, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def gpus_visible_without_hip():
+    """GPUs this process would see, counted WITHOUT bringing up the HIP runtime (torch.cuda.device_count() stays clear of it
+    only while torch's amdsmi path works; its fallback is hipGetDeviceCount, and a fork + exec from a process that has
+    initialised the GPU is refused on this pool): KFD topology nodes with SIMDs, narrowed by ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when the topology cannot be read -- the ranks then check for themselves."""
+    import glob
+    total = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            total += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in os.environ:
+            ids = [x for x in os.environ[var].split(",") if x.strip()]
+            total = min(total, len([x for x in ids if not x.strip().lstrip("-").isdigit() or 0 <= int(x) < total]))
+    return total
+
+
 def self_launch(args, argv):
     """`--gpus N` with N > 1 and no launcher: start N ranks of this script under torch.distributed.run as a CHILD process
-    (this process has not touched the GPU: counting devices does not initialise it), pass its stdout / stderr through and
-    return its exit code.  Fewer than N visible devices is an error, never a smaller measurement."""
+    (this process never touches the GPU: devices are counted from the KFD topology, not through HIP), pass its stdout /
+    stderr through and return its exit code.  Fewer than N visible devices is an error, never a smaller measurement: said
+    here when the topology is readable, else by rank 0 of the child (`main`: exit 2 with the cause on stdout)."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus:
+    have = gpus_visible_without_hip()
+    if have is not None and have < args.gpus:
         fail("--gpus %d but only %d GPU(s) visible to this process: refusing to measure fewer GPUs than asked for" % (args.gpus, have))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -1007,6 +1035,10 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
+    if under_launcher and torch.cuda.device_count() < max(world, local_rank + 1) and world > 1:
+        if rank == 0:                                   # every rank sees the same count: all leave, rank 0 says why
+            fail("--gpus %d but only %d GPU(s) visible to this process: refusing to measure fewer GPUs than asked for" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(2)
     if torch.cuda.device_count() < 1:
         fail("no GPU visible to this process (torch.cuda.device_count() == 0): bench.py measures the HIP path only, there is no CPU fallback")
     torch.cuda.set_device(local_rank if under_launcher else 0)

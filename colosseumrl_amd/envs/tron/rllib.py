@@ -8,7 +8,8 @@ from ..wrappers.spaces import Discrete
 from .TronGridEnvironment import TronGridEnvironment
 from .TronRllibEnvironment import tron_observation_space
 
-ACTION_NAMES = ("forward", "right", "left")              # integer action -> the environment's action string
+ACTION_NAMES = {0: "forward", 1: "right", 2: "left"}     # integer action -> the environment's action string; a dict, as in the
+                                                         # reference (envs/tron/rllib.py:16): -1 or 3 from a faulty policy is a KeyError
 
 
 class TronRayEnvironment:
@@ -51,7 +52,7 @@ class SimpleAvoidAgent:
 
     def __call__(self, env, observation):
         if random.random() <= self.noise:
-            return random.choice(ACTION_NAMES)
+            return random.choice(tuple(ACTION_NAMES.values()))
         board = observation["board"]
         n = board.shape[0]
         head, direction = observation["heads"][0], observation["directions"][0]

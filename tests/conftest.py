@@ -69,6 +69,17 @@ def run_fresh():
     return run
 
 
+@pytest.fixture
+def no_gpu_context():
+    """For the CPU-suite tests that start children with `subprocess` straight from the pytest process: an unfiltered
+    `pytest tests` on a GPU box reaches them AFTER test_gpu_* has initialised the GPU in this process, and a fork + exec
+    from a process that holds a GPU context is what tests/_launcher.py exists to avoid (the pool refuses it).  They skip
+    then; the driver's `-m "not gpu"` run never has a context."""
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        pytest.skip("this process holds a GPU context: not starting child processes from it (run with -m 'not gpu')")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -118,7 +118,7 @@ def _run_bench(argv, env_extra=None):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
-def test_gpus_2_with_fewer_devices_fails_loudly():
+def test_gpus_2_with_fewer_devices_fails_loudly(no_gpu_context):
     """`--gpus N` means N ranks: with fewer devices visible the run exits non-zero and says why on stdout -- it never
     measures one GPU and calls it two."""
     rc, out, _ = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5"])
@@ -129,7 +129,7 @@ def test_gpus_2_with_fewer_devices_fails_loudly():
     assert "value" not in rec and "--gpus 2" in rec["error"] and "visible" in rec["error"]
 
 
-def test_gpus_must_equal_world_size_under_a_launcher():
+def test_gpus_must_equal_world_size_under_a_launcher(no_gpu_context):
     rc, out, _ = _run_bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                               "MASTER_PORT": str(_free_port())})
     assert rc != 0
@@ -138,7 +138,7 @@ def test_gpus_must_equal_world_size_under_a_launcher():
 
 
 @pytest.mark.skipif(torch.cuda.device_count() >= 1, reason="needs a box without a GPU")
-def test_no_gpu_is_an_error_not_a_cpu_measurement():
+def test_no_gpu_is_an_error_not_a_cpu_measurement(no_gpu_context):
     rc, out, _ = _run_bench([])
     assert rc != 0 and "no GPU" in json.loads(out.strip())["error"]
 

@@ -160,18 +160,29 @@ def test_hand_made_states_with_wild_heads_stay_inside_the_slab(kernel):
 
 
 def test_observe_with_out_of_range_player_ids():
-    """An observer id outside 0..P-1 observes as player 0 (documented in the header) instead of reading a wild table entry."""
+    """ANY observer id is an observer, as in the reference (ABI 109; TronGridEnvironment.py:393, CyTronGrid.pyx:70-71):
+    ids congruent mod P up to id == P observe alike, and every id -- negative, P, beyond P -- matches the oracle (which the
+    reference-generated tron_observe_wrap_* fixtures pin) instead of reading a wild table entry."""
     import torch
     from colosseumrl_amd.batched import TronBatch
+    from oracle import oracle as O
     tb = TronBatch(20, 4, 512)
     tb.rollout(9, 1)
     pl = torch.zeros((512,), dtype=torch.int8, device="cuda")
     ref = tb.observe(pl)
-    pl[::3] = 9
-    pl[1::3] = -2
+    pl[::3] = 4
+    pl[1::3] = -4
     got = tb.observe(pl)
     for k in ("board", "heads", "directions", "deaths"):
         assert torch.equal(ref[k], got[k]), k
+    pl = torch.randint(-128, 128, (512,), dtype=torch.int8, device="cuda")
+    got = tb.observe(pl)
+    st = O.TronState(20, 4, 512)
+    st.board[:] = tb.board.cpu().numpy().reshape(512, -1)
+    st.heads[:], st.dirs[:], st.deaths[:] = tb.heads.cpu().numpy(), tb.dirs.cpu().numpy(), tb.deaths.cpu().numpy()
+    ob, oh, od, ok = O.tron_observe(st, pl.cpu().numpy())
+    for k, want in (("board", ob), ("heads", oh), ("directions", od), ("deaths", ok)):
+        assert np.array_equal(got[k].cpu().numpy().reshape(want.shape), want), k
 
 
 @pytest.mark.parametrize("N,P,T,kernel", [(20, 4, 20, "auto"), (20, 4, 16383 + 40, "auto"), (40, 4, 64, "auto"), (12, 6, 50, "auto"),

@@ -60,13 +60,13 @@ print("ragged-ok")
 """
 
 
-def test_sanitizer_sees_the_oracle():
+def test_sanitizer_sees_the_oracle(no_gpu_context):
     p = subprocess.run([sys.executable, "-c", CANARY], env=_asan_env(), cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "canary-survived" not in p.stdout
     assert "AddressSanitizer: heap-buffer-overflow" in p.stderr and "orc_philox4x32" in p.stderr
 
 
-def test_oracle_is_clean_under_asan_ubsan():
+def test_oracle_is_clean_under_asan_ubsan(no_gpu_context):
     env = _asan_env()
     p = subprocess.run([sys.executable, "-c", RAGGED], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ragged-ok" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])

@@ -18,14 +18,14 @@ def test_there_are_scripts_to_check():
 
 
 @pytest.mark.parametrize("path", SCRIPTS, ids=[os.path.relpath(p, ROOT) for p in SCRIPTS])
-def test_script_compiles_and_prints_its_usage(path):
+def test_script_compiles_and_prints_its_usage(path, no_gpu_context):
     p = subprocess.run([sys.executable, path, "--help"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(p.stdout.strip()) > 40                        # the module docstring: what it measures and how to call it
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))), ids=os.path.basename)
-def test_shell_script_parses(path):
+def test_shell_script_parses(path, no_gpu_context):
     assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0
     assert open(path).read().startswith("#!/bin/bash")
 
@@ -37,7 +37,7 @@ def test_readme_names_only_scripts_that_exist():
         assert os.path.exists(os.path.join(ROOT, "tools", name)) or os.path.exists(os.path.join(ROOT, name)), name
 
 
-def test_bank_conflict_model_runs():
+def test_bank_conflict_model_runs(no_gpu_context):
     """The CPU-only LDS bank model that chose the Blokus count pass's table layout (row-major, 9 entries per row)."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "blokus_bank_model.py"), "20"], capture_output=True,
                        text=True, timeout=300, cwd=ROOT)
@@ -76,7 +76,7 @@ UBENCH = sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.hip")))
 
 
 @pytest.mark.parametrize("path", UBENCH, ids=os.path.basename)
-def test_ubench_source_compiles_for_gfx950(path, tmp_path):
+def test_ubench_source_compiles_for_gfx950(path, tmp_path, no_gpu_context):
     """The calibration / latency micro-benchmarks are stand-alone HIP programs built on the GPU box; here: they still compile."""
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

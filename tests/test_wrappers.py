@@ -112,7 +112,7 @@ def test_simple_avoid_agent_rules():
     assert {agent(TronGridEnvironment, obs) for _ in range(40)} <= {"left", "right"}
     random.seed(1)
     noisy = SimpleAvoidAgent(noise=1.0)
-    assert {noisy(TronGridEnvironment, obs) for _ in range(60)} == set(ACTION_NAMES)
+    assert {noisy(TronGridEnvironment, obs) for _ in range(60)} == set(ACTION_NAMES.values())
 
 
 @pytest.mark.gpu

@@ -7,10 +7,13 @@ set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/build/bounds
 mkdir -p "$OUT"
+rm -f "$OUT"/*.o "$OUT/libcolosseum_hip.so"        # a failed compile must not link against an object of an earlier run
+pids=()
 for f in capi tron ttt blokus; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DCRL_BOUNDS \
       -c "$ROOT/colosseumrl_amd/csrc/$f.hip" -o "$OUT/$f.o" &
+  pids+=($!)
 done
-wait
+for p in "${pids[@]}"; do wait "$p"; done           # a bare `wait` returns 0 whatever the jobs returned
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o "$OUT/libcolosseum_hip.so" "$OUT"/capi.o "$OUT"/tron.o "$OUT"/ttt.o "$OUT"/blokus.o
 echo "$OUT/libcolosseum_hip.so"

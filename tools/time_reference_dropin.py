@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Per-call latency of the REFERENCE's single-state API (build container only; the reference cannot travel).
 
-    python tools/time_reference_dropin.py            # prints one JSON object
+    python tools/time_reference_dropin.py            # prints one JSON object and writes profiles/reference_dropin.json
 
 Times new_state / next_state / valid_actions / state_to_observation of the reference envs imported from
 /root/reference (oracle/ref_loader.py) on one core, random play with restarts at terminal: the figures bench.py's
-`dropin` section prints beside this package's own per-call latencies (REFERENCE_DROPIN_US there).
+`dropin` section prints beside this package's own per-call latencies (it reads profiles/reference_dropin.json).
 TicTacToe is driven with canonical '(r, c)' strings (under numpy 2 the reference's own valid_actions strings
 do not parse), chosen from the empty cells; Blokus runs un-jitted (numba absent) and is sampled for a few plies only.
 """
@@ -90,6 +90,9 @@ def main():
     out["blokus"] = play(R["blokus"](), pick_blokus, 12, 12, rng)
     out = {k: {m: round(v, 1) for m, v in d.items()} for k, d in out.items()}
     out["where"] = "build container, one core, reference imported from /root/reference (numba absent: Blokus un-jitted)"
+    out["script"] = "tools/time_reference_dropin.py"
+    with open(os.path.join(ROOT, "profiles", "reference_dropin.json"), "w") as f:
+        json.dump(out, f, indent=1)
     print(json.dumps(out))
 
 
