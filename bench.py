@@ -94,6 +94,10 @@ WORKLOADS = {
     "blokus_p4_b16384": ("blokus", dict(), 16384, 2048, 8),
 }
 HEADLINE = "tron_p4_n20_b65536"
+# the end-of-rollout collective of the contract region: "gather" (to rank 0: seven shards over seven xGMI links at once) or
+# "all_gather" (every rank gets everything: a ring).  CRL_BENCH_COLLECTIVE overrides; both are timed in every N > 1 record
+# (`collective` section) and in a one-rank RCCL group by --gather-probe (profiles/r5_gather_probe.json).
+COLLECTIVE = os.environ.get("CRL_BENCH_COLLECTIVE", "gather")
 
 
 def reference_python(workload):
@@ -255,15 +259,22 @@ def pmc_for(workload, steps_per_launch):
     return shapes.get(str(int(steps_per_launch)))
 
 
-def valu_peaks(waves_per_simd):
-    """(chip VALU issue peak, peak at this occupancy, source) in wave64 instructions / s from the calibration ubench."""
+def valu_peaks(waves_per_simd, mix="valu"):
+    """(chip VALU issue peak, peak at this occupancy, source) in wave64 VALU instructions / s from the calibration ubench;
+    `mix` = "valu" (independent integer VALU only: the pure peak) or a game's instruction mix ("tron" / "ttt" / "blokus":
+    VALU with that game's share of SALU, LDS and quarter-rate multiplies in the stream -- what THAT stream can reach)."""
     cal = _load_json(CALIBRATION) if CALIBRATION else None
-    if not cal:
+    if not cal or mix not in cal.get("mixes", {}):
+        if mix != "valu":
+            return None, None, None
         return VALU_PEAK_MODEL, None, "model: 1 wave64 VALU / 2 cycles / SIMD at 2.4 GHz (no calibration file)"
-    rows = {int(r["waves_per_simd"]): r for r in cal["mixes"]["valu"]}
+    rows = {int(r["waves_per_simd"]): r for r in cal["mixes"][mix]}
     peak = max(r["valu_wave_insts_per_s"] for r in rows.values())
     w = max(k for k in rows if k <= max(1, waves_per_simd))
     return peak, rows[w]["valu_wave_insts_per_s"], "measured: profiles/%s (tools/ubench/valu_rate.hip)" % os.path.basename(CALIBRATION)
+
+
+MIX_OF_GAME = {"tron": "tron", "ttt": "ttt", "blokus": "blokus"}
 
 
 def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, launch_source=None):
@@ -303,7 +314,18 @@ def roofline(workload, batch, steps_per_launch, launch_s, mean_len, copy_gbs, la
         if peak_occ:
             vi["peak_at_occupancy"] = peak_occ
             vi["frac_at_occupancy"] = v / peak_occ
+        _, mix_occ, _ = valu_peaks(wps, MIX_OF_GAME[game])
+        if mix_occ:                                        # against what this game's instruction MIX issues at this occupancy
+            vi["mix"] = MIX_OF_GAME[game]
+            vi["peak_of_mix"] = mix_occ
+            vi["frac_of_mix"] = v / mix_occ
         r["valu_issue"] = vi
+    # Which roof is nearer: the launch's PHYSICAL HBM traffic / time against 8 TB/s, or its VALU instructions / time against
+    # what its instruction mix can issue.  "hbm" only where the memory fraction is the larger one (`frac`, the contract's
+    # algorithmic-bytes formula, stays as it is: it credits bytes a fused launch never moves).
+    issue = (r.get("valu_issue") or {}).get("frac_of_mix") or (r.get("valu_issue") or {}).get("frac")
+    r["bound"] = "hbm" if issue is None or r["physical_frac"] >= issue else "issue"
+    r["traffic_over_algorithmic"] = traffic / max(alg_bps * batch * steps_per_launch, 1.0)
     return r
 
 
@@ -378,6 +400,21 @@ class Plumbing:
         if self.cuda:
             self.torch.cuda.synchronize()
 
+    def complete(self, sr):
+        """End of this rank's timed work.  Without a process group everything was queued on ONE stream, and the product's own
+        stream-scoped wait ends the region (`ShardedRollout.wait` -> `TronBatch.wait` -> crl_stream_wait_mapped: the host
+        spins on a word in mapped memory that a one-thread kernel behind the launches publishes; ~3.5 us cheaper than a
+        device synchronise -- the same call a user of the batched steppers makes).  With a process group the collective
+        runs on the communicator's own stream: device synchronise, as the contract says."""
+        if self.cuda and not self.use_dist and hasattr(sr, "wait"):
+            sr.wait()
+        else:
+            self.sync()
+
+    def completion(self):
+        return ("ShardedRollout.wait (crl_stream_wait_mapped on the launch stream)" if self.cuda and not self.use_dist
+                else "torch.cuda.synchronize" if self.cuda else "none (cpu)")
+
     def barrier(self):
         self.sync()
         if self.use_dist:
@@ -392,7 +429,7 @@ class Plumbing:
         return [float(v) for v in t.tolist()]
 
 
-def timed_rollout(pl, sr, steps, seed, chunk, events=None, dst=None):
+def timed_rollout(pl, sr, steps, seed, chunk, events=None, dst=None, gather=True):
     """The contract's timed region: exactly `steps` env-steps + the gather of the per-game results, bracketed by
     barrier + synchronize on both sides.  The clock stops when THIS rank's work (incl. the collective, which itself waits
     for the other ranks' shards) has completed on the device; the closing barrier follows, and the caller takes the MAX of
@@ -413,8 +450,10 @@ def timed_rollout(pl, sr, steps, seed, chunk, events=None, dst=None):
         launches = sr.rollout(steps, seed, chunk)
         if events:
             events[1].record()
-        gathered = sr.gather(dst=dst, copy=False)          # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused receive buffer)
-        pl.sync()
+        # the one collective: per-game results to rank `dst` (no host sync between the last launch and it; the reused
+        # receive buffer).  gather=False (the attribution regions only, never `value`): the same region without it
+        gathered = sr.gather(dst=dst, copy=False) if gather else None
+        pl.complete(sr)
         elapsed = time.perf_counter() - t0
     finally:
         if gc_on:
@@ -430,13 +469,58 @@ def contract_region(pl, sr, steps, warmup, seed, chunk, events=None):
     (same launch path, gather and barriers), so nothing in the timed region runs for the first time.  Every rank calls
     this; returns {elapsed (MAX over ranks), elapsed_rank, marker_s, launches, rows (rank 0: snapshot of all games' result
     rows, else None)}."""
-    dst = 0 if pl.use_dist else None                       # the episode-end gather goes to rank 0
+    dst = (0 if pl.use_dist else None) if COLLECTIVE == "gather" else None    # the episode-end gather goes to rank 0
+    if pl.use_dist and hasattr(sr, "warm_collective"):
+        sr.warm_collective(dst)                            # set-up: communicator, channels, receive buffer (no stepping)
     if warmup > 0:
         timed_rollout(pl, sr, warmup, seed, chunk, events, dst)
     else:
         sr.gather(dst=dst, copy=False)                     # brings the communicator / receive buffer up outside the clock
     e, k, n, g = timed_rollout(pl, sr, steps, seed, chunk, events, dst)
     return {"elapsed": pl.max_over_ranks([e])[0], "elapsed_rank": e, "marker_s": k, "launches": n, "rows": g}
+
+
+def collective_attribution(pl, sr, steps, seed, chunk, reps=9):
+    """What the end-of-rollout collective costs in THIS world, so that an N > 1 line separates kernel scaling from
+    collective latency: further regions of the contract's shape (barrier + synchronise on both sides, max over ranks per
+    region, median over `reps`) without a collective, with `gather` to rank 0 and with `all_gather_into_tensor`.
+    Every rank calls this.  {region_no_gather_us, region_gather_us, region_all_gather_us, gather_us, all_gather_us,
+    elapsed_ranks_us (every rank's own time of the last gather region), rank_spread_us}."""
+    def regions(dst, gather):
+        ts = []
+        for i in range(reps):
+            e = timed_rollout(pl, sr, steps, seed, chunk, None, dst, gather)[0]
+            ts.append(pl.max_over_ranks([e])[0])
+            if hasattr(sr.stepper, "reset_stats") and (i + 1) * steps % 2000 < steps:
+                sr.stepper.reset_stats()                  # keep the 16-bit rows exact (what a short region ships)
+        ts = sorted(ts[1:])
+        return ts[len(ts) // 2] * 1e6, e
+    none_us, _ = regions(0, False)
+    gather_us, e_rank = regions(0, True)
+    all_us, _ = regions(None, True)
+    if pl.use_dist:
+        t = pl.torch.zeros((pl.world,), dtype=pl.torch.float64, device=pl.device)
+        t[pl.rank] = e_rank * 1e6
+        pl.dist.all_reduce(t, op=pl.dist.ReduceOp.SUM)
+        ranks = [round(float(v), 2) for v in t.tolist()]
+    else:
+        ranks = [round(e_rank * 1e6, 2)]
+    return {"region_no_gather_us": round(none_us, 2), "region_gather_us": round(gather_us, 2), "region_all_gather_us": round(all_us, 2),
+            "gather_us": round(gather_us - none_us, 2), "all_gather_us": round(all_us - none_us, 2),
+            "elapsed_ranks_us": ranks, "rank_spread_us": round(max(ranks) - min(ranks), 2),
+            "what": "median of %d further regions of the timed shape each (max over ranks per region): no collective / gather to rank 0 / all_gather_into_tensor" % (reps - 1)}
+
+
+def attach_collective(out, coll, row_bytes, batch, world, steps):
+    """Put `collective_attribution`'s result into the record of an N-rank run: the `collective` section + the two scalars
+    a reader of the line wants first, `gather_us` and `value_without_gather`."""
+    if not coll:
+        return
+    coll.update({"row_bytes": row_bytes, "rows_bytes_per_rank": row_bytes * batch, "rows_bytes_into_rank0": row_bytes * batch * (world - 1),
+                 "value_without_gather": world * batch * steps / (coll["region_no_gather_us"] * 1e-6),
+                 "value_in_attribution_regions": world * batch * steps / (coll["region_%s_us" % COLLECTIVE] * 1e-6)})
+    out["collective"] = coll
+    out["gather_us"], out["value_without_gather"] = coll["%s_us" % COLLECTIVE], coll["value_without_gather"]
 
 
 def dispatch_time_pass(torch, sr, steps, seed, chunk, events, reps=20):
@@ -524,6 +608,88 @@ def steady_state(torch, workload, device, seed, copy_gbs, target_s=0.25):
            "dtype": "u32" if game == "ttt" else "int8",
            "roofline": roofline(workload, batch, chunk, launch_s, mean_len, copy_gbs)}
     del st
+    return out
+
+
+OUT_OF_CACHE_BATCH = 1 << 20       # Tron 20 x 20: 1,048,576 games x 416 B = 436 MB of state > the 256 MiB Infinity Cache
+
+
+def out_of_cache(torch, device, seed, steps=20):
+    """The Tron kernels on a batch whose state does NOT fit the Infinity Cache (B = 1,048,576: 436 MB; at BASELINE's
+    65,536 games the 27 MB of state live in the 256 MiB MALL between launches, and the PMC's FETCH_SIZE counts those hits):
+    the `steps`-step rollout launch (events attached to the dispatch, median of 9 isolated launches) and the fused
+    step_observe call (events around 20 calls back to back), each with its algorithmic bytes, the PMC traffic of the
+    same launch shape where a pass exists (profiles/traffic_tron_p4_n20_b1048576.json) and the fractions of 8 TB/s."""
+    from colosseumrl_amd.batched import TronBatch
+    B, N, P = OUT_OF_CACHE_BATCH, 20, 4
+    tb = TronBatch(N, P, B, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    torch.cuda.synchronize()
+    tb.rollout(steps, seed)
+    ts = []
+    for i in range(9):
+        torch.cuda.synchronize()
+        tb.rollout(steps, seed, events=(e0, e1))
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+        if i % 4 == 3:
+            tb.reset_stats()
+    launch_s = sorted(ts)[len(ts) // 2]
+    mean_len = mean_episode_len(tb.results(copy=False))[0]
+    alg = algorithmic_bytes_per_step("tron", dict(num_players=P, board_size=N), mean_len) * B * steps
+    kp = ((_load_json(os.path.join(ROOT, "profiles", "traffic_out_of_cache.json")) or {}).get("kernels") or {})
+    pmc = kp.get("tron_rollout_quad_kernel<24>") or {}
+    if pmc.get("steps_per_launch") not in (None, steps) or pmc.get("games") not in (None, B):
+        pmc = {}                                            # a PMC record describes exactly one launch shape
+    out = {"games": B, "state_bytes": B * (N * N + 4 * P), "infinity_cache_bytes": 256 << 20}
+    r = {"kernel": "tron_rollout_quad_kernel", "steps_per_launch": steps, "launch_ms": launch_s * 1e3, "mean_episode_len": round(mean_len, 3),
+         "value": B * steps / launch_s, "algorithmic_bytes": alg, "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS,
+         "traffic_model": int(launch_traffic_model("tron", dict(num_players=P, board_size=N)) * B)}
+    r["traffic"] = int(pmc["hbm_bytes_per_call"]) if pmc.get("hbm_bytes_per_call") else None
+    phys = r["traffic"] or r["traffic_model"]
+    r["physical_frac"] = phys / launch_s / 1e9 / HBM_PEAK_GBS
+    r["traffic_source"] = ("rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE), same launch shape: profiles/traffic_out_of_cache.json" if r["traffic"]
+                           else "model: state in + out once + statistics (no PMC pass)")
+    r["traffic_over_algorithmic"] = phys / alg
+    if pmc.get("valu_insts_per_call"):
+        _, mix_occ, _ = valu_peaks(4, "tron")
+        if mix_occ:
+            r["valu_frac_of_mix"] = pmc["valu_insts_per_call"] / launch_s / mix_occ
+    r["bound"] = "hbm" if r["physical_frac"] >= (r.get("valu_frac_of_mix") or 0.0) else "issue"
+    out["rollout"] = r
+    fo = tb.step_observe(None, seed=7, out=None)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        tb.step_observe(None, seed=7, out=fo)
+    e1.record()
+    torch.cuda.synchronize()
+    call_s = e0.elapsed_time(e1) * 1e-3 / 20
+    nbytes = (1 + P) * N * N * B
+    so = {"kernel": "tron_step_observe_kernel<4, 64>", "gpu_us_per_call": call_s * 1e6, "algorithmic_bytes": nbytes,
+          "frac": nbytes / call_s / 1e9 / HBM_PEAK_GBS, "value": B / call_s,
+          "traffic": (kp.get("tron_step_observe_kernel<4, 64>") or {}).get("hbm_bytes_per_call")}
+    if so["traffic"]:
+        so["physical_frac"] = so["traffic"] / call_s / 1e9 / HBM_PEAK_GBS
+    out["step_observe"] = so
+    acts = torch.randint(-1, 2, (P, B), dtype=torch.int8, device=device)
+    tb.step(acts, auto_reset=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        tb.step(acts, auto_reset=True)
+    e1.record()
+    torch.cuda.synchronize()
+    call_s = e0.elapsed_time(e1) * 1e-3 / 20
+    st = {"kernel": "tron_step_kernel<4>", "gpu_us_per_call": call_s * 1e6, "algorithmic_bytes": (12 * P + 2) * B,
+          "frac": (12 * P + 2) * B / call_s / 1e9 / HBM_PEAK_GBS, "value": B / call_s,
+          "traffic": (kp.get("tron_step_kernel<4>") or {}).get("hbm_bytes_per_call")}
+    if st["traffic"]:
+        st["physical_frac"] = st["traffic"] / call_s / 1e9 / HBM_PEAK_GBS
+    out["step"] = st
+    del tb, fo, acts
+    torch.cuda.empty_cache()
     return out
 
 
@@ -764,26 +930,34 @@ def world_of_one_gather_us(torch, dist, make, args, steps_per_launch):
                             device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
         sr = ShardedRollout(make, WORKLOADS[args.workload][2] if args.batch <= 0 else args.batch)
-        def region(with_gather):
+        def region(mode):
             ts = []
             for i in range(60):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 sr.rollout(steps_per_launch, args.seed, steps_per_launch)
-                if with_gather:
+                if mode == "gather":
                     sr.gather(dst=0, copy=False)
+                elif mode == "all_gather":
+                    sr.gather(dst=None, copy=False)
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
                 if i % 20 == 19:
                     sr.stepper.reset_stats()                # keep the 16-bit rows exact (what a 20-step region ships)
             ts = sorted(ts[10:])
             return ts[len(ts) // 2] * 1e6
-        region(True)
-        a, b = region(False), region(True)
+        sr.warm_collective(0)
+        sr.warm_collective(None)
+        region("gather")
+        a, b, c = region(None), region("gather"), region("all_gather")
+        a2, b2, c2 = region(None), region("gather"), region("all_gather")      # a second round: the order must not decide
         row = sr.gather(dst=0, copy=False)
-        return {"gather_us": round(b - a, 2), "region_us": round(b, 2), "region_no_gather_us": round(a, 2),
-                "row_bytes": int(row.shape[1] * row.element_size()), "what": "median of 50 launch [+ gather] + synchronise "
-                "regions of the timed launch shape in a one-rank RCCL group created for this measurement"}
+        return {"gather_us": round(min(b, b2) - min(a, a2), 2), "all_gather_us": round(min(c, c2) - min(a, a2), 2),
+                "region_us": round(min(b, b2), 2), "region_all_gather_us": round(min(c, c2), 2), "region_no_gather_us": round(min(a, a2), 2),
+                "rounds": [[round(a, 2), round(b, 2), round(c, 2)], [round(a2, 2), round(b2, 2), round(c2, 2)]],
+                "row_bytes": int(row.shape[1] * row.element_size()), "what": "median of 50 launch [+ collective] + synchronise "
+                "regions of the timed launch shape in a one-rank RCCL group created for this measurement, two rounds (the lower "
+                "median of each): no collective / torch.distributed.gather with the per-rank view list / all_gather_into_tensor"}
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -802,8 +976,8 @@ def compact_summary(out):
     def wl(rec):
         r = rec.get("roofline", {})
         return {"v": sig(rec.get("value")), "ms": sig(r.get("launch_ms")), "alg": sig(r.get("frac"), 3), "hbm": sig(r.get("physical_frac"), 3),
-                "valu": sig(r.get("valu_issue", {}).get("frac"), 3),
-                "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
+                "valu": sig(r.get("valu_issue", {}).get("frac"), 3), "mix": sig(r.get("valu_issue", {}).get("frac_of_mix"), 3),
+                "bound": r.get("bound"), "cpu": sig(rec.get("cpu_baseline", {}).get("value"), 3)}
     warmed = out.get("warmed") or {}
     sm = {"headline": {"v": sig(out["value"]), "us": sig(out["timed_region_ms"] * 1e3), "kernel_us": sig((out.get("kernel_ms") or 0) * 1e3) or None,
                        "kernel_dispatch_us": sig((out.get("kernel_ms_dispatch") or 0) * 1e3) or None,
@@ -833,9 +1007,11 @@ def compact_summary(out):
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data")
 CONFIG_KEYS = ("workload", "games_per_gpu", "global_games", "steps_per_launch", "launches", "mean_episode_len", "episodes",
-               "parallelism", "gather", "device_warmup")
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_env_step",
-                 "physical_frac", "frac_of_copy", "valu_frac", "steady_value", "steady_frac", "steady_valu_frac",
+               "parallelism", "gather", "completion", "device_warmup", "cpu_baseline")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "launch_ms",
+                 "bytes_per_env_step", "physical_frac", "frac_of_copy", "valu_frac", "valu_frac_of_mix", "steady_value",
+                 "steady_bound", "steady_frac", "steady_valu_frac", "steady_valu_frac_of_mix",
+                 "oc_games", "oc_launch_ms", "oc_frac", "oc_physical_frac", "oc_step_observe_frac",
                  "box_clock_mhz", "box_issue_vs_calibration", "box_clock_mhz_warm", "box_issue_vs_calibration_warm", "note")
 LINE_LIMIT = 4096
 
@@ -864,7 +1040,14 @@ def compact_line(full):
         if isinstance(cb.get("reference_python"), dict):
             c["reference_python"] = _sig(cb["reference_python"]["value"], 4)
         line["cpu_baseline"] = c
-    for k in ("value_warmed", "placement_tests_per_s", "detail"):
+    coll = full.get("collective")
+    if coll:                                               # the N > 1 record: kernel scaling apart from collective latency
+        line["collective"] = {k: (_sig(coll[k], 5) if isinstance(coll[k], float) else coll[k])
+                              for k in ("gather_us", "all_gather_us", "region_no_gather_us", "region_gather_us", "region_all_gather_us",
+                                        "value_without_gather", "row_bytes", "rows_bytes_into_rank0", "rank_spread_us") if k in coll}
+        ranks = coll.get("elapsed_ranks_us") or []
+        line["collective"]["elapsed_ranks_us"] = ranks if len(ranks) <= 8 else [min(ranks), max(ranks)]
+    for k in ("gather_us", "value_without_gather", "value_warmed", "placement_tests_per_s", "detail"):
         if full.get(k) is not None:
             line[k] = _sig(full[k], 5) if isinstance(full[k], float) else full[k]
     line["summary"] = compact_summary(full)
@@ -929,6 +1112,8 @@ def parse_args(argv=None):
     ap.add_argument("--only-headline", action="store_true", help="skip warmed / steady_state / seeds / others / step_api / dropin (profiling runs)")
     ap.add_argument("--only-step-api", action="store_true", help="run just the per-step API section (profiling runs)")
     ap.add_argument("--only-dropin", action="store_true", help="run just the single-state drop-in latency section")
+    ap.add_argument("--only-out-of-cache", action="store_true",
+                    help="run just the out-of-Infinity-Cache section (Tron 20x20, 1,048,576 games: 20-step rollout, step_observe, step)")
     return ap.parse_args(argv)
 
 
@@ -1051,6 +1236,9 @@ def main(argv=None):
     if args.only_dropin:
         print(json.dumps({"dropin": dropin_latencies()}))
         return
+    if args.only_out_of_cache:
+        print(json.dumps({"out_of_cache": out_of_cache(torch, device, args.seed)}))
+        return
     if args.only_step_api:
         copy_gbs, write_gbs = measure_copy_bandwidth(torch, device)
         print(json.dumps({"copy_peak_GBs": copy_gbs, "write_stream_peak_GBs": write_gbs,
@@ -1086,6 +1274,8 @@ def main(argv=None):
     if kernel_s is None:
         kernel_s = launch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events)
     kernel_dispatch_s = dispatch_time_pass(torch, sr, args.steps, args.seed, args.chunk, events) if args.steps <= 4096 else None
+    # every rank: what the collective costs in this world (further regions of the same shape; never `value`)
+    coll = collective_attribution(pl, sr, args.steps, args.seed, args.chunk) if pl.use_dist else None
     if rank == 0:
         copy_gbs, write_gbs = measure_copy_bandwidth(torch, device) if world == 1 else (None, None)
         # The launch's duration for the roofline: HIP events ATTACHED to the dispatch (the kernel's own begin -> end, median
@@ -1101,7 +1291,8 @@ def main(argv=None):
                              "timed shape; marker events recorded around such a launch: %.2f us" % (kernel_s * 1e6))
         box_cold = box_issue_probe(torch, device)          # the box as it is right behind the contract region
         row_bytes = int(meas["rows"].shape[-1] * meas["rows"].element_size())
-        gather_desc = ("rccl gather to rank 0 (torch.distributed.gather), %d-byte rows" % row_bytes) if pl.use_dist \
+        gather_desc = ("rccl %s, %d-byte rows" % ("gather to rank 0 (torch.distributed.gather)" if COLLECTIVE == "gather"
+                                                 else "all_gather_into_tensor", row_bytes)) if pl.use_dist \
             else "none (single process, no process group)"
         out = contract_record(args.workload, batch, world, args.steps, args.warmup, args.chunk, meas, launch_s, launch_source,
                               copy_gbs, gather_desc)
@@ -1109,10 +1300,15 @@ def main(argv=None):
                     "kernel_ms_source": ("HIP marker events around the launches of the timed region" if region_events else
                                          "HIP marker events around the launches of one more region of the same shape, right after the timed "
                                          "one (two event records cost 3.6 us of the region, ~10 us next to a collective: not recorded inside it)")})
+        out["config"]["completion"] = pl.completion()
+        attach_collective(out, coll, row_bytes, batch, world, args.steps)
+        if world > 1:
+            out["config"]["cpu_baseline"] = "not run at N > 1 (rank 0 at N = 1 only)"
         out["box"] = {"after_contract_region": box_cold,
                       "what": "crl_diag_issue_probe: independent integer VALU instructions at 4 waves per SIMD on every CU; clock_mhz = "
                               "shader clock under that load; vs_calibration = rate / profiles/%s at the same occupancy"
                               % (os.path.basename(CALIBRATION) if CALIBRATION else "(no calibration file)")}
+        out["roofline"]["valu_frac_of_mix"] = (out["roofline"].get("valu_issue") or {}).get("frac_of_mix")
         out["roofline"]["box_clock_mhz"] = box_cold["clock_mhz"]
         out["roofline"]["box_issue_vs_calibration"] = box_cold.get("vs_calibration")
         full_run = world == 1 and not args.only_headline
@@ -1140,7 +1336,9 @@ def main(argv=None):
             ssr = out["steady_state"]["roofline"]
             out["roofline"].update({"steady_value": out["steady_state"]["value"], "steady_launch_ms": ssr["launch_ms"],
                                     "steady_frac": ssr["frac"], "steady_physical_frac": ssr["physical_frac"],
-                                    "steady_valu_frac": ssr.get("valu_issue", {}).get("frac")})
+                                    "steady_valu_frac": ssr.get("valu_issue", {}).get("frac"),
+                                    "steady_valu_frac_of_mix": ssr.get("valu_issue", {}).get("frac_of_mix"),
+                                    "steady_bound": ssr.get("bound")})
             others = {}
             for wl in WORKLOADS:
                 if wl != args.workload:
@@ -1150,6 +1348,14 @@ def main(argv=None):
             out["roofline"]["box_clock_mhz_warm"] = warm["clock_mhz"]
             out["roofline"]["box_issue_vs_calibration_warm"] = warm.get("vs_calibration")
             out["step_api"] = step_api_rates(torch, device, copy_gbs, write_gbs)
+            if args.workload == HEADLINE:
+                try:                                        # the first real-HBM rows: state that does not fit the Infinity Cache
+                    out["out_of_cache"] = oc = out_of_cache(torch, device, args.seed)
+                    out["roofline"].update({"oc_games": oc["games"], "oc_launch_ms": oc["rollout"]["launch_ms"],
+                                            "oc_frac": oc["rollout"]["frac"], "oc_physical_frac": oc["rollout"]["physical_frac"],
+                                            "oc_step_observe_frac": oc["step_observe"]["frac"]})
+                except Exception as exc:                    # never fatal for the bench line
+                    out["out_of_cache"] = {"error": repr(exc)[:300]}
             out["stream_peaks"] = {"copy_GBs": copy_gbs, "write_GBs": write_gbs,
                                    "what": "measured in this run over 1 GiB: best read+write copy, pure write stream"}
             try:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
-CRL_ABI_VERSION = 109
+CRL_ABI_VERSION = 110
 CRL_STEP_AUTO_RESET = 1
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
@@ -84,6 +84,9 @@ PROTOTYPES = {
     "crl_tron_observe_all": (_I, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "crl_tron_ranking": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "crl_tron_step_observe": (_I, [_VP, _I64, _U64, _U64] + [_VP] * 13 + [_U32, _VP]),
+    "crl_tron_next_state_inplace64": (_I, [_VP, _I64] + [_VP] * 12 + [_VP]),
+    "crl_tron_next_state_inplace64_host": (_I, [_VP] + [_VP] * 12 + [_VP, _VP, _U32, C.c_double]),
+    "crl_tron_relative_player_inplace64": (_I, [_VP, _I64, _VP, _I64, _VP, _VP]),
     "crl_tron_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _I, _VP, _VP]),
     "crl_tron_check_state": (_I, [_VP, _I64, _VP, _VP, _VP, _VP]),
     "crl_ttt_create": (_I, [_I, _I, _I, _I, _I, C.POINTER(_VP)]),

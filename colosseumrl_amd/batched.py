@@ -83,7 +83,31 @@ class _Ctx:
             pass
 
 
-class TronBatch:
+class _Waitable:
+    """``wait()``: block the host until everything queued so far on the stream the stepper launches on (torch's CURRENT
+    stream of its device) has run -- the stream-scoped end of a rollout.  The wait is on MAPPED MEMORY
+    (``crl_stream_wait_mapped``, include/colosseum_hip.h: a one-thread kernel behind the queued work publishes a sequence
+    number into page-locked host memory, the host spins on it): ~3.5 us less than ``hipStreamSynchronize`` /
+    ``torch.cuda.synchronize()`` behind a short launch (tools/ubench/mailbox_rtt.hip), which is a tenth of a 20-step
+    rollout region.  Work on OTHER streams is not waited for (``torch.cuda.synchronize()`` does that)."""
+    WAIT_TIMEOUT_S = 30.0            # after this long without the flag the call falls back to hipStreamSynchronize (and its error)
+    _wait_flag = None
+
+    def wait(self):
+        if self._wait_flag is None:
+            import numpy as np
+            from .single import HostBlob
+            blob = HostBlob(self._lib, [("seq", np.uint32, 1)])
+            self._wait_flag = (blob, blob.d["seq"], C.c_void_p(blob.v["seq"].ctypes.data))
+            self._wait_seq = 0
+        self._wait_seq = seq = (self._wait_seq + 1) & 0xFFFFFFFF or 1
+        with _DevGuard(self.device):
+            rc = self._lib.crl_stream_wait_mapped(_stream(), self._wait_flag[1], self._wait_flag[2], seq, self.WAIT_TIMEOUT_S)
+        if rc:
+            check(rc, "crl_stream_wait_mapped")
+
+
+class TronBatch(_Waitable):
     """B games of N x N Tron with P players (reference: envs/tron/TronGridEnvironment.py).
 
     State tensors (device):
@@ -316,7 +340,7 @@ class TronBatch:
         return torch.stack(cols, dim=1).to(torch.int16).contiguous()
 
 
-class TTTBatch:
+class TTTBatch(_Waitable):
     """B games of n-player TicTacToe on a dims board, K in a row (reference: envs/tictactoe/*).
 
     State tensors (device): occ int32 [P, B] bit masks; winner int8 [B] (-1 none); to_move int8 [B].
@@ -498,7 +522,7 @@ class TTTBoards:
         return obs, valid
 
 
-class BlokusBatch:
+class BlokusBatch(_Waitable):
     """B games of 4-player 20x20 Blokus (reference: envs/blokus/*).
 
     State tensors (device): occ int32 [B, 4, 20] row bitboards per colour; inv int32 [B, 4] piece masks;

@@ -68,6 +68,26 @@ __global__ void __launch_bounds__(64) signal_kernel(uint32_t *flag, const uint32
 }
 } // namespace
 
+// spin on a word of mapped memory until it reads `seq`: 3.5 us less than hipStreamSynchronize for a short launch chain
+// (tools/ubench/mailbox_rtt.hip).  The clock is read every 256 polls only; a stream that faulted never delivers -> after
+// `timeout_s` the runtime's own wait reports it.
+int crl_spin_mapped(void *stream, const volatile uint32_t *flag_host, uint32_t seq, double timeout_s, const char *who)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; ++spins) {
+        if (*flag_host == seq) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return CRL_OK;
+        }
+        if ((spins & 255u) == 0u &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            break;
+    }
+    CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
+    CRL_REQUIRE(*flag_host == seq, "%s: the stream drained but the flag reads %u, not %u", who, (unsigned)*flag_host, (unsigned)seq);
+    return CRL_OK;
+}
+
 extern "C" {
 
 const char *crl_last_error(void) { return g_err; }
@@ -145,21 +165,7 @@ int crl_stream_wait_mapped(void *stream, uint32_t *flag_device, const volatile u
     CRL_REQUIRE(flag_device != nullptr && flag_host != nullptr, "crl_stream_wait_mapped: NULL flag pointer");
     hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag_device, seq);
     CRL_LAUNCH_CHECK();
-    // spin on the mapped word: 3.5 us less than hipStreamSynchronize for a short launch chain (tools/ubench/mailbox_rtt.hip).
-    // The clock is read every 256 polls only; a stream that faulted never delivers -> the runtime's own wait reports it.
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 1;; ++spins) {
-        if (*flag_host == seq) {
-            std::atomic_thread_fence(std::memory_order_acquire);
-            return CRL_OK;
-        }
-        if ((spins & 255u) == 0u &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-            break;
-    }
-    CRL_HIP(hipStreamSynchronize((hipStream_t)stream));
-    CRL_REQUIRE(*flag_host == seq, "crl_stream_wait_mapped: the stream drained but the flag reads %u, not %u", (unsigned)*flag_host, (unsigned)seq);
-    return CRL_OK;
+    return crl_spin_mapped(stream, flag_host, seq, timeout_s, "crl_stream_wait_mapped");
 }
 
 int crl_diag_bounds(uint32_t *out12)

@@ -89,6 +89,10 @@ int crl_tron_bounds(unsigned int *out4);
 int crl_ttt_bounds(unsigned int *out4);
 int crl_blokus_bounds(unsigned int *out4);
 
+// host side of a completion flag in mapped memory (capi.hip): spin until *flag_host == seq, fall back to hipStreamSynchronize
+// after timeout_s; `who` names the caller in error messages
+int crl_spin_mapped(void *stream, const volatile uint32_t *flag_host, uint32_t seq, double timeout_s, const char *who);
+
 // ---------------------------------------------------------------- Philox-4x32-10
 // Salmon et al., SC'11 (Random123 constants). 10 rounds of two 32 x 32 -> 64-bit products.
 // WIDE: each product is ONE v_mad_u64_u32 instead of the v_mul_lo_u32 + v_mul_hi_u32 pair the compiler picks (it splits

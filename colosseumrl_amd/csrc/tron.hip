@@ -2917,6 +2917,124 @@ tron_step_observe_any_kernel(const crl_tron_cfg cfg, const TronGeom g, const int
     }
 }
 
+// ---- the reference's own native boundary, with its own types ---------------------------------------------------------
+// CyTronGrid.pyx:3-7 next_state_inplace(long[:, ::1] board, long[::1] heads, long[::1] directions, long[::1] deaths,
+// const long[::1] actions) and :65 relative_player_inplace(long[:, ::1] board, num_players, player): C-contiguous int64
+// arrays in the reference's layout, mutated in place.  For callers that HOLD reference states (the single-state drop-in
+// class on crl_host_alloc memory): no int64 <-> int8 conversion on the host, and the board is touched where the step
+// touches it -- <= P probes and <= P trail stores of 8 bytes.  One workgroup per game (B games lie one behind the other,
+// each in the reference layout).  With observation outputs (optional) the whole board is staged into LDS as bytes by all
+// threads -- its loads are in flight together with thread 0's player vectors, ONE round trip on mapped memory --, thread 0
+// then probes the LDS copy, and all threads write the P relabelled int64 copies (CyTronGrid.pyx:70-71, C remainder).
+struct Board64 {                    // in place on the caller's int64 board
+    int64_t *p;
+    __device__ __forceinline__ int raw(const int c) const { return (int)p[c]; }
+    __device__ __forceinline__ int owner(const int r) const { return r; }
+    __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (int64_t)who; }
+};
+struct DualBoard64 {                // step on the LDS byte copy, mirror the trail writes to the caller's int64 board
+    uint8_t *l;
+    int64_t *g;
+    __device__ __forceinline__ int raw(const int c) const { return l[c]; }
+    __device__ __forceinline__ int owner(const int r) const { return r; }
+    __device__ __forceinline__ void put(const int c, const int who) const { l[c] = (uint8_t)who; g[c] = (int64_t)who; }
+};
+
+// the player vectors of ONE game by value (kernel arguments): what the single-state call passes instead of letting the
+// kernel fetch them over PCIe before it can probe the board
+struct TronVec64 {
+    int32_t h[CRL_TRON_MAX_P], d[CRL_TRON_MAX_P], k[CRL_TRON_MAX_P], a[CRL_TRON_MAX_P];
+};
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_next_state64_kernel(const TronGeom g, const int64_t B, int64_t *__restrict__ board, int64_t *__restrict__ heads,
+                         int64_t *__restrict__ dirs, int64_t *__restrict__ deaths, const int64_t *__restrict__ actions,
+                         int64_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                         int64_t *__restrict__ obs_board, int64_t *__restrict__ oh, int64_t *__restrict__ od,
+                         int64_t *__restrict__ ok, const TronVec64 vec, const bool by_value, uint32_t *flag, const uint32_t seq)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int NN = g.NN;
+    const int64_t b = blockIdx.x;
+    int64_t *gb = board + b * NN;
+    const bool want_obs = obs_board != nullptr;
+    TronRegs<P> s;
+    int act[P], rew[P];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = by_value ? vec.h[p] : (int)heads[b * P + p];
+            s.d[p] = by_value ? vec.d[p] : (int)dirs[b * P + p];
+            s.k[p] = by_value ? vec.k[p] : (int)deaths[b * P + p];
+            act[p] = by_value ? vec.a[p] : (int)actions[b * P + p];
+        }
+    }
+    if (want_obs) {
+        for (int c = threadIdx.x; c < NN; c += 256) lds[c] = (uint8_t)gb[c];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tron_split_heads<P>(g, s);
+        int term, wm;
+        if (want_obs) {
+            const DualBoard64 bd{lds, gb};
+            tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
+        } else {
+            const Board64 bd{gb};
+            tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            heads[b * P + p] = s.h[p];
+            dirs[b * P + p] = s.d[p];
+            deaths[b * P + p] = s.k[p];
+            if (rewards) rewards[b * P + p] = rew[p];           // TronGridEnvironment.py:313,319-321
+        }
+        if (terminal) terminal[b] = (uint8_t)term;
+        if (winners) winners[b] = (uint8_t)wm;
+        if (want_obs) {
+#pragma unroll
+            for (int p = 0; p < P; ++p)                         // TronGridEnvironment.py:393-397: rolled so index 0 is the observer
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const int src = (i + p) % P;
+                    oh[(b * P + p) * P + i] = s.h[src];
+                    od[(b * P + p) * P + i] = s.d[src];
+                    ok[(b * P + p) * P + i] = s.k[src];
+                }
+        }
+    }
+    if (!want_obs) {                                            // (single-state call: completion behind thread 0's own stores)
+        if (flag && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < NN; c += 256) {
+        const int v = lds[c];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            obs_board[(b * P + p) * (int64_t)NN + c] = v > 0 ? (int64_t)((v - (p + 1) + P) % P + 1) : (int64_t)v;
+    }
+    if (flag) {                                                 // every thread's stores are out system-wide before the flag is
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// CyTronGrid.pyx:65-71 on int64 boards in place; `player` as the reference passes it (observer id + 1), one per game
+__global__ void __launch_bounds__(256)
+tron_relative_player64_kernel(const int64_t total, const int NN, int64_t *__restrict__ board, const int64_t num_players,
+                              const int64_t *__restrict__ player)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = board[i];
+        if (v > 0) board[i] = ((v - player[i / NN] + num_players) % num_players) + 1;    // C remainder, as cdivision=True
+    }
+}
+
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 inline TronGeom geom_of(const crl_tron_cfg &cfg)
@@ -3335,6 +3453,70 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
                            (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,
                            actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags);
     });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+static int tron_next_state64_launch(const char *fn, const crl_ctx *ctx, int64_t B, int64_t *board, int64_t *heads, int64_t *directions,
+                                    int64_t *deaths, const int64_t *actions, int64_t *rewards, uint8_t *terminal, uint8_t *winners,
+                                    int64_t *obs_board, int64_t *obs_heads, int64_t *obs_directions, int64_t *obs_deaths, void *stream,
+                                    const bool by_value, uint32_t *flag, const uint32_t seq)
+{
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TRON, "%s: ctx is not a tron context", fn);
+    CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 31), "%s: B=%lld out of range", fn, (long long)B);
+    CRL_REQUIRE(board && heads && directions && deaths && actions, "%s: NULL state / action pointer", fn);
+    CRL_REQUIRE(!obs_board == !obs_heads && !obs_board == !obs_directions && !obs_board == !obs_deaths,
+                "%s: the four observation pointers go together (all or none)", fn);
+    const crl_tron_cfg &cfg = ctx->tron;
+    const int NN = cfg.N * cfg.N;
+    CRL_REQUIRE(!obs_board || NN <= 60 * 1024, "%s: board too large for LDS", fn);
+    TronVec64 vec = {};
+    if (by_value)                                               // host-visible state (crl_host_alloc): read here, passed as arguments
+        for (int p = 0; p < cfg.P; ++p) {
+            vec.h[p] = (int32_t)heads[p]; vec.d[p] = (int32_t)directions[p]; vec.k[p] = (int32_t)deaths[p]; vec.a[p] = (int32_t)actions[p];
+        }
+    hipStream_t s = (hipStream_t)stream;
+    const TronGeom g = geom_of(cfg);
+    const size_t lds_bytes = obs_board ? (size_t)((NN + 15) & ~15) : 0;
+    TRON_DISPATCH_P(cfg.P, {
+        hipLaunchKernelGGL((tron_next_state64_kernel<PP>), dim3((unsigned)B), dim3(256), lds_bytes, s, g, B, board, heads,
+                           directions, deaths, actions, rewards, terminal, winners, obs_board, obs_heads, obs_directions, obs_deaths,
+                           vec, by_value, flag, seq);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
+int crl_tron_next_state_inplace64(const crl_ctx *ctx, int64_t B, int64_t *board, int64_t *heads, int64_t *directions,
+                                  int64_t *deaths, const int64_t *actions, int64_t *rewards, uint8_t *terminal, uint8_t *winners,
+                                  int64_t *obs_board, int64_t *obs_heads, int64_t *obs_directions, int64_t *obs_deaths, void *stream)
+{
+    return tron_next_state64_launch("crl_tron_next_state_inplace64", ctx, B, board, heads, directions, deaths, actions, rewards, terminal,
+                                    winners, obs_board, obs_heads, obs_directions, obs_deaths, stream, false, nullptr, 0u);
+}
+
+int crl_tron_next_state_inplace64_host(const crl_ctx *ctx, int64_t *board, int64_t *heads, int64_t *directions,
+                                       int64_t *deaths, const int64_t *actions, int64_t *rewards, uint8_t *terminal, uint8_t *winners,
+                                       int64_t *obs_board, int64_t *obs_heads, int64_t *obs_directions, int64_t *obs_deaths, void *stream,
+                                       uint32_t *flag, uint32_t seq, double timeout_s)
+{
+    CRL_REQUIRE(flag != nullptr, "crl_tron_next_state_inplace64_host: flag is NULL");
+    const int rc = tron_next_state64_launch("crl_tron_next_state_inplace64_host", ctx, 1, board, heads, directions, deaths, actions, rewards,
+                                            terminal, winners, obs_board, obs_heads, obs_directions, obs_deaths, stream, true, flag, seq);
+    if (rc != CRL_OK) return rc;
+    return crl_spin_mapped(stream, flag, seq, timeout_s, "crl_tron_next_state_inplace64_host");
+}
+
+int crl_tron_relative_player_inplace64(const crl_ctx *ctx, int64_t B, int64_t *board, int64_t num_players, const int64_t *player,
+                                       void *stream)
+{
+    TRON_CTX_CHECK("crl_tron_relative_player_inplace64");
+    CRL_REQUIRE(board && player, "crl_tron_relative_player_inplace64: NULL pointer");
+    CRL_REQUIRE(num_players > 0, "crl_tron_relative_player_inplace64: num_players=%lld (the reference divides by it)", (long long)num_players);
+    const int NN = ctx->tron.N * ctx->tron.N;
+    const int64_t total = B * (int64_t)NN;
+    hipLaunchKernelGGL(tron_relative_player64_kernel, dim3(std::min<unsigned>(blocks_for(total, 256), 8192u)), dim3(256), 0,
+                       (hipStream_t)stream, total, NN, board, num_players, player);
     CRL_LAUNCH_CHECK();
     return CRL_OK;
 }

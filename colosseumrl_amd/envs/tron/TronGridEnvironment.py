@@ -69,8 +69,9 @@ class TronGridEnvironment(BaseEnvironment):
         self._device = device
         self._stepper = None
         self._start_boards = {}                      # spawn layout -> start board (new_state)
-        self._observed = None                        # (state key, observations of all players) of the last next_state
-        self._staged = None                          # key of the state the staging block holds
+        self._observed = None                        # (value identity of the state, observations of all players) of the last next_state
+        self._obs_idle = 0                           # next_state calls since somebody last asked for an observation
+        self._staged = None                          # key of the state the int8 staging block holds (compute_ranking)
 
     def __repr__(self):
         return ("Tron Finite Grid Environment\n" + "=" * 50 + "\n"
@@ -158,23 +159,33 @@ class TronGridEnvironment(BaseEnvironment):
                 self._start_boards[key] = board
         return (board.copy(), heads, directions, np.zeros(self.num_players, dtype=np.int64)), self.player_array
 
+    OBS_IDLE_STEPS = 8    # next_state calls in a row whose fused observations nobody asked for before the launch stops writing them
+
     def next_state(self, state: object, players: List[int], actions: List[str]):
-        """One simultaneous move of every listed player (reference :265-323), evaluated on the GPU: one fused launch
-        (next_state + the observations of every player of the new state, which ``state_to_observation`` then serves
-        without another GPU call), no copies, one synchronise."""
+        """One simultaneous move of every listed player (reference :265-323), evaluated on the GPU through the Cython
+        module's own signature (``crl_tron_next_state_inplace64``: the reference's int64 arrays, stepped in place in
+        host-mapped memory -- no conversion of the state either way): the four arrays are copied where the GPU reads them
+        (the reference copies them too, :301-304), ONE launch steps them and writes rewards / terminal -- and, while
+        somebody consumes them, the observations of every player of the new state, which ``state_to_observation`` then
+        serves without another GPU call (a match loop asks for all P of them per tick, match_server.py:218) -- one wait."""
         for player, action in zip(players, actions):
             self._moves[player] = self.STRING_TO_ACTION[action]      # KeyError on an unknown string, like the reference
-        st = self._stage(state)
-        st.step_observe(self._moves)
-        new_state = st.state64()
-        v = st.v
-        self._staged = self._key(new_state)           # the staging block now holds the new state
-        self._observed = (self._staged, v["obs_board"].copy(), v["obs_heads"].copy(), v["obs_dirs"].copy(),
-                          v["obs_deaths"].copy())
-        new_players = np.where(new_state[3] == 0)[0]
-        rewards = v["rewards"].astype(np.int64)
-        term = np.bool_(bool(v["terminal"][0]))
-        return new_state, new_players, rewards, term, (new_players if term else None)
+        board, heads, directions, deaths = state
+        st = self._single()
+        fuse = self._obs_idle < self.OBS_IDLE_STEPS
+        st.next_state64(board, heads, directions, deaths, self._moves, fuse)
+        v = st.s64
+        new_board, new_heads = v["board"].copy(), v["heads"].copy()
+        new_directions, new_deaths = v["dirs"].copy(), v["deaths"].copy()
+        if fuse:
+            self._obs_idle += 1
+            self._observed = (v["all"].tobytes(), v["obs"].copy())   # value identity of the new state, its P observations
+        else:
+            self._observed = None
+        new_players = np.where(new_deaths == 0)[0]
+        rewards = v["rewards"].copy()
+        term = np.bool_(v["terminal"][0] != 0)
+        return (new_board, new_heads, new_directions, new_deaths), new_players, rewards, term, (new_players if term else None)
 
     def valid_actions(self, state: object, player: int) -> List[str]:
         return self.move_array                        # every move is always allowed (reference :325-341)
@@ -185,33 +196,30 @@ class TronGridEnvironment(BaseEnvironment):
     def state_to_observation(self, state: object, player: int) -> Dict[str, np.ndarray]:
         """Board relabelled so the observer is player 1; per-player vectors rolled (reference :363-420).  For the
         state the last ``next_state`` returned the observation is already there (the fused launch wrote it for
-        every player); any other state takes one ``crl_tron_observe`` call."""
+        every player); any other state takes one ``crl_tron_relative_player_inplace64`` call (the Cython function the
+        reference calls here, :390) and numpy's roll of the three vectors (:393-397)."""
         P, N = self.num_players, self.N
         NN = N * N
         seen = self._observed
-        # Any integer is an observer in the reference: the vectors roll by (arange + player) % P (:393) and the board goes
-        # through C's remainder (CyTronGrid.pyx:71, cdivision=True) -- up to player == P that is observer `player % P`,
-        # beyond P low trail ids come out <= 0; crl_tron_observe reproduces both.  int8 on the wire: fold the id into range
-        # without changing either result (2P + player % P keeps the sign of every v - (player + 1) + P and the class mod P).
-        player = int(player)
-        if player < 0:
-            player %= P
-        elif player >= 2 * P:
-            player = 2 * P + player % P
-        pl = player % P
-        if player <= P and seen is not None and seen[0] == self._key(state):
-            board = seen[1][pl * NN:(pl + 1) * NN].astype(np.int64).reshape(N, N)
-            heads = seen[2][pl * P:(pl + 1) * P].astype(np.int64)
-            directions = seen[3][pl * P:(pl + 1) * P].astype(np.int64)
-            deaths = seen[4][pl * P:(pl + 1) * P].astype(np.int64)
+        # Any integer is an observer in the reference: the vectors roll by (arange + player) % P with numpy's modulo (:393),
+        # the board goes through C's remainder (CyTronGrid.pyx:71, cdivision=True) -- for 0 <= player <= P both are
+        # observer `player % P`, which the fused launch of next_state has written; everything else takes the Cython
+        # function's own arithmetic on the GPU (crl_tron_relative_player_inplace64) and numpy's roll here.
+        try:
+            hit = seen is not None and 0 <= player <= P and seen[0] == b"".join(a.tobytes() for a in state)
+        except (AttributeError, TypeError):
+            hit = False
+        if hit:
+            self._obs_idle = 0
+            pl, ob = int(player) % P, seen[1]
+            board = ob[pl * NN:(pl + 1) * NN].reshape(N, N).copy()
+            o = P * NN + pl * P
+            heads, directions, deaths = ob[o:o + P].copy(), ob[o + P * P:o + P * P + P].copy(), ob[o + 2 * P * P:o + 2 * P * P + P].copy()
         else:
-            st = self._stage(state)
-            st.observe(player)
-            v = st.v
-            board = v["obs_board"][:NN].astype(np.int64).reshape(N, N)
-            heads = v["obs_heads"][:P].astype(np.int64)
-            directions = v["obs_dirs"][:P].astype(np.int64)
-            deaths = v["obs_deaths"][:P].astype(np.int64)
+            self._obs_idle = 0                         # somebody wants observations: the next next_state fuses them again
+            board = self._single().relative_board64(state[0], player + 1)
+            rolled_idx = (np.arange(P) + player) % P
+            heads, directions, deaths = state[1][rolled_idx], state[2][rolled_idx], state[3][rolled_idx]
         if self.fully_observable:
             return {"board": board, "heads": heads, "directions": directions, "deaths": deaths}
         # unfinished window branch of the reference (:407-420): no 'directions', python slice semantics

@@ -113,6 +113,24 @@ class ShardedRollout:
             launches += 1
         return launches
 
+    def wait(self):
+        """Block until this rank's queued rollout launches (and a collective issued behind them on the same stream) have
+        run: the stepper's stream-scoped wait on mapped memory (``TronBatch.wait`` & co., ``crl_stream_wait_mapped``) where
+        it has one, else a device synchronise."""
+        w = getattr(self.stepper, "wait", None)
+        if w is not None:
+            w()
+        elif torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+
+    def warm_collective(self, dst: Optional[int] = None, times: int = 3):
+        """SET-UP, not stepping: bring the communicator, its channels and the receive buffer up by running the rollout's one
+        collective `times` times on the rows as they are (RCCL creates the communicator lazily at the first collective, and
+        the second and third calls still pay first-use costs); a no-op without a process group."""
+        if self.dist:
+            for _ in range(int(times)):
+                self.gather(dst=dst, copy=False)
+
     def _local_rows(self, packed):
         st = self.stepper
         if packed is not False and hasattr(st, "results_packed") and (packed is True or st.packed_rows_exact()):

@@ -114,6 +114,7 @@ class SingleTron(_Single):
                            d["obs_heads"], d["obs_dirs"], d["obs_deaths"], s)
         self._a_rank = (h, 1, d["board"], d["deaths"], d["rank"], s)
         self._a_reset = (h, 1, None, d["board"], d["heads"], d["dirs"], d["deaths"], s)
+        self._open64()
 
     def load(self, board, heads, dirs, deaths):
         v = self.v
@@ -127,6 +128,66 @@ class SingleTron(_Single):
         v = self.v
         return (v["board"].astype(np.int64).reshape(self.N, self.N), v["heads"].astype(np.int64),
                 v["dirs"].astype(np.int64), v["deaths"].astype(np.int64))
+
+    # ---- the reference's own layout: int64 arrays, stepped in place (crl_tron_next_state_inplace64) ----------------
+    def _open64(self):
+        """A second mapped block in the REFERENCE's layout: `state` = board [N*N] | heads [P] | directions [P] | deaths [P]
+        as one run of int64 (so a state's value identity is one ``tobytes``), the actions, the outputs of the step and the
+        observations of all P players of the new state, also one run: P boards | P x P heads | directions | deaths."""
+        N, P, NN = self.N, self.P, self.NN
+        self.b64 = b = HostBlob(self._lib, [("state", np.int64, NN + 3 * P), ("actions", np.int64, P), ("rewards", np.int64, P),
+                                            ("obs", np.int64, P * NN + 3 * P * P), ("player", np.int64, 1),
+                                            ("terminal", np.uint8, 1), ("winners", np.uint8, 1)])
+        st, ob = b.v["state"], b.v["obs"]
+        self.s64 = {"all": st, "board": st[:NN].reshape(N, N), "heads": st[NN:NN + P], "dirs": st[NN + P:NN + 2 * P],
+                    "deaths": st[NN + 2 * P:], "actions": b.v["actions"], "rewards": b.v["rewards"], "obs": ob,
+                    "terminal": b.v["terminal"], "player": b.v["player"]}
+        base, obase = b.d["state"].value, b.d["obs"].value
+        at = lambda off: C.c_void_p(base + 8 * off)                                                   # noqa: E731
+        oat = lambda off: C.c_void_p(obase + 8 * off)                                                 # noqa: E731
+        state = (at(0), at(NN), at(NN + P), at(NN + 2 * P), b.d["actions"], b.d["rewards"], b.d["terminal"], b.d["winners"])
+        h, s = self._handle, self._stream
+        self._a_next64 = (h, 1) + state + (None, None, None, None, s)
+        self._a_next64_obs = (h, 1) + state + (oat(0), oat(P * NN), oat(P * NN + P * P), oat(P * NN + 2 * P * P), s)
+        self._a_rel64 = (h, 1, oat(0), P, b.d["player"], s)
+        # the one-call form (crl_tron_next_state_inplace64_host): only where the mapped blocks have ONE address for host and GPU
+        self._unified = (b.d["state"].value == st.ctypes.data and self._flag.d["seq"].value == self._flag.v["seq"].ctypes.data)
+        tail = (s, self._flag.d["seq"])
+        self._a_host64 = (h,) + state + (None, None, None, None) + tail
+        self._a_host64_obs = (h,) + state + (oat(0), oat(P * NN), oat(P * NN + P * P), oat(P * NN + 2 * P * P)) + tail
+
+    def next_state64(self, board, heads, dirs, deaths, actions, with_obs: bool):
+        """``CyTronGrid.next_state_inplace`` on the four int64 arrays (copied into the mapped block as the reference copies
+        them, TronGridEnvironment.py:301-304) + rewards / terminal; with `with_obs` also the observations of all P players
+        of the new state.  ONE launch, one wait; the results are the views in ``self.s64``."""
+        v = self.s64
+        np.copyto(v["board"], board, casting="unsafe")
+        np.copyto(v["heads"], heads, casting="unsafe")
+        np.copyto(v["dirs"], dirs, casting="unsafe")
+        np.copyto(v["deaths"], deaths, casting="unsafe")
+        np.copyto(v["actions"], actions, casting="unsafe")
+        if self._unified:                                        # launch + completion in one call, vectors by value
+            self._seq = seq = (self._seq + 1) & 0xFFFFFFFF or 1
+            rc = self._lib.crl_tron_next_state_inplace64_host(*(self._a_host64_obs if with_obs else self._a_host64), seq, self.WAIT_TIMEOUT_S)
+            if rc:
+                check(rc, "crl_tron_next_state_inplace64_host")
+            return
+        rc = self._lib.crl_tron_next_state_inplace64(*(self._a_next64_obs if with_obs else self._a_next64))
+        if rc:
+            check(rc, "crl_tron_next_state_inplace64")
+        self.sync()
+
+    def relative_board64(self, board, player_plus_1: int):
+        """``relative_player_inplace(copy of board, P, player_plus_1)`` (CyTronGrid.pyx:65-71): the relabelled int64 board."""
+        NN = self.NN
+        dst = self.s64["obs"][:NN].reshape(self.N, self.N)
+        np.copyto(dst, board, casting="unsafe")
+        self.s64["player"][0] = player_plus_1
+        rc = self._lib.crl_tron_relative_player_inplace64(*self._a_rel64)
+        if rc:
+            check(rc, "crl_tron_relative_player_inplace64")
+        self.sync()
+        return dst.copy()
 
     def step_observe(self, actions):
         """next_state + the observations of all P players, one launch (``crl_tron_step_observe``)."""

@@ -66,8 +66,8 @@ const char *crl_last_error(void);
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
  * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits.  108: crl_diag_bounds.
  * 109: crl_blokus_step / _step_observe place ANY action as the reference's next_state does (numpy index rules, extended ids,
- *      CRL_BLOKUS_*_ERROR codes in the reward slot). */
-#define CRL_ABI_VERSION 109
+ *      CRL_BLOKUS_*_ERROR codes in the reward slot).  110: crl_tron_next_state_inplace64 (+ _host) / _relative_player_inplace64. */
+#define CRL_ABI_VERSION 110
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -238,6 +238,42 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
                           int8_t *rewards, uint8_t *terminal, uint8_t *winners,
                           int8_t *obs_board, int16_t *obs_heads, int8_t *obs_dirs, int8_t *obs_deaths,
                           uint32_t flags, void *stream);
+
+/* The Cython module's OWN functions with their own types (the reference's only native boundary), for callers that hold
+ * reference states:
+ *   CyTronGrid.pyx:3-7   next_state_inplace(long[:, ::1] board, long[::1] heads, long[::1] directions, long[::1] deaths,
+ *                                           const long[::1] actions)
+ *   CyTronGrid.pyx:65    relative_player_inplace(long[:, ::1] board, const long num_players, const long player)
+ * int64, C-contiguous, the reference's layout (board [N][N]; heads / directions / deaths / actions [P]; actions in
+ * {0 forward, +1 right, -1 left}), MUTATED IN PLACE, caller owns every buffer, no error path for the contents (as there;
+ * directions + actions are taken mod 4 like crl_tron_step).  B games lie one behind the other ([B][N*N], [B][P]); the
+ * single-state drop-in class calls it with B = 1 on crl_host_alloc memory, so TronGridEnvironment.next_state neither
+ * converts its four arrays to the batched steppers' int8 / int16 struct-of-arrays nor back.  The step touches the board where the
+ * reference does: <= P probes, <= P trail stores.  Optional outputs (NULL to skip), what TronGridEnvironment.next_state
+ * computes around the call (TronGridEnvironment.py:309-321): rewards int64 [B][P] (-1 dead, +1 alive, +10 surviving
+ * winner), terminal uint8 [B], winners uint8 [B] (bitmask of the alive players if terminal, else 0).  Optional
+ * observations of the NEW state for all P observers (all four pointers or none; TronGridEnvironment.py:385-405):
+ * obs_board int64 [B][P][N*N] (relative_player_inplace of a copy with player = p + 1), obs_heads / obs_directions /
+ * obs_deaths int64 [B][P][P] (rolled so index 0 is the observer). */
+int crl_tron_next_state_inplace64(const crl_ctx *ctx, int64_t B, int64_t *board, int64_t *heads, int64_t *directions,
+                                  int64_t *deaths, const int64_t *actions, int64_t *rewards, uint8_t *terminal, uint8_t *winners,
+                                  int64_t *obs_board, int64_t *obs_heads, int64_t *obs_directions, int64_t *obs_deaths, void *stream);
+/* The single-state form of the call above, ONE BLOCKING call for a caller whose state lies in crl_host_alloc memory (B = 1;
+ * every pointer is such memory, which host and GPU address alike under ROCm's unified addressing -- a binding checks that
+ * crl_host_alloc returned equal host / device addresses before it uses this entry): launch + completion.  Because the host can
+ * read the state, the player vectors (heads, directions, deaths, actions) travel BY VALUE in the kernel arguments -- the
+ * kernel's first data access is then the board probe, one PCIe round trip instead of two -- and the kernel publishes
+ * completion itself: `seq` into *flag (a 32-bit word of crl_host_alloc memory; a fresh value per call) behind its last
+ * store, on which the host spins (timeout_s and the fallback as crl_stream_wait_mapped).  No signal kernel, one call through
+ * the binding instead of two.  Results as above, visible when the call returns. */
+int crl_tron_next_state_inplace64_host(const crl_ctx *ctx, int64_t *board, int64_t *heads, int64_t *directions,
+                                       int64_t *deaths, const int64_t *actions, int64_t *rewards, uint8_t *terminal, uint8_t *winners,
+                                       int64_t *obs_board, int64_t *obs_heads, int64_t *obs_directions, int64_t *obs_deaths, void *stream,
+                                       uint32_t *flag, uint32_t seq, double timeout_s);
+/* board[b][i][j] > 0  ->  ((board - player[b] + num_players) % num_players) + 1 with C's remainder (cdivision=True), in place;
+ * player int64 [B] as the reference passes it (TronGridEnvironment.py:390: the observer's id + 1). */
+int crl_tron_relative_player_inplace64(const crl_ctx *ctx, int64_t B, int64_t *board, int64_t num_players, const int64_t *player,
+                                       void *stream);
 
 /* replaces TronGridEnvironment.compute_ranking (TronGridEnvironment.py:483-508) for B games:
  * rank int8 [P][B], 0 = best; trail-length scores, the mutual-kill tie rule (with its deaths[-1] read for

@@ -40,7 +40,10 @@ def _canned_full():
             "launch_ms_source": long, "bytes_per_env_step": 99.23, "formula": long, "physical_achieved": 3661.123456,
             "physical_frac": 0.457640432, "copy_peak": 5100.123456, "frac_of_copy": 0.71784321, "note": long,
             "valu_issue": {"achieved": 5.43e11, "peak": 1.08e12, "unit": "wave-instr/s", "frac": 0.50277777, "peak_source": long,
-                           "waves_per_simd": 4, "peak_at_occupancy": 1.0e12, "frac_at_occupancy": 0.543},
+                           "waves_per_simd": 4, "peak_at_occupancy": 1.0e12, "frac_at_occupancy": 0.543, "mix": "tron",
+                           "peak_of_mix": 6.44123e11, "frac_of_mix": 0.8712345},
+            "traffic_over_algorithmic": 0.5081234, "valu_frac_of_mix": 0.5512345, "steady_valu_frac_of_mix": 0.8712345, "steady_bound": "issue",
+            "oc_games": 1048576, "oc_launch_ms": 0.2101234, "oc_frac": 0.98765432, "oc_physical_frac": 0.5123456, "oc_step_observe_frac": 0.7123456,
             "steady_value": 2.136e11, "steady_launch_ms": 2.5131234, "steady_frac": 2.53123, "steady_physical_frac": 0.00328123,
             "steady_valu_frac": 0.516123, "box_clock_mhz": 2391.3, "box_issue_vs_calibration": 0.98765432,
             "box_clock_mhz_warm": 2377.7, "box_issue_vs_calibration_warm": 1.0123456}
@@ -64,7 +67,14 @@ def _canned_full():
         "config": {"workload": WL, "games_per_gpu": 65536, "global_games": 65536, "steps_per_launch": 20, "launches": 1,
                    "agent": "uniform random (Philox-4x32-10), auto-reset", "mean_episode_len": 8.452, "episodes": 193841,
                    "parallelism": "dp1", "gather": "rccl gather to rank 0 (torch.distributed.gather), 16-byte rows",
+                   "completion": "ShardedRollout.wait (crl_stream_wait_mapped on the launch stream)",
+                   "cpu_baseline": "not run at N > 1 (rank 0 at N = 1 only)",
                    "device_warmup": "none: `value` is the first W + K region of the process"},
+        "collective": {"gather_us": 27.12345, "all_gather_us": 31.12345, "region_no_gather_us": 36.12345, "region_gather_us": 63.12345,
+                       "region_all_gather_us": 67.12345, "value_without_gather": 2.9012345e11, "row_bytes": 16, "rows_bytes_per_rank": 1048576,
+                       "rows_bytes_into_rank0": 7340032, "rank_spread_us": 3.12, "elapsed_ranks_us": [61.12, 62.23, 63.34, 60.45, 61.56, 62.67, 63.78, 60.89],
+                       "what": long},
+        "gather_us": 27.12345, "value_without_gather": 2.9012345e11,
         "timed_region_ms": 0.03489123, "kernel_ms": 0.0282123, "kernel_ms_dispatch": 0.01756123, "kernel_ms_source": long,
         "roofline": roof, "warmed": {"value": 4.228e10, "timed_region_us": 31.0123, "device_warmup_ms": 91.2, "what": long},
         "value_warmed": 4.228e10,
@@ -93,6 +103,11 @@ def test_compact_line_is_small_and_carries_roofline_and_cpu_baseline(tmp_path):
     assert rec["roofline"]["frac"] == pytest.approx(0.90139, rel=1e-4)
     assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["peak"] == 8000.0 and rec["roofline"]["traffic"] == 66123456
     assert rec["roofline"]["achieved"] / rec["roofline"]["peak"] == pytest.approx(rec["roofline"]["frac"], rel=1e-3)
+    assert rec["roofline"]["traffic_over_algorithmic"] == pytest.approx(0.50812, rel=1e-4) and rec["roofline"]["valu_frac_of_mix"] == pytest.approx(0.55123, rel=1e-4)
+    assert rec["roofline"]["steady_bound"] == "issue" and rec["roofline"]["oc_games"] == 1048576 and rec["roofline"]["oc_physical_frac"] > 0
+    assert rec["gather_us"] == pytest.approx(27.123, rel=1e-4) and rec["value_without_gather"] == pytest.approx(2.9012e11, rel=1e-4)
+    assert rec["collective"]["all_gather_us"] > 0 and len(rec["collective"]["elapsed_ranks_us"]) == 8 and rec["collective"]["rows_bytes_into_rank0"] == 7340032
+    assert "crl_stream_wait_mapped" in rec["config"]["completion"]
     assert rec["cpu_baseline"]["value"] == pytest.approx(2.6012e8, rel=1e-3) and rec["cpu_baseline"]["kind"] == "port"
     assert rec["cpu_baseline"]["value"] >= rec["cpu_baseline"]["threads_16"]
     assert rec["value"] == pytest.approx(full["value"], rel=1e-5)
@@ -187,11 +202,14 @@ def _world2(rank, world, port, batch, out_dir):
         both = [torch.zeros_like(elapsed) for _ in range(world)]
         dist.all_gather(both, elapsed)
         assert both[0].item() == both[1].item()                     # every rank holds the same (max) time
+        coll = bench.collective_attribution(pl, sr, 20, 0, 8192, reps=4)         # every rank, as in main()
         if rank == 0:
             rows = meas["rows"]
             assert rows.dtype == torch.int16 and rows.shape == (world * batch, 8)     # the 16-bit rows, int32-viewed on the wire
             full = bench.contract_record(WL, batch, world, 20, 5, 8192, meas, launch_s=meas["elapsed"], launch_source="test",
                                          copy_gbs=None, gather_desc="gloo gather to rank 0, %d-byte rows" % (rows.shape[1] * 2))
+            bench.attach_collective(full, coll, rows.shape[1] * 2, batch, world, 20)
+            full["config"]["completion"] = pl.completion()
             out = io.StringIO()
             bench.emit(full, out=out, detail_paths=[os.path.join(out_dir, "detail.json")])
             with open(os.path.join(out_dir, "stdout.txt"), "w") as f:
@@ -224,3 +242,11 @@ def test_contract_region_and_line_in_a_world_of_two(tmp_path):
     assert rec["config"]["episodes"] == n_ep and rec["config"]["mean_episode_len"] == pytest.approx(len_sum / n_ep, abs=1e-3)
     assert n_ep <= 2 * batch * 25 / 2                                # W + K = 25 steps; no Tron episode is shorter than 2 steps
     assert rec["roofline"]["frac"] > 0 and rec["roofline"]["traffic"] is not None
+    # the N > 1 record is attributable: the collective's cost in this world, the value without it, every rank's time
+    c = rec["collective"]
+    assert rec["gather_us"] == c["gather_us"] and c["region_gather_us"] - c["region_no_gather_us"] == pytest.approx(c["gather_us"], abs=0.02)
+    assert c["all_gather_us"] == pytest.approx(c["region_all_gather_us"] - c["region_no_gather_us"], abs=0.02)
+    assert rec["value_without_gather"] == pytest.approx(2 * batch * 20 / (c["region_no_gather_us"] * 1e-6), rel=1e-3)
+    assert c["row_bytes"] == 16 and c["rows_bytes_into_rank0"] == 16 * batch and len(c["elapsed_ranks_us"]) == 2
+    assert c["rank_spread_us"] == pytest.approx(max(c["elapsed_ranks_us"]) - min(c["elapsed_ranks_us"]), abs=0.02)
+    assert rec["config"]["completion"] == "none (cpu)"

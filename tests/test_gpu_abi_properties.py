@@ -185,6 +185,42 @@ def test_observe_with_out_of_range_player_ids():
         assert np.array_equal(got[k].cpu().numpy().reshape(want.shape), want), k
 
 
+def test_wait_on_mapped_memory_ends_the_queued_work():
+    """`wait()` of the batched steppers (crl_stream_wait_mapped on the launch stream): when it returns, everything queued
+    before it has run.  Checked on DATA, without any synchronise: an asynchronous copy of the result rows into pinned host
+    memory is queued behind the rollout, and when `wait()` returns the host buffer holds the rows a twin produced that
+    synchronised.  (Event / stream queries are no witness: the runtime learns of a completion only when it looks.)"""
+    import torch
+    from colosseumrl_amd.batched import BlokusBatch, TronBatch, TTTBatch
+    from colosseumrl_amd.parallel import ShardedRollout
+    for make, T in ((lambda: TronBatch(20, 4, 65536), 20), (lambda: TronBatch(20, 4, 65536), 3000), (lambda: TTTBatch((3, 5), 3, 3, 4096), 64),
+                    (lambda: BlokusBatch(256), 40)):
+        a, b = make(), make()
+        host = torch.zeros_like(a.results(), device="cpu").pin_memory()
+        torch.cuda.synchronize()
+        for i in range(3):
+            b.rollout(T, 9)
+            torch.cuda.synchronize()
+            want = b.results().cpu()
+            host.fill_(-1)
+            a.rollout(T, 9)
+            host.copy_(a.results(copy=False), non_blocking=True)
+            a.wait()
+            assert torch.equal(host, want), (T, i)                # no synchronise in between: the wait covered launch and copy
+    side = torch.cuda.Stream()                                    # the wait follows torch's CURRENT stream
+    sr = ShardedRollout(lambda batch, first_env_id: TronBatch(20, 4, batch, first_env_id=first_env_id), 8192)
+    twin = TronBatch(20, 4, 8192)
+    twin.rollout(500, 1)
+    torch.cuda.synchronize()
+    want = twin.results().cpu()
+    host = torch.zeros_like(want).pin_memory()
+    with torch.cuda.stream(side):
+        sr.rollout(500, 1, 250)
+        host.copy_(sr.stepper.results(copy=False), non_blocking=True)
+        sr.wait()
+        assert torch.equal(host, want)
+
+
 @pytest.mark.parametrize("N,P,T,kernel", [(20, 4, 20, "auto"), (20, 4, 16383 + 40, "auto"), (40, 4, 64, "auto"), (12, 6, 50, "auto"),
                                          (20, 4, 30, "global")])
 def test_rollout_with_events_attached_to_the_dispatches(N, P, T, kernel):

@@ -104,7 +104,10 @@ def test_bench_driver_style_line(run_fresh):
     assert abs(rec["config"]["mean_episode_len"] - 8.45) < 0.1
     assert rec["value"] == pytest.approx(65536 * 20 / (rec["ms_per_step"] * 20 * 1e-3), rel=1e-4) and rec["value"] > 1e9
     r = rec["roofline"]
-    assert r["bound"] == "hbm" and r["kernel"] == "tron_rollout_quad_kernel" and 0.3 < r["frac"] < 1.2
+    assert r["kernel"] == "tron_rollout_quad_kernel" and 0.3 < r["frac"] < 1.2
+    # the bound names the nearer roof: physical HBM traffic / time against 8 TB/s, or VALU instructions / time against the mix's peak
+    assert r["bound"] == ("hbm" if r["physical_frac"] >= r["valu_frac_of_mix"] else "issue") and 0.3 < r["traffic_over_algorithmic"] < 0.8
+    assert "crl_stream_wait_mapped" in rec["config"]["completion"]
     assert r["achieved"] == pytest.approx(r["bytes_per_env_step"] * 65536 * 20 / (r["launch_ms"] * 1e-3) / 1e9, rel=1e-3)
     assert 300 < r["box_clock_mhz"] < 4000 and 0.1 < r["box_issue_vs_calibration"] < 1.5        # the box's own issue probe
     assert "RCCL" not in err and "NCCL version" not in err      # the contract run creates no process group
@@ -121,6 +124,12 @@ def test_bench_self_launch_runs_ranks_under_rccl(run_fresh):
     rec = _one_json_line(out)
     assert rec["n_gpus"] == 1 and rec["config"]["gather"].startswith("rccl") and rec["config"]["parallelism"] == "dp1"
     assert "torch.distributed.run" in err
+    # a record with a process group is attributable: what the collective costs here, the value without it, each rank's time
+    c = rec["collective"]
+    assert rec["gather_us"] == c["gather_us"] and 0 < c["gather_us"] < 200 and 0 < c["all_gather_us"] < 200
+    assert c["region_gather_us"] > c["region_no_gather_us"] > 10 and len(c["elapsed_ranks_us"]) == 1 and c["row_bytes"] == 16
+    assert rec["value_without_gather"] == pytest.approx(65536 * 20 / (c["region_no_gather_us"] * 1e-6), rel=1e-3)
+    assert rec["config"]["completion"] == "torch.cuda.synchronize"
 
 
 def test_bench_gpus_2_on_a_one_gpu_box_fails(run_fresh):

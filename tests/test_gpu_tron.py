@@ -48,6 +48,149 @@ def test_observe_golden(golden, name):
     assert np.array_equal(od, g["obs_dirs"].T) and np.array_equal(ok, g["obs_deaths"].T)
 
 
+# ---- the Cython module's own signature: int64 arrays in the reference's layout, in place (ABI 110) ----------------
+class Inplace64:
+    """B games in the reference's layout on the device: board int64 [B][N*N], heads / directions / deaths [B][P]."""
+
+    def __init__(self, N, P, B):
+        import ctypes as C
+        import torch
+        from colosseumrl_amd import _native
+        self.C, self.torch, self.lib, self.N, self.P, self.B = C, torch, _native.require_gpu(), N, P, B
+        self.h = C.c_void_p()
+        sh, sd = (C.c_int16 * P)(*range(P)), (C.c_int8 * P)(*([0] * P))
+        _native.check(self.lib.crl_tron_create(N, P, sh, sd, C.byref(self.h)), "crl_tron_create")
+        z = lambda *shape, dt=torch.int64: torch.zeros(shape, dtype=dt, device="cuda")     # noqa: E731
+        self.board, self.heads, self.dirs, self.deaths = z(B, N * N), z(B, P), z(B, P), z(B, P)
+        self.rewards, self.terminal, self.winners = z(B, P), z(B, dt=torch.uint8), z(B, dt=torch.uint8)
+        self.ob, self.oh, self.od, self.ok = z(B, P, N * N), z(B, P, P), z(B, P, P), z(B, P, P)
+
+    def __del__(self):
+        self.lib.crl_destroy(self.h)
+
+    def set_state(self, board, heads, dirs, deaths):       # [B][NN], [B][P] numpy
+        for dst, src in ((self.board, board), (self.heads, heads), (self.dirs, dirs), (self.deaths, deaths)):
+            dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src).astype(np.int64)))
+
+    def step(self, actions, obs):
+        from colosseumrl_amd import _native
+        p = lambda t: self.C.c_void_p(t.data_ptr())                                        # noqa: E731
+        a = self.torch.from_numpy(np.ascontiguousarray(actions).astype(np.int64)).cuda()
+        o = [p(self.ob), p(self.oh), p(self.od), p(self.ok)] if obs else [None] * 4
+        _native.check(self.lib.crl_tron_next_state_inplace64(self.h, self.B, p(self.board), p(self.heads), p(self.dirs), p(self.deaths),
+                                                             p(a), p(self.rewards), p(self.terminal), p(self.winners), *o, None),
+                      "crl_tron_next_state_inplace64")
+        self.torch.cuda.synchronize()
+
+    def relative(self, board, num_players, player):
+        from colosseumrl_amd import _native
+        b = self.torch.from_numpy(np.ascontiguousarray(board).astype(np.int64)).cuda()
+        pl = self.torch.from_numpy(np.ascontiguousarray(player).astype(np.int64)).cuda()
+        _native.check(self.lib.crl_tron_relative_player_inplace64(self.h, b.shape[0], self.C.c_void_p(b.data_ptr()), num_players,
+                                                                  self.C.c_void_p(pl.data_ptr()), None), "crl_tron_relative_player_inplace64")
+        return b.cpu().numpy()
+
+    def np(self, *names):
+        return [getattr(self, n).cpu().numpy() for n in names]
+
+
+@pytest.mark.parametrize("obs", [False, True])
+def test_next_state_inplace64_edge_cases_golden(golden, obs):
+    """The reference's order-dependence cases (SURVEY T2-order i-iv, stale heads, walls) through the Cython signature."""
+    g = golden("tron_edge")
+    N, P, E = int(g["N"]), int(g["P"]), len(g["names"])
+    be = Inplace64(N, P, E)
+    be.set_state(g["pre_board"], g["pre_heads"], g["pre_dirs"], g["pre_deaths"])
+    be.step(g["actions"], obs)
+    board, heads, dirs, deaths, rew, term, win = be.np("board", "heads", "dirs", "deaths", "rewards", "terminal", "winners")
+    assert np.array_equal(board, g["post_board"]) and np.array_equal(heads, g["post_heads"]) and np.array_equal(dirs, g["post_dirs"])
+    assert np.array_equal(deaths, g["post_deaths"]) and np.array_equal(rew, g["rewards"])
+    assert np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
+
+
+@pytest.mark.parametrize("N,P,B,T", [(20, 4, 300, 40), (40, 4, 64, 60), (19, 3, 77, 40), (9, 8, 130, 30), (5, 2, 100, 20)])
+def test_next_state_inplace64_vs_oracle_random(N, P, B, T):
+    """Seeded random play: the int64 in-place entry (with and without the fused observations) against the oracle's step
+    and observe on the same states; terminal games are reset on both sides."""
+    rng = np.random.default_rng(N * 77 + P)
+    sh, sd = O.tron_start_positions(N, P)
+    orc = OracleTron(N, P, B, sh, sd)
+    be = Inplace64(N, P, B)
+    for t in range(T):
+        s = orc.state()
+        be.set_state(s["board"], s["heads"].T, s["dirs"].T, s["deaths"].T)
+        a = rng.integers(-1, 2, size=(P, B)).astype(np.int8)
+        obs = (t % 2) == 0
+        be.step(a.T, obs)
+        r, term, w = orc.step(a)
+        s = orc.state()
+        board, heads, dirs, deaths, rew, tm, wn = be.np("board", "heads", "dirs", "deaths", "rewards", "terminal", "winners")
+        assert np.array_equal(board, s["board"]) and np.array_equal(heads, s["heads"].T) and np.array_equal(dirs, s["dirs"].T), t
+        assert np.array_equal(deaths, s["deaths"].T) and np.array_equal(rew, r.T) and np.array_equal(tm, term) and np.array_equal(wn, w), t
+        if obs:
+            ob, oh, od, ok = be.np("ob", "oh", "od", "ok")
+            for p in range(P):
+                eb, eh, ed, ek = orc.observe(np.full(B, p, np.int8))
+                assert np.array_equal(ob[:, p], eb) and np.array_equal(oh[:, p], eh.T), (t, p)
+                assert np.array_equal(od[:, p], ed.T) and np.array_equal(ok[:, p], ek.T), (t, p)
+        orc.reset(term.astype(bool))
+
+
+@pytest.mark.parametrize("N,P", [(20, 4), (19, 3), (9, 8), (40, 4)])
+def test_next_state_inplace64_host_single_state_call(N, P):
+    """The one-call single-state form on crl_host_alloc memory (player vectors by value, completion published by the kernel)
+    against the two-call form (launch + crl_stream_wait_mapped) and the oracle, with and without fused observations."""
+    from colosseumrl_amd.single import SingleTron
+    rng = np.random.default_rng(N + P)
+    sh, sd = O.tron_start_positions(N, P)
+    orc = OracleTron(N, P, 1, sh, sd)
+    one, two = SingleTron(N, P, sh, sd), SingleTron(N, P, sh, sd)
+    assert one._unified                                          # ROCm's unified addressing: mapped memory has one address
+    two._unified = False
+    for t in range(300):
+        s = orc.state()
+        state = (s["board"].reshape(N, N).astype(np.int64), s["heads"][:, 0].astype(np.int64), s["dirs"][:, 0].astype(np.int64),
+                 s["deaths"][:, 0].astype(np.int64))
+        a = rng.integers(-1, 2, size=(P, 1)).astype(np.int8)
+        obs = (t % 3) != 0
+        for st in (one, two):
+            st.s64["obs"][:] = -7
+            st.next_state64(*state, a[:, 0].astype(np.int64), obs)
+        r, term, w = orc.step(a)
+        s = orc.state()
+        for st in (one, two):
+            v = st.s64
+            assert np.array_equal(v["board"].reshape(-1), s["board"][0]) and np.array_equal(v["heads"], s["heads"][:, 0]), t
+            assert np.array_equal(v["dirs"], s["dirs"][:, 0]) and np.array_equal(v["deaths"], s["deaths"][:, 0]), t
+            assert np.array_equal(v["rewards"], r[:, 0]) and int(v["terminal"][0]) == int(term[0]), t
+        assert np.array_equal(one.s64["obs"], two.s64["obs"]) and (obs == bool((one.s64["obs"] != -7).any())), t
+        if obs:
+            NN = N * N
+            for p in range(P):
+                eb, eh, ed, ek = orc.observe(np.full(1, p, np.int8))
+                assert np.array_equal(one.s64["obs"][p * NN:(p + 1) * NN], eb[0]), (t, p)
+                o = P * NN + p * P
+                assert np.array_equal(one.s64["obs"][o:o + P], eh[:, 0]) and np.array_equal(one.s64["obs"][o + P * P:o + P * P + P], ed[:, 0]), (t, p)
+                assert np.array_equal(one.s64["obs"][o + 2 * P * P:o + 2 * P * P + P], ek[:, 0]), (t, p)
+        orc.reset(term.astype(bool))
+
+
+@pytest.mark.parametrize("name", ["n20p4", "n9p6", "wrap_n20p4", "wrap_n9p6"])
+def test_relative_player_inplace64_golden(golden, name):
+    """CyTronGrid.relative_player_inplace with its own arguments (player = observer id + 1, any integer) against the
+    reference's boards, incl. the observer ids outside 0..P-1."""
+    g = golden("tron_observe_" + name)
+    N, P = int(g["N"]), int(g["P"])
+    be = Inplace64(N, P, 1)
+    got = be.relative(g["board"], P, g["player"].astype(np.int64) + 1)
+    assert np.array_equal(got, g["obs_board"])
+    wild = np.array([-(1 << 40) + 3, (1 << 40) + 1, -7, 0][: len(g["player"])], np.int64)   # far outside int8: C remainder on int64
+    b = g["board"][: len(wild)].astype(np.int64)
+    got = be.relative(b, P, wild)
+    want = np.where(b > 0, np.fmod(b - wild[:, None] + P, P) + 1, b)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("N,P,B,T", [(20, 4, 4096 + 37, 40), (40, 4, 1000, 60), (19, 3, 777, 40), (9, 8, 513, 30), (5, 2, 300, 20)])
 def test_step_vs_oracle_random(N, P, B, T):
     """Seeded random actions, ragged batch sizes (not a multiple of the wave), odd boards (byte reset path)."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box (via gpurun): rocprofv3 kernel trace + PMC passes for a SET of bench workloads, one call.
 #   gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh r3 tron_n20_t20 tron_n20 tron_n40 blokus step_api'
-# <round prefix> then any of: tron_n20_t20 (the driver's 20-step launch) tron_n20 tron_n40 ttt_5x5 ttt_3x5 ttt_3x3x3 blokus step_api
+# <round prefix> then any of: tron_n20_t20 (the driver's 20-step launch) tron_n20 tron_n40 ttt_5x5 ttt_3x5 ttt_3x3x3 blokus step_api out_of_cache
 # Leaves gpurun_out/prof_<prefix>_<name>/summary.{txt,json}; back in the build container `tools/collect_profiles.py`
 # copies them into profiles/ (see profiles/README.md).  A pass that fails or times out ends the script (no further GPU step).
 set -uo pipefail
@@ -19,6 +19,7 @@ for NAME in "$@"; do
     ttt_3x3x3)    ARGS="--workload ttt_p4_3x3x3_b262144 --steps 8192 --warmup 2048" ;;
     blokus)       ARGS="--workload blokus_p4_b16384 --steps 4096 --warmup 2048" ;;
     step_api)     ARGS="--only-step-api" ;;
+    out_of_cache) ARGS="--only-out-of-cache" ;;     # Tron 20x20 at 1,048,576 games (436 MB of state > the 256 MiB Infinity Cache)
     *) echo "unknown profile set $NAME"; exit 2 ;;
   esac
   timeout -k 10 420 bash tools/profile_bench.sh ${PFX}_$NAME $ARGS > gpurun_out/prof_${PFX}_$NAME.log 2>&1

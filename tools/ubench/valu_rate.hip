@@ -5,12 +5,21 @@
 //   mix "tron"  : the instruction mix of the Tron rollout loop per PMC (profiles/r1_tron_n20: 175 VALU : 30 SALU : 16 LDS
 //                 per wave-step): per block 11 VALU (2 of them v_cmp -> SGPR pair, 2 v_cndmask reading one), 2 SALU
 //                 (s_and_b64 / s_or_b64 on lane masks) and 1 ds_read_u8, the LDS result consumed at the block's end.
+//   mix "ttt"   : the TicTacToe rollout ply per PMC (profiles/r4_ttt_5x5: 58 VALU : 6 SALU : 1 LDS per wave-ply; 7.8 % of the
+//                 5x5 rollout kernel's VALU instructions are full-width 32-bit multiplies -- Philox rounds, the mulhi draws --,
+//                 which issue at half the rate): per block 53 plain VALU + 5 multiplies + 6 SALU + 1 ds_read_b32;
+//   mix "blokus": the Blokus rollout ply per PMC (profiles/r4_blokus: 438 VALU : 261 SALU : 99 LDS per wave-ply): per block
+//                 22 VALU (2 v_cmp -> SGPR pair, 2 v_cndmask, 2 v_bcnt among them), 13 SALU (lane-mask logic, s_bcnt1,
+//                 address arithmetic) and 5 ds_read_b64 consumed at the block's end.
+// bench.py prices a kernel's PMC VALU rate against the rate of ITS mix at ITS occupancy (`valu_frac_of_mix`) next to the
+// pure-integer peak (`valu_frac`): with the scalar unit, the LDS and quarter-rate multiplies in the stream, the pure peak
+// is not reachable by that instruction stream whatever the schedule.
 // The shader clock is measured in the kernel (s_memtime ticks per s_memrealtime tick x 100 MHz), so the result is
 // quoted both as wave-instructions per second (what bench.py divides by) and as cycles per instruction per SIMD.
 // Everything is inline asm so the compiler can neither fuse nor drop instructions.
 //
 // Build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
-// Prints one JSON object (committed as profiles/r2_valu_issue_calibration.json).
+// Prints one JSON object (committed as profiles/r<round>_issue_calibration.json; bench.py reads the newest).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -119,6 +128,94 @@ __global__ void __launch_bounds__(256) tron_mix_kernel(uint32_t *out, uint64_t *
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// TicTacToe ply mix: 53 plain VALU on 8 independent chains (2 of them consume the LDS word), 5 full-width multiplies
+// (2 v_mul_hi_u32 + v_mul_lo_u32 pairs and one v_mul_lo_u32: the static share of the 5x5 rollout kernel's code, 7.8 % of its
+// VALU instructions), 6 SALU, 1 LDS dword read -- see the header.
+__global__ void __launch_bounds__(256) ttt_mix_kernel(uint32_t *out, uint64_t *clk, int iters)
+{
+    __shared__ uint32_t table[256 * 3];
+    for (int j = 0; j < 3; ++j) table[threadIdx.x * 3 + j] = threadIdx.x + j;
+    __syncthreads();
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 | 1u, a7 = a0 + 9, l0 = 0;
+    uint32_t m0 = a0 | 1u, m1 = a0 + 11, m2 = a0 + 13, h0 = 0, h1 = 0;
+    const uint32_t c = blockIdx.x | 1u;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2;
+    uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)table + threadIdx.x * 12;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(
+            ".rept 4\n"
+            "ds_read_b32 %8, %18\n"                                                       // 1 LDS (table lookup)
+            ".rept 3\n"                                                                   // 48 plain VALU, 8 independent chains
+            "v_add_u32 %0, %0, %17\n v_xor_b32 %1, %1, %17\n v_add_u32 %2, %2, %17\n v_xor_b32 %3, %3, %17\n"
+            "v_add_u32 %4, %4, %17\n v_xor_b32 %5, %5, %17\n v_add_u32 %6, %6, %17\n v_xor_b32 %7, %7, %17\n"
+            "v_lshlrev_b32 %0, 1, %0\n v_and_b32 %1, %1, %17\n v_lshrrev_b32 %2, 1, %2\n v_or_b32 %3, %3, %17\n"
+            "v_xor_b32 %4, %4, %17\n v_add_u32 %5, %5, %17\n v_xor_b32 %6, %6, %17\n v_add_u32 %7, %7, %17\n"
+            ".endr\n"
+            "v_mul_hi_u32 %12, %9, %17\n v_mul_lo_u32 %9, %9, %17\n"                       // 5 full-width multiplies ...
+            "s_add_u32 %14, %14, %19\n s_xor_b32 %15, %15, %19\n s_lshl_b32 %16, %16, 1\n" // ... 6 SALU between them
+            "v_mul_hi_u32 %13, %10, %17\n v_mul_lo_u32 %10, %10, %17\n"
+            "s_add_u32 %15, %15, %19\n s_xor_b32 %14, %14, %19\n s_or_b32 %16, %16, %19\n"
+            "v_mul_lo_u32 %11, %11, %17\n"
+            "v_add_u32 %0, %0, %12\n v_xor_b32 %1, %1, %13\n v_add_u32 %2, %2, %17\n"      // 3 more plain VALU
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_xor_b32 %3, %3, %8\n v_bcnt_u32_b32 %4, %8, %4\n"                           // 2 VALU consuming the table word
+            ".endr\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(l0), "+v"(m0), "+v"(m1), "+v"(m2),
+              "+v"(h0), "+v"(h1), "+s"(s0), "+s"(s1), "+s"(s2)
+            : "v"(c), "v"(addr), "s"(c) : "scc", "memory");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ l0 ^ m0 ^ m1 ^ m2 ^ h0 ^ h1 ^ s0 ^ s1 ^ s2;
+}
+
+// Blokus ply mix: 22 VALU (2 v_cmp -> SGPR pair, 2 v_cndmask, 2 v_bcnt), 13 SALU, 5 ds_read_b64 -- see the header.
+__global__ void __launch_bounds__(256) blokus_mix_kernel(uint32_t *out, uint64_t *clk, int iters)
+{
+    __shared__ uint64_t rows[256 * 5 + 8];
+    for (int j = 0; j < 5; ++j) rows[threadIdx.x * 5 + j] = threadIdx.x * 0x9E3779B97F4A7C15ull + j;
+    __syncthreads();
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5;
+    const uint32_t c = blockIdx.x | 1u;
+    uint32_t s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
+    uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint64_t *)rows + threadIdx.x * 40;
+    uint64_t t0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int i = 0; i < iters; ++i) {
+        asm volatile(
+            ".rept 4\n"
+            "ds_read_b64 v[40:41], %12\n ds_read_b64 v[42:43], %12 offset:8\n ds_read_b64 v[44:45], %12 offset:16\n"   // 5 LDS
+            "ds_read_b64 v[46:47], %12 offset:24\n ds_read_b64 v[48:49], %12 offset:32\n"   // (fixed registers: the low halves are consumed below)
+            "v_add_u32 %0, %0, %10\n v_xor_b32 %1, %1, %10\n s_add_u32 %6, %6, %11\n"
+            "v_lshlrev_b32 %2, 1, %2\n v_and_b32 %3, %3, %0\n s_xor_b32 %7, %7, %11\n"
+            "v_or_b32 %4, %4, %1\n v_add_u32 %5, %5, %10\n s_lshl_b32 %8, %8, 1\n"
+            "v_cmp_eq_u32 s[20:21], %0, %1\n s_bcnt1_i32_b64 %9, s[20:21]\n"
+            "v_cmp_lt_u32 s[22:23], %2, %4\n s_and_b64 s[20:21], s[20:21], s[22:23]\n"
+            "v_xor_b32 %2, %2, %10\n v_lshrrev_b32 %3, 1, %3\n s_or_b64 s[22:23], s[22:23], exec\n"
+            "v_cndmask_b32 %5, %5, %0, s[20:21]\n s_add_u32 %6, %6, %9\n"
+            "v_cndmask_b32 %4, %4, %1, s[22:23]\n s_xor_b32 %7, %7, %11\n"
+            "v_add_u32 %0, %0, %2\n v_xor_b32 %1, %1, %3\n s_add_u32 %8, %8, %11\n"
+            "v_and_b32 %2, %2, %4\n v_or_b32 %3, %3, %5\n s_lshr_b32 %9, %9, 1\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_and_b32 %0, %0, v40\n v_bcnt_u32_b32 %1, v42, %1\n s_or_b32 %6, %6, %11\n"       // consume the five rows
+            "v_xor_b32 %2, %2, v44\n v_bcnt_u32_b32 %3, v46, %3\n s_xor_b32 %8, %8, %7\n"
+            "v_or_b32 %4, %4, v48\n s_and_b32 %7, %7, %6\n v_add_u32 %5, %5, %10\n"
+            ".endr\n"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
+            : "v"(c), "s"(c), "v"(addr)
+            : "s20", "s21", "s22", "s23", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime() - t0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ s0 ^ s1 ^ s2 ^ s3;
+}
+
 // Scalar issue rate (round 3: the Blokus rollout issues 408 SALU next to 529 VALU instructions per wave-step -- is the
 // scalar unit a bound?).  `with_valu` = 0: 64 independent s_add_u32 / s_xor_b32 per iteration on 8 chains;
 // 1: the same 64 SALU interleaved one to one with 64 independent VALU instructions (do the two pipes issue side by side?).
@@ -170,8 +267,8 @@ int main()
     const int iters = 40000;
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"note\": \"wave64 instructions per second, whole chip; "
            "cycles = shader cycles per instruction per SIMD at the in-kernel clock\", \"mixes\": {", prop.gcnArchName, cus, cus * 4);
-    for (int mix = 0; mix < 7; ++mix) {
-        static const char *const names[7] = {"valu", "tron", "valu_half_exec", "mul_lo_hi_pairs", "mad_u64_u32", "salu", "salu_valu_1to1"};
+    for (int mix = 0; mix < 9; ++mix) {
+        static const char *const names[9] = {"valu", "tron", "valu_half_exec", "mul_lo_hi_pairs", "mad_u64_u32", "salu", "salu_valu_1to1", "ttt", "blokus"};
         printf("%s\"%s\": [", mix ? ", " : "", names[mix]);
         for (int wps = 1; wps <= 8; wps *= 2) {
             const int blocks = cus * wps;                          // wps blocks of 4 waves per CU = wps waves per SIMD
@@ -179,7 +276,9 @@ int main()
             CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; ++rep) {                    // rep 0 warms up (clock ramp), rep 1 is timed
                 CHECK(hipEventRecord(e0));
-                if (mix >= 5) hipLaunchKernelGGL(salu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 6);
+                if (mix == 7) hipLaunchKernelGGL(ttt_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 4);
+                else if (mix == 8) hipLaunchKernelGGL(blokus_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 2);
+                else if (mix >= 5) hipLaunchKernelGGL(salu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 6);
                 else if (mix >= 3) hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters / 4, mix == 4);
                 else if (mix != 1) hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters, mix == 2);
                 else hipLaunchKernelGGL(tron_mix_kernel, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
@@ -193,9 +292,10 @@ int main()
             const double ghz = (double)h[0] / (double)h[1] * 0.1;
             // (mul mixes: iters / 4 iterations of 64 multiplies, or of 32 v_mad_u64_u32 = the same 32 full products)
             // (salu mixes: 64 SALU per iteration, plus 64 VALU in the 1:1 mix; "valu" columns then count the VALU part only)
-            const double valu_per_wave = mix == 5 ? 0.0 : mix == 6 ? (double)iters * 64 : mix >= 3 ? (double)(iters / 4) * (mix == 4 ? 32 : 64)
+            // (ttt: iters / 4 iterations of 4 blocks of 58 VALU + 6 SALU + 1 LDS; blokus: iters / 2 iterations of 4 blocks of 22 + 13 + 5)
+            const double valu_per_wave = mix == 7 ? (double)(iters / 4) * 4 * 58 : mix == 8 ? (double)(iters / 2) * 4 * 22 : mix == 5 ? 0.0 : mix == 6 ? (double)iters * 64 : mix >= 3 ? (double)(iters / 4) * (mix == 4 ? 32 : 64)
                                                   : (double)iters * (mix == 1 ? kBlocksPerIter * 11 : kValuPerIter);
-            const double all_per_wave = mix == 5 ? (double)iters * 64 : mix == 6 ? (double)iters * 128 : mix >= 3 ? valu_per_wave
+            const double all_per_wave = mix == 7 ? (double)(iters / 4) * 4 * 65 : mix == 8 ? (double)(iters / 2) * 4 * 40 : mix == 5 ? (double)iters * 64 : mix == 6 ? (double)iters * 128 : mix >= 3 ? valu_per_wave
                                                   : (double)iters * (mix == 1 ? kBlocksPerIter * 14 : kValuPerIter);
             const double waves = (double)blocks * 4;
             const double s = ms * 1e-3;
