@@ -17,6 +17,8 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
 CRL_ABI_VERSION = 110
 CRL_STEP_AUTO_RESET = 1
+CRL_STEP_BYTES = 2
+CRL_STEP_STAGED = 4
 CRL_ROLLOUT_NO_LDS = 2
 CRL_ROLLOUT_BYTES = 4
 CRL_ROLLOUT_BITS = 8

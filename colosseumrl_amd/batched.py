@@ -39,6 +39,9 @@ _ROLLOUT_KERNEL_FLAGS = {"auto": 0, "bits": _native.CRL_ROLLOUT_BITS, "bytes": _
                          "qbits": _native.CRL_ROLLOUT_QBITS}
 
 
+_STEP_KERNEL_FLAGS = {"auto": 0, "bytes": _native.CRL_STEP_BYTES, "staged": _native.CRL_STEP_STAGED}
+
+
 class _DevGuard:
     """``torch.cuda.device(dev)`` only when `dev` is not already current (the context manager costs several
     microseconds per call, which is visible next to a 20-step rollout launch)."""
@@ -175,12 +178,15 @@ class TronBatch(_Waitable):
         self._stat_steps = 0
 
     # -- next_state for all games; actions int8 [P, B] in {0, +1, -1}
-    def step(self, actions: torch.Tensor, auto_reset: bool = False):
+    def step(self, actions: torch.Tensor, auto_reset: bool = False, kernel: str = "auto"):
+        """next_state of every game (``crl_tron_step``).  ``kernel``: "auto", or pin one of the two interchangeable kernels --
+        "bytes" (byte probes in HBM) / "staged" (boards read once into LDS; ignored where the board shape does not allow it)."""
         _want(actions, torch.int8, (self.P, self.B), self.device, "actions")
+        flags = (CRL_STEP_AUTO_RESET if auto_reset else 0) | _STEP_KERNEL_FLAGS[kernel]
         with torch.cuda.device(self.device):
             check(self._lib.crl_tron_step(self._ctx.handle, self.B, _ptr(self.board), _ptr(self.heads), _ptr(self.dirs),
                                           _ptr(self.deaths), _ptr(actions), _ptr(self.rewards), _ptr(self.terminal),
-                                          _ptr(self.winners), CRL_STEP_AUTO_RESET if auto_reset else 0, _stream()),
+                                          _ptr(self.winners), flags, _stream()),
                   "crl_tron_step")
         return self.rewards, self.terminal, self.winners
 

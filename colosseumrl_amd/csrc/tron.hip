@@ -30,6 +30,9 @@
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
 #include <hip/hip_ext.h>
+#ifndef CRL_STEP_DEFAULT_STAGED
+#define CRL_STEP_DEFAULT_STAGED 0      // crl_tron_step's default kernel: 0 = byte probes, 1 = boards staged through LDS (A/B: profiles/r5_step_ab.json)
+#endif
 #include <type_traits>
 #include <algorithm>
 
@@ -2833,6 +2836,89 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
     }
 }
 
+// crl_tron_step through LDS: the workgroup reads its G boards ONCE, coalesced 16-byte loads (phase A of the fused kernel
+// above), one lane per game plays the step on the LDS copy and mirrors the <= P trail bytes to HBM, and the boards of the
+// games that were reset are rewritten by all threads.  Against tron_step_kernel's byte probes (each a 64-byte sector, ~10x
+// the algorithmic bytes: profiles/traffic_step_api.json) this streams N*N bytes per game in and probes for free.
+template <int P, int G>
+__global__ void __launch_bounds__(256)
+tron_step_staged_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t inv_cp, const int64_t B,
+                        int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                        int8_t *__restrict__ deaths, const int8_t *__restrict__ actions,
+                        int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                        const uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int NN = g.NN, SLAB = NN + 16;                        // NN % 16 == 0: 16-byte LDS accesses stay aligned
+    const int cp = NN >> 4;                                     // 16-byte chunks per board
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);
+    const int total = n_game * cp;
+    uint8_t *rflag = lds + G * SLAB;                            // [G] this game was reset by the step
+    __shared__ int any_reset;
+    if (threadIdx.x == 0) any_reset = 0;
+    // the stepping lanes' player vectors: in flight together with the board loads
+    TronRegs<P> s;
+    int act[P], rew[P];
+    const int e = threadIdx.x;
+    const bool stepper = e < G, valid = stepper && e < n_game;
+    const int64_t b = g0 + (valid ? e : 0);
+    if (stepper) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = valid ? heads[p * B + b] : 0;
+            s.d[p] = valid ? dirs[p * B + b] : 0;
+            s.k[p] = valid ? deaths[p * B + b] : 1;
+            act[p] = valid ? actions[p * B + b] : 0;
+        }
+    }
+    for (int base = threadIdx.x; base < total; base += 4 * 256) {
+        uint4 v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * 256;
+            const int cc = c < total ? c : 0;
+            const int ee = cp == 1 ? cc : (int)__umulhi((uint32_t)cc, inv_cp);
+            const int off = (cc - ee * cp) << 4;
+            dst[u] = c < total ? ee * SLAB + off : -1;
+            v[u] = *reinterpret_cast<const uint4 *>(board + (g0 + ee) * NN + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<uint4 *>(lds + dst[u]) = v[u];
+    }
+    __syncthreads();
+    if (stepper) {
+        tron_split_heads<P>(g, s);
+        int term, wm;
+        const DualBoard bd{lds + e * SLAB, board + b * NN};
+        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
+        rflag[e] = do_reset ? 1 : 0;
+        if (do_reset) { tron_regs_to_start<P>(cfg, g, s); any_reset = 1; }
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                rewards[p * B + b] = (int8_t)rew[p];
+                heads[p * B + b] = (int16_t)s.h[p];
+                dirs[p * B + b] = (int8_t)s.d[p];
+                deaths[p * B + b] = (int8_t)s.k[p];
+            }
+            terminal[b] = (uint8_t)term;
+            winners[b] = (uint8_t)wm;
+        }
+    }
+    if (!(flags & CRL_STEP_AUTO_RESET)) return;                 // (uniform)
+    __syncthreads();
+    if (!any_reset) return;                                     // (uniform: read after the barrier)
+    for (int c = threadIdx.x; c < total; c += 256) {            // new_state: the fresh board replaces the finished one
+        const int ee = cp == 1 ? c : (int)__umulhi((uint32_t)c, inv_cp);
+        const int off = (c - ee * cp) << 4;
+        if (rflag[ee]) *reinterpret_cast<uint4 *>(board + (g0 + ee) * NN + off) = tron_fresh_chunk16<P>(cfg, off);
+    }
+}
+
 // The same fused call for every shape the kernel above cannot take (N*N % 16 != 0 -- the reference's default 19x19 board
 // among them --, P = 8, boards too large for 16 slabs of LDS): ONE GAME PER WORKGROUP, byte granularity throughout.  The
 // board goes into LDS with coalesced byte loads, thread 0 plays the step there (mirroring the <= P trail bytes to HBM),
@@ -3151,15 +3237,37 @@ int crl_tron_step(const crl_ctx *ctx, int64_t B,
     TRON_CTX_CHECK("crl_tron_step");
     CRL_REQUIRE(board && heads && dirs && deaths, "crl_tron_step: NULL state pointer");
     CRL_REQUIRE(actions && rewards && terminal && winners, "crl_tron_step: NULL action/output pointer");
-    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_tron_step: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_STEP_AUTO_RESET | CRL_STEP_BYTES | CRL_STEP_STAGED)) == 0, "crl_tron_step: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     CRL_REQUIRE(!(flags & CRL_STEP_AUTO_RESET) || ((cfg.N * cfg.N) % 16 != 0) || (((uintptr_t)board & 15) == 0),
                 "crl_tron_step: board must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const TronGeom g = geom_of(cfg);
+    // Boards of whole 16-byte chunks that fit 64 (or 16) to a workgroup's LDS go through tron_step_staged_kernel (one coalesced
+    // read of every board); everything else, or flags & CRL_STEP_BYTES, through the byte probes of tron_step_kernel.  Identical
+    // results (tests run both); CRL_STEP_STAGED pins the LDS kernel where the shape allows it.
+    const int NN = cfg.N * cfg.N, slab = NN + 16;
+    const int G = (64 * slab + 64 <= 48 * 1024) ? 64 : (16 * slab + 16 <= 48 * 1024) ? 16 : 0;
+    const bool can_stage = (NN % 16) == 0 && G > 0 && (((uintptr_t)board & 15) == 0);
+    const bool staged = can_stage && !(flags & CRL_STEP_BYTES) && (CRL_STEP_DEFAULT_STAGED || (flags & CRL_STEP_STAGED));
+    const uint32_t kflags = flags & CRL_STEP_AUTO_RESET;
+    if (staged) {
+        const uint32_t inv_cp = NN == 16 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;
+        const size_t lds_bytes = (size_t)G * slab + G;
+        TRON_DISPATCH_P(cfg.P, {
+            if (G == 64)
+                hipLaunchKernelGGL((tron_step_staged_kernel<PP, 64>), dim3(blocks_for(B, 64)), dim3(256), lds_bytes, s, cfg, g, inv_cp, B,
+                                   board, heads, dirs, deaths, actions, rewards, terminal, winners, kflags);
+            else
+                hipLaunchKernelGGL((tron_step_staged_kernel<PP, 16>), dim3(blocks_for(B, 16)), dim3(256), lds_bytes, s, cfg, g, inv_cp, B,
+                                   board, heads, dirs, deaths, actions, rewards, terminal, winners, kflags);
+        });
+        CRL_LAUNCH_CHECK();
+        return CRL_OK;
+    }
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_step_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, g, B,
-                           board, heads, dirs, deaths, actions, rewards, terminal, winners, flags);
+                           board, heads, dirs, deaths, actions, rewards, terminal, winners, kflags);
     });
     CRL_LAUNCH_CHECK();
     return CRL_OK;

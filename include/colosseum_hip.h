@@ -48,6 +48,9 @@ extern "C" {
 
 /* flags for *_step */
 #define CRL_STEP_AUTO_RESET 1u  /* after writing the step outputs, reset every env that just became terminal */
+/* crl_tron_step only: pin one of its two interchangeable kernels (identical results; the default is the faster one) */
+#define CRL_STEP_BYTES      2u  /* byte probes in HBM, one lane per game, nothing staged */
+#define CRL_STEP_STAGED     4u  /* boards read once, coalesced, into LDS (boards of whole 16-byte chunks that fit; else ignored) */
 /* flags for crl_tron_rollout */
 #define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
 #define CRL_ROLLOUT_BYTES   4u  /* force the lane-per-game byte-per-cell LDS kernel */

@@ -72,8 +72,10 @@ class HipTron:
         self.tb.dirs.copy_(self._dev(dirs, t.int8))
         self.tb.deaths.copy_(self._dev(deaths, t.int8))
 
+    step_kernel = "auto"            # "bytes" / "staged" pin one of crl_tron_step's two interchangeable kernels
+
     def step(self, actions, auto_reset=False):
-        r, t, w = self.tb.step(self._dev(actions, self.torch.int8), auto_reset=auto_reset)
+        r, t, w = self.tb.step(self._dev(actions, self.torch.int8), auto_reset=auto_reset, kernel=self.step_kernel)
         return r.cpu().numpy(), t.cpu().numpy(), w.cpu().numpy()
 
     def state(self):

@@ -11,21 +11,32 @@ from replay import replay_tron, replay_tron_fused_reset
 TRAJ = ["n20p4", "n40p4", "n20p2", "n21p3", "n20p6", "n7p5", "n20p4_noreset", "n9p8_noreset"]
 
 
+class HipTronStaged(HipTron):
+    step_kernel = "staged"
+
+
+class HipTronBytes(HipTron):
+    step_kernel = "bytes"
+
+
+@pytest.mark.parametrize("backend", [HipTronBytes, HipTronStaged], ids=["bytes", "staged"])
 @pytest.mark.parametrize("name", TRAJ)
-def test_traj_golden(golden, name):
-    assert replay_tron(golden("tron_traj_" + name), HipTron) > 0
+def test_traj_golden(golden, name, backend):
+    assert replay_tron(golden("tron_traj_" + name), backend) > 0
 
 
+@pytest.mark.parametrize("backend", [HipTronBytes, HipTronStaged], ids=["bytes", "staged"])
 @pytest.mark.parametrize("name", ["n20p4", "n40p4", "n7p5", "n21p3"])
-def test_traj_golden_fused_reset(golden, name):
-    replay_tron_fused_reset(golden("tron_traj_" + name), HipTron)
+def test_traj_golden_fused_reset(golden, name, backend):
+    replay_tron_fused_reset(golden("tron_traj_" + name), backend)
 
 
-def test_edge_cases_golden(golden):
+@pytest.mark.parametrize("backend", [HipTronBytes, HipTronStaged], ids=["bytes", "staged"])
+def test_edge_cases_golden(golden, backend):
     g = golden("tron_edge")
     N, P = int(g["N"]), int(g["P"])
     E = len(g["names"])
-    be = HipTron(N, P, E, [0, 1, 2], [0, 0, 0])
+    be = backend(N, P, E, [0, 1, 2], [0, 0, 0])
     be.set_state(g["pre_board"], g["pre_heads"].T, g["pre_dirs"].T, g["pre_deaths"].T)
     rew, term, win = be.step(np.ascontiguousarray(g["actions"].T))
     s = be.state()
@@ -191,12 +202,17 @@ def test_relative_player_inplace64_golden(golden, name):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("N,P,B,T", [(20, 4, 4096 + 37, 40), (40, 4, 1000, 60), (19, 3, 777, 40), (9, 8, 513, 30), (5, 2, 300, 20)])
-def test_step_vs_oracle_random(N, P, B, T):
-    """Seeded random actions, ragged batch sizes (not a multiple of the wave), odd boards (byte reset path)."""
+@pytest.mark.parametrize("kernel", ["bytes", "staged"])
+@pytest.mark.parametrize("N,P,B,T", [(20, 4, 4096 + 37, 40), (40, 4, 1000, 60), (19, 3, 777, 40), (9, 8, 513, 30), (5, 2, 300, 20), (12, 6, 63, 40),
+                                     (4, 2, 200, 12), (100, 4, 70, 30)])
+def test_step_vs_oracle_random(N, P, B, T, kernel):
+    """Seeded random actions, ragged batch sizes (not a multiple of the wave or of a workgroup's 64 / 16 games), odd boards
+    (byte reset path), on both interchangeable kernels of crl_tron_step (byte probes / boards staged through LDS; boards that
+    are not whole 16-byte chunks or do not fit LDS take the byte kernel under either pin)."""
     rng = np.random.default_rng(N * 1000 + P)
     sh, sd = O.tron_start_positions(N, P)
     hip, orc = HipTron(N, P, B, sh, sd), OracleTron(N, P, B, sh, sd)
+    hip.step_kernel = kernel
     for t in range(T):
         a = rng.integers(-1, 2, size=(P, B)).astype(np.int8)
         auto = (t % 3) != 2

@@ -55,6 +55,8 @@ GPU_RUNS = [
     (["tools/kernel_ab.py", "20", "64"], "quad"),
     (["tools/debug/dropin_stress.py", "3", "1500"], "0 errors"),
     (["tools/debug/host_latency.py"], "region raw"),
+    (["tools/debug/step_ab.py", "quick"], "staged_over_bytes"),
+    (["tools/debug/dropin_breakdown.py", "200"], "env_next_state"),
     (["examples/dropin_game.py", "tron", "1"], "ranking"),
     (["examples/dropin_game.py", "blokus", "2"], "ranking"),
     (["examples/dropin_game.py", "tictactoe_4p", "3"], "ranking"),
