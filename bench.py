@@ -633,8 +633,6 @@ def out_of_cache(torch, device, seed, steps=20):
         tb.rollout(steps, seed, events=(e0, e1))
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e-3)
-        if i % 4 == 3:
-            tb.reset_stats()
     launch_s = sorted(ts)[len(ts) // 2]
     mean_len = mean_episode_len(tb.results(copy=False))[0]
     alg = algorithmic_bytes_per_step("tron", dict(num_players=P, board_size=N), mean_len) * B * steps

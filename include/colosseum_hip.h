@@ -88,6 +88,11 @@ void crl_destroy(crl_ctx *ctx);
 int crl_host_alloc(size_t bytes, void **host, void **device);
 int crl_host_free(void *host);
 int crl_stream_create(void **stream);
+/* Only for streams crl_stream_create returned, and only once NOTHING else refers to them: a stream that was handed to another
+ * runtime object (e.g. wrapped as torch.cuda.ExternalStream, or with events / graphs of another library recorded on it) stays
+ * referenced there, and destroying it under that object crashes the process at ITS next use of the handle, not inside this
+ * library (seen in round 4: a segmentation fault at interpreter exit).  Let the other owner go first, or give it a stream it
+ * owns itself and pass THAT stream's handle to the crl_* calls instead. */
 int crl_stream_destroy(void *stream);
 /* the blocking calls of the ABI besides create / destroy: */
 int crl_stream_synchronize(void *stream);
