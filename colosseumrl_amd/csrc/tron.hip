@@ -30,6 +30,33 @@
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
 #include <hip/hip_ext.h>
+// Observation boards are written once and not read again by the kernel that writes them; whether their 16-byte stores should
+// be NONTEMPORAL depends on where they land (round-5 A/B on one box, tools/debug/stream_ab.py -> profiles/r5_stream_ab.txt;
+// Tron 20x20 P4, GPU us per call, plain / nontemporal):
+//   games                    65,536        131,072       262,144        524,288        1,048,576
+//   crl_tron_step_observe    23.1 / 25.9   51.0 / 47.4   120.8 / 88.9   244.4 / 168.4  480-558 / 415-472
+//   crl_tron_observe_all     21.7 / 20.6   43.7 / 38.9    98.1 / 79.0   191.9 / 149.8  385-391 / 397-448
+// observe_all: nontemporal always.  step_observe: nontemporal once the call's boards in + out (131 MB at 65,536 games,
+// where plain stores are absorbed by the 256 MiB Infinity Cache) exceed 192 MiB.  CRL_NT_STREAM=0 / 1 (A/B builds) forces
+// one form everywhere.
+typedef uint32_t crl_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void crl_stream_store16(void *ptr, const uint4 v, const bool nt)
+{
+    if (nt) __builtin_nontemporal_store(crl_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<crl_u32x4 *>(ptr));
+    else *reinterpret_cast<uint4 *>(ptr) = v;
+}
+constexpr int64_t kStreamNtBytes = (int64_t)192 << 20;
+inline bool crl_stream_nt(const int64_t bytes_per_call, const bool small_default)
+{
+#ifdef CRL_NT_STREAM
+    return CRL_NT_STREAM != 0;
+#else
+    return bytes_per_call > kStreamNtBytes ? true : small_default;
+#endif
+}
+#ifndef CRL_SO_HOIST
+#define CRL_SO_HOIST 1                 // tron_step_observe_kernel: the stepping lanes' player vectors are loaded ahead of the board staging (A/B switch)
+#endif
 #ifndef CRL_STEP_DEFAULT_STAGED
 #define CRL_STEP_DEFAULT_STAGED 0      // crl_tron_step's default kernel: 0 = byte probes, 1 = boards staged through LDS (A/B: profiles/r5_step_ab.json)
 #endif
@@ -2620,7 +2647,7 @@ tron_ranking_wide_kernel(const int NN, const uint32_t inv_cp, const int64_t B, c
 // board bytes (values 0..7) are its selector.  Pure streaming: N*N bytes in, P*N*N bytes out per game.
 template <int P>
 __global__ void __launch_bounds__(256)
-tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs)
+tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs, const bool nt)
 {
     const int64_t total = B * (int64_t)NN;
     const bool wide = (NN & 15) == 0;
@@ -2665,7 +2692,7 @@ tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict_
                     }
                     o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
                 }
-                *reinterpret_cast<uint4 *>(obs + (int64_t)p * total + off) = o;
+                crl_stream_store16(obs + (int64_t)p * total + off, o, nt);
             }
         } else {
             const int c = board[i];
@@ -2717,6 +2744,8 @@ struct DualBoard {                  // step on the LDS copy, mirror the trail wr
     __device__ __forceinline__ void put(const int c, const int who) const { l[c] = (uint8_t)who; g[c] = (int8_t)who; }
 };
 
+constexpr uint32_t kStepObserveNT = 0x80000000u;            // kernel-side flag bit next to CRL_STEP_AUTO_RESET
+
 template <int P, int G>
 __global__ void __launch_bounds__(256)
 tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t inv_cp, const int64_t B,
@@ -2735,6 +2764,26 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
     const int n_game = (int)((B - g0) < G ? (B - g0) : G);
     const int total = n_game * cp;
     uint8_t *rflag = lds + G * SLAB;                            // [G] this game was reset by the step
+    const bool nt = (flags & kStepObserveNT) != 0;              // nontemporal observation stores (see crl_stream_nt)
+    // the stepping lanes' player vectors (and step counter): issued FIRST, in flight together with the board loads of
+    // phase A instead of a second round of memory latency behind the barrier (round 5: -4 % out of cache)
+    const int e = threadIdx.x;
+    const bool stepper = e < G, valid = stepper && e < n_game;
+    const int64_t b = g0 + (valid ? e : 0);
+    TronRegs<P> s;
+    int act[P], rew[P];
+    uint32_t c_in = 0u;
+    auto load_players = [&]() {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = valid ? heads[p * B + b] : 0;
+            s.d[p] = valid ? dirs[p * B + b] : 0;
+            s.k[p] = valid ? deaths[p * B + b] : 1;
+            act[p] = (valid && actions) ? actions[p * B + b] : 0;
+        }
+        if (!actions) c_in = valid ? tcount[b] : 0u;
+    };
+    if (CRL_SO_HOIST && stepper) load_players();
     // ---- phase A: boards HBM -> LDS, coalesced 16-byte loads, up to 4 in flight per thread
     for (int base = threadIdx.x; base < total; base += 4 * 256) {
         uint4 v[4];
@@ -2743,10 +2792,10 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
         for (int u = 0; u < 4; ++u) {
             const int c = base + u * 256;
             const int cc = c < total ? c : 0;
-            const int e = cp == 1 ? cc : (int)__umulhi((uint32_t)cc, inv_cp);
-            const int off = (cc - e * cp) << 4;
-            dst[u] = c < total ? e * SLAB + off : -1;
-            v[u] = *reinterpret_cast<const uint4 *>(board + (g0 + e) * NN + off);
+            const int ee = cp == 1 ? cc : (int)__umulhi((uint32_t)cc, inv_cp);
+            const int off = (cc - ee * cp) << 4;
+            dst[u] = c < total ? ee * SLAB + off : -1;
+            v[u] = *reinterpret_cast<const uint4 *>(board + (g0 + ee) * NN + off);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -2754,23 +2803,11 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
     }
     __syncthreads();
     // ---- phase B: one lane per game plays the step on its LDS board
-    if (threadIdx.x < G) {
-        const int e = threadIdx.x;
-        const bool valid = e < n_game;
-        const int64_t b = g0 + (valid ? e : 0);
-        TronRegs<P> s;
-        int act[P], rew[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            s.h[p] = valid ? heads[p * B + b] : 0;
-            s.d[p] = valid ? dirs[p * B + b] : 0;
-            s.k[p] = valid ? deaths[p * B + b] : 1;
-            act[p] = (valid && actions) ? actions[p * B + b] : 0;
-        }
+    if (stepper) {
+        if (!CRL_SO_HOIST) load_players();
         if (!actions) {                                         // the rollout's random agent at this game's step counter
-            const uint32_t c = valid ? tcount[b] : 0u;
-            tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c, seed_lo, seed_hi, act);
-            if (valid) tcount[b] = c + 1u;
+            tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c_in, seed_lo, seed_hi, act);
+            if (valid) tcount[b] = c_in + 1u;
         }
         tron_split_heads<P>(g, s);
         int term, wm;
@@ -2831,7 +2868,7 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
             o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
             o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
             o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
-            *reinterpret_cast<uint4 *>(obs_board + (int64_t)p * plane + gofs) = o;
+            crl_stream_store16(obs_board + (int64_t)p * plane + gofs, o, nt);
         }
     }
 }
@@ -3499,7 +3536,8 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
     const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
     const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     TRON_DISPATCH_P(cfg.P, {
-        hipLaunchKernelGGL((tron_observe_all_kernel<PP>), dim3(grid), dim3(256), 0, s, NN, B, board, obs_board);
+        hipLaunchKernelGGL((tron_observe_all_kernel<PP>), dim3(grid), dim3(256), 0, s, NN, B, board, obs_board,
+                           crl_stream_nt((int64_t)(PP + 1) * NN * B, true));
         hipLaunchKernelGGL((tron_observe_all_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, obs_heads, obs_dirs, obs_deaths);
     });
@@ -3534,17 +3572,18 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
         const uint32_t inv_cp = NN == 16 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;
         const size_t lds_bytes = (size_t)G * slab + G;
         const dim3 grid(blocks_for(B, G));
+        const uint32_t kflags = flags | (crl_stream_nt((int64_t)(cfg.P + 1) * NN * B, false) ? kStepObserveNT : 0u);
         switch (cfg.P) {
 #define CRL_SO_CASE(P_)                                                                                                   \
         case P_:                                                                                                          \
             if (G == 64)                                                                                                  \
                 hipLaunchKernelGGL((tron_step_observe_kernel<P_, 64>), grid, dim3(256), lds_bytes, s, cfg, g, inv_cp, B,   \
                                    (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,     \
-                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags); \
+                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
             else                                                                                                          \
                 hipLaunchKernelGGL((tron_step_observe_kernel<P_, 16>), grid, dim3(256), lds_bytes, s, cfg, g, inv_cp, B,   \
                                    (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,     \
-                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, flags); \
+                                   actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
             break;
             CRL_SO_CASE(1) CRL_SO_CASE(2) CRL_SO_CASE(3) CRL_SO_CASE(4) CRL_SO_CASE(5) CRL_SO_CASE(6) CRL_SO_CASE(7)
 #undef CRL_SO_CASE
