@@ -401,18 +401,19 @@ class Plumbing:
             self.torch.cuda.synchronize()
 
     def complete(self, sr):
-        """End of this rank's timed work.  Without a process group everything was queued on ONE stream, and the product's own
-        stream-scoped wait ends the region (`ShardedRollout.wait` -> `TronBatch.wait` -> crl_stream_wait_mapped: the host
-        spins on a word in mapped memory that a one-thread kernel behind the launches publishes; ~3.5 us cheaper than a
-        device synchronise -- the same call a user of the batched steppers makes).  With a process group the collective
-        runs on the communicator's own stream: device synchronise, as the contract says."""
-        if self.cuda and not self.use_dist and hasattr(sr, "wait"):
+        """End of this rank's timed work: the product's own stream-scoped wait (`ShardedRollout.wait` -> `TronBatch.wait` ->
+        crl_stream_wait_mapped: the host spins on a word in mapped memory that a one-thread kernel behind the queued work
+        publishes; ~3.5 us cheaper than a device synchronise -- the same call a user of the batched steppers makes).  The
+        same at every world size: a synchronous torch.distributed collective makes the launch stream wait for the
+        communicator's stream, so the signal kernel behind it runs after the rows have arrived
+        (tests/test_gpu_rccl.py checks that on data).  CRL_BENCH_SYNC=device falls back to torch.cuda.synchronize()."""
+        if self.cuda and hasattr(sr, "wait") and os.environ.get("CRL_BENCH_SYNC") != "device":
             sr.wait()
         else:
             self.sync()
 
     def completion(self):
-        return ("ShardedRollout.wait (crl_stream_wait_mapped on the launch stream)" if self.cuda and not self.use_dist
+        return ("ShardedRollout.wait (crl_stream_wait_mapped on the launch stream)" if self.cuda and os.environ.get("CRL_BENCH_SYNC") != "device"
                 else "torch.cuda.synchronize" if self.cuda else "none (cpu)")
 
     def barrier(self):

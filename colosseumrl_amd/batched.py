@@ -96,13 +96,22 @@ class _Waitable:
     WAIT_TIMEOUT_S = 30.0            # after this long without the flag the call falls back to hipStreamSynchronize (and its error)
     _wait_flag = None
 
+    def _open_wait(self):
+        """Construction-time set-up of the completion channel: the flag word in mapped memory (a hipHostMalloc: ~1.3 ms, and the
+        launches right behind a fresh mapping are slow) and one first wait, so that no rollout region ever pays for either --
+        a stepper whose first `wait()` allocated lazily ran its NEXT region 6 us (35 us under a process group) slower."""
+        import numpy as np
+        from .single import HostBlob
+        with torch.cuda.device(self.device):                   # the mapping is made for the stepper's device
+            blob = HostBlob(self._lib, [("seq", np.uint32, 1)])
+        self._wait_flag = (blob, blob.d["seq"], C.c_void_p(blob.v["seq"].ctypes.data))
+        self._wait_seq = 0
+        self.wait()
+
     def wait(self):
         if self._wait_flag is None:
-            import numpy as np
-            from .single import HostBlob
-            blob = HostBlob(self._lib, [("seq", np.uint32, 1)])
-            self._wait_flag = (blob, blob.d["seq"], C.c_void_p(blob.v["seq"].ctypes.data))
-            self._wait_seq = 0
+            self._open_wait()
+            return
         self._wait_seq = seq = (self._wait_seq + 1) & 0xFFFFFFFF or 1
         with _DevGuard(self.device):
             rc = self._lib.crl_stream_wait_mapped(_stream(), self._wait_flag[1], self._wait_flag[2], seq, self.WAIT_TIMEOUT_S)
@@ -162,6 +171,7 @@ class TronBatch(_Waitable):
         self._stat_steps = 0                      # rollout steps the running totals span (since reset_stats)
         self._rollout_args = None
         self.reset()
+        self._open_wait()
 
     # -- new_state for all (or masked) games
     def reset(self, mask: Optional[torch.Tensor] = None):
@@ -385,6 +395,7 @@ class TTTBatch(_Waitable):
             self.draw_count = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.len_sum = torch.zeros((B,), dtype=torch.int32, device=dev)
             self._results = torch.zeros((B, 3 + P), dtype=torch.int32, device=dev)
+        self._open_wait()
 
     def reset_stats(self):
         for t in (self.tcount, self.tstep, self.n_episodes, self.win_count, self.draw_count, self.len_sum, self._results):
@@ -570,6 +581,7 @@ class BlokusBatch(_Waitable):
             self.score_sum = torch.zeros((4, B), dtype=torch.int32, device=dev)
             self._results = torch.zeros((B, 10), dtype=torch.int32, device=dev)
         self.reset()
+        self._open_wait()
 
     def _state(self):
         return (_ptr(self.occ), _ptr(self.inv), _ptr(self.score), _ptr(self.round), _ptr(self.to_move))
