@@ -9,6 +9,7 @@ and every player spawns at the section centre plus its spawn offset, facing
 columns their names suggest and ``4 * side`` differs from the ring length; both
 are part of the observable behaviour and are kept.
 """
+from functools import lru_cache
 from typing import List, Sequence, Tuple
 
 
@@ -18,8 +19,10 @@ def _split_sizes(length: int, parts: int) -> List[int]:
     return [base + (1 if i < extra else 0) for i in range(parts)]
 
 
+@lru_cache(maxsize=256)
 def ring_walk(board_size: int, ring_offset: int) -> Tuple[List[int], int]:
-    """Ordered ring cells (flat indices) and the nominal side length."""
+    """Ordered ring cells (flat indices) and the nominal side length.  (A pure function of two integers, cached: the N*N
+    scan is most of what a drop-in ``new_state`` costs -- the reference rebuilds its ogrid masks on every call.)"""
     n = board_size
     half, odd = divmod(n, 2)
     inner, outer = half - ring_offset - 1, half - ring_offset

@@ -12,6 +12,7 @@ timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > gpurun_o
 [ $rc -ne 0 ] && exit 1
 timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_driver.json 2> gpurun_out/bench_driver.err; rc=$?; echo "bench rc=$rc lines=$(wc -l < gpurun_out/bench_driver.json) bytes=$(wc -c < gpurun_out/bench_driver.json)"; cat gpurun_out/bench_driver.json; echo
 [ $rc -ne 0 ] && exit 1
+cp gpurun_out/bench_detail.json gpurun_out/bench_detail_driver.json      # (the default bench below writes bench_detail.json again)
 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --warmup 5 --only-headline --no-cpu-baseline > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err; rc=$?; echo "torchrun rc=$rc"; head -c 900 gpurun_out/bench_torchrun1.json; echo
 [ $rc -ne 0 ] && exit 1
 if [ "${1:-}" = "default" ]; then
