@@ -106,7 +106,8 @@ class _Waitable:
             blob = HostBlob(self._lib, [("seq", np.uint32, 1)])
         self._wait_flag = (blob, blob.d["seq"], C.c_void_p(blob.v["seq"].ctypes.data))
         self._wait_seq = 0
-        self.wait()
+        if not torch.cuda.is_current_stream_capturing():        # (a stepper built under graph capture: nothing may block there)
+            self.wait()
 
     def wait(self):
         if self._wait_flag is None:
