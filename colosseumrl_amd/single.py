@@ -88,7 +88,10 @@ class _Single:
 
 
 class SingleTron(_Single):
-    """One Tron game in the reference's layout (board [N*N], heads / dirs / deaths [P]) on host-mapped memory."""
+    """One Tron game on host-mapped memory, in two blocks: the reference's own layout (int64 board [N*N], heads / directions /
+    deaths [P]: `s64`, stepped in place by ``crl_tron_next_state_inplace64_host`` -- what ``next_state`` and
+    ``state_to_observation`` of the drop-in class run on) and the batched steppers' int8 / int16 layout at B = 1 (`v`: what
+    ``new_state`` (``crl_tron_reset``) and ``compute_ranking`` (``crl_tron_ranking``) run on)."""
 
     def __init__(self, board_size: int, num_players: int, start_heads: Sequence[int], start_dirs: Sequence[int]):
         super().__init__()
@@ -99,19 +102,12 @@ class SingleTron(_Single):
         check(lib.crl_tron_create(N, P, sh, sd, C.byref(self._handle)), "crl_tron_create")
         self._open_stream()
         NN = self.NN
-        self.blob = HostBlob(lib, [
-            ("board", np.int8, NN), ("obs_board", np.int8, P * NN), ("heads", np.int16, P), ("dirs", np.int8, P),
-            ("deaths", np.int8, P), ("actions", np.int8, P), ("rewards", np.int8, P), ("terminal", np.uint8, 1),
-            ("winners", np.uint8, 1), ("obs_heads", np.int16, P * P), ("obs_dirs", np.int8, P * P),
-            ("obs_deaths", np.int8, P * P), ("player", np.int8, 1), ("rank", np.int8, P)])
+        self.blob = HostBlob(lib, [("board", np.int8, NN), ("heads", np.int16, P), ("dirs", np.int8, P), ("deaths", np.int8, P),
+                                   ("rank", np.int8, P)])
         v, d = self.blob.v, self.blob.d
         self.v = v
         h, s = self._handle, self._stream
         # argument tuples bound once (ctypes converts them per call; the pointers never change)
-        self._a_step = (h, 1, 0, 0, d["board"], d["heads"], d["dirs"], d["deaths"], d["actions"], None, d["rewards"],
-                        d["terminal"], d["winners"], d["obs_board"], d["obs_heads"], d["obs_dirs"], d["obs_deaths"], 0, s)
-        self._a_observe = (h, 1, d["board"], d["heads"], d["dirs"], d["deaths"], d["player"], d["obs_board"],
-                           d["obs_heads"], d["obs_dirs"], d["obs_deaths"], s)
         self._a_rank = (h, 1, d["board"], d["deaths"], d["rank"], s)
         self._a_reset = (h, 1, None, d["board"], d["heads"], d["dirs"], d["deaths"], s)
         self._open64()
@@ -188,21 +184,6 @@ class SingleTron(_Single):
             check(rc, "crl_tron_relative_player_inplace64")
         self.sync()
         return dst.copy()
-
-    def step_observe(self, actions):
-        """next_state + the observations of all P players, one launch (``crl_tron_step_observe``)."""
-        np.copyto(self.v["actions"], actions, casting="unsafe")
-        rc = self._lib.crl_tron_step_observe(*self._a_step)
-        if rc:
-            check(rc, "crl_tron_step_observe")
-        self.sync()
-
-    def observe(self, player: int):
-        self.v["player"][0] = player
-        rc = self._lib.crl_tron_observe(*self._a_observe)
-        if rc:
-            check(rc, "crl_tron_observe")
-        self.sync()
 
     def ranking(self):
         rc = self._lib.crl_tron_ranking(*self._a_rank)

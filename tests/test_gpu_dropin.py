@@ -106,6 +106,51 @@ def test_tron_dropin_vs_oracle(config):
     assert episodes >= 3
 
 
+def test_tron_dropin_fuses_observations_only_while_they_are_read():
+    """The drop-in Tron class writes the P observations of the new state in next_state's launch while somebody reads them, and
+    stops after OBS_IDLE_STEPS unread calls (stepping-only loops then touch the board where the reference does and nothing else).
+    Both forms, and the switch between them in either direction, against the oracle; an observation asked of a state whose
+    launch did not fuse them comes from crl_tron_relative_player_inplace64."""
+    from colosseumrl_amd import get_environment
+    env = get_environment("tron")("20;4")
+    N, P = 20, 4
+    rng = np.random.default_rng(11)
+    names = {0: "forward", 1: "right", -1: "left"}
+    sh, sd = O.tron_start_positions(N, P)
+
+    def fresh():
+        st, _ = env.new_state()
+        return st, OracleTron(N, P, 1, sh, sd)
+
+    def step(state, orc):
+        act = rng.integers(-1, 2, size=P)
+        state, _, rewards, terminal, _ = env.next_state(state, list(range(P)), [names[int(x)] for x in act])
+        r2, t2, _ = orc.step(act.astype(np.int8).reshape(P, 1))
+        assert np.array_equal(state[0].reshape(-1), orc.st.board[0]) and np.array_equal(state[1], orc.st.heads[:, 0])
+        assert np.array_equal(state[2], orc.st.dirs[:, 0]) and np.array_equal(state[3], orc.st.deaths[:, 0])
+        assert rewards.tolist() == r2[:, 0].tolist() and bool(terminal) == bool(t2[0])
+        return (state, orc) if not terminal else fresh()
+
+    def check_obs(state, orc, p):
+        ob, oh, od, ok = O.tron_observe(orc.st, np.array([p], np.int8))
+        got = env.state_to_observation(state, p)
+        assert np.array_equal(got["board"].reshape(-1), ob[0]) and np.array_equal(got["heads"], oh[:, 0])
+        assert np.array_equal(got["directions"], od[:, 0]) and np.array_equal(got["deaths"], ok[:, 0])
+
+    state, orc = fresh()
+    for phase in range(3):
+        for _ in range(env.OBS_IDLE_STEPS + 6):                  # nobody reads: after OBS_IDLE_STEPS the launch stops fusing
+            state, orc = step(state, orc)
+        assert env._observed is None and env._obs_idle >= env.OBS_IDLE_STEPS
+        check_obs(state, orc, phase % P)                         # not fused for this state: the Cython function's own entry
+        assert env._obs_idle == 0
+        for _ in range(5):                                       # read every step: served from the fused launch
+            state, orc = step(state, orc)
+            assert env._observed is not None
+            for p in range(P):
+                check_obs(state, orc, p)
+
+
 def test_dropin_results_are_cached_by_value_not_by_identity():
     """What next_state leaves behind for valid_actions / state_to_observation is keyed by the state's VALUE: an equal
     copy hits it, a state changed in place does not (and is evaluated afresh on the GPU)."""
