@@ -689,6 +689,41 @@ def out_of_cache(torch, device, seed, steps=20):
     out["step"] = st
     del tb, fo, acts
     torch.cuda.empty_cache()
+    # the other two games at batches whose state exceeds the Infinity Cache: short rollout launches (the state goes in and
+    # out once per launch whatever its length), events around back-to-back launches
+    from colosseumrl_amd.batched import BlokusBatch, TTTBatch
+    for name, make, plies, kernel, game, kw, wps in (
+            ("ttt_p3_3x5_k3", lambda: TTTBatch((3, 5), 3, 3, 20 * (1 << 20), device=device), 8, "ttt_rollout_kernel<3, 4, true>", "ttt",
+             dict(dims=(3, 5), k=3, num_players=3), 4),
+            ("blokus_p4", lambda: BlokusBatch(3 * (1 << 18), device=device), 8, "blokus_rollout_kernel", "blokus", dict(), 8)):
+        sb = make()
+        sb.rollout(plies, seed)
+        torch.cuda.synchronize()
+        n = 5
+        e0.record()
+        for _ in range(n):
+            sb.rollout(plies, seed)
+        e1.record()
+        torch.cuda.synchronize()
+        launch_s = e0.elapsed_time(e1) * 1e-3 / n
+        mean_len = mean_episode_len(sb.results(copy=False))[0]
+        state_b = sb.B * (4 * 3 + 2 if game == "ttt" else 360)
+        alg = algorithmic_bytes_per_step(game, kw, mean_len) * sb.B * plies
+        pmc = kp.get(kernel) or {}
+        rec = {"kernel": kernel, "games": sb.B, "state_bytes": state_b, "steps_per_launch": plies, "launch_ms": launch_s * 1e3,
+               "value": sb.B * plies / launch_s, "algorithmic_bytes": alg, "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS,
+               "traffic_model": int(launch_traffic_model(game, kw) * sb.B),
+               "traffic": int(pmc["hbm_bytes_per_call"]) if pmc.get("hbm_bytes_per_call") and pmc.get("games") == sb.B else None}
+        phys = rec["traffic"] or rec["traffic_model"]
+        rec["physical_frac"] = phys / launch_s / 1e9 / HBM_PEAK_GBS
+        if pmc.get("valu_insts_per_call") and pmc.get("games") == sb.B:
+            _, mix_occ, _ = valu_peaks(wps, MIX_OF_GAME[game])
+            if mix_occ:
+                rec["valu_frac_of_mix"] = pmc["valu_insts_per_call"] / launch_s / mix_occ
+        rec["bound"] = "hbm" if rec["physical_frac"] >= (rec.get("valu_frac_of_mix") or 0.0) else "issue"
+        out[name] = rec
+        del sb
+        torch.cuda.empty_cache()
     return out
 
 

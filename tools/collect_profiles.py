@@ -41,15 +41,17 @@ if len(sys.argv) == 3 and prefix.endswith("out_of_cache"):
     rec = {}
     for name, vals in summ.get("pmc", {}).items():
         short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and short in ("tron_rollout_quad_kernel<24>", "tron_step_observe_kernel<4, 64>", "tron_step_kernel<4>"):
+        games = {"tron_rollout_quad_kernel<24>": 1 << 20, "tron_step_observe_kernel<4, 64>": 1 << 20, "tron_step_kernel<4>": 1 << 20,
+                 "ttt_rollout_kernel<3, 4, true>": 20 * (1 << 20), "blokus_rollout_kernel": 3 * (1 << 18)}
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and short in games:
             rec[short] = {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
                           "hbm_bytes_per_call": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
                           "valu_insts_per_call": vals.get("SQ_INSTS_VALU"), "tcc_hit": vals.get("TCC_HIT_sum"), "tcc_miss": vals.get("TCC_MISS_sum"),
-                          "games": 1 << 20}
+                          "games": games[short]}
             if short.startswith("tron_rollout"):
                 rec[short]["steps_per_launch"] = 20
     json.dump({"note": "bench.py --only-out-of-cache under rocprofv3 --pmc (separate passes): Tron 20x20, 1,048,576 games = 436 MB of state, "
-                       "more than the 256 MiB Infinity Cache; per-dispatch averages; hbm_bytes_per_call = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                       "TicTacToe 3x5 at 20,971,520 games = 294 MB, Blokus at 786,432 games = 283 MB: each more than the 256 MiB Infinity Cache; per-dispatch averages; hbm_bytes_per_call = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                        "(gfx950 correction of MI355X_MICROARCH.md)",
                "source": "profiles/%s_rocprofv3_summary.json" % prefix, "kernels": rec},
               open(os.path.join(dst, "traffic_out_of_cache.json"), "w"), indent=1)
