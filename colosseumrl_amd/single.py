@@ -157,11 +157,11 @@ class SingleTron(_Single):
         them, TronGridEnvironment.py:301-304) + rewards / terminal; with `with_obs` also the observations of all P players
         of the new state.  ONE launch, one wait; the results are the views in ``self.s64``."""
         v = self.s64
-        np.copyto(v["board"], board, casting="unsafe")
-        np.copyto(v["heads"], heads, casting="unsafe")
-        np.copyto(v["dirs"], dirs, casting="unsafe")
-        np.copyto(v["deaths"], deaths, casting="unsafe")
-        np.copyto(v["actions"], actions, casting="unsafe")
+        v["board"][...] = board                                  # (slice assignment: numpy's unsafe cast, 0.6 us less than five copyto calls)
+        v["heads"][:] = heads
+        v["dirs"][:] = dirs
+        v["deaths"][:] = deaths
+        v["actions"][:] = actions
         if self._unified:                                        # launch + completion in one call, vectors by value
             self._seq = seq = (self._seq + 1) & 0xFFFFFFFF or 1
             rc = self._lib.crl_tron_next_state_inplace64_host(*(self._a_host64_obs if with_obs else self._a_host64), seq, self.WAIT_TIMEOUT_S)
