@@ -91,11 +91,24 @@ __device__ __forceinline__ void tron_split_heads(const TronGeom &g, TronRegs<P> 
 }
 
 // Board views: how a step reads "who owns this cell" (0 = empty) and writes a trail cell.
+// (the cell-indexed views below carry the board's cell count in the bounds-assert build: every probe / trail index of the
+//  step, step_observe and int64 in-place kernels is checked against it -- codes 13x; a probe of a dead or out-of-board
+//  player reads cell 0 by construction)
+#ifdef CRL_BOUNDS
+#define CRL_CELLS_MEMBER int cells;
+#define CRL_CELLS_INIT(nn) , (nn)
+#define CRL_CELLS_CHECK(c, code) CRL_BOUNDS_LT((c), cells, (code))
+#else
+#define CRL_CELLS_MEMBER
+#define CRL_CELLS_INIT(nn)
+#define CRL_CELLS_CHECK(c, code) do { } while (0)
+#endif
 struct PlainBoard {                 // canonical int8 cells, global memory
     int8_t *p;
-    __device__ __forceinline__ int raw(const int c) const { return p[c]; }
+    CRL_CELLS_MEMBER
+    __device__ __forceinline__ int raw(const int c) const { CRL_CELLS_CHECK(c, 130); return p[c]; }
     __device__ __forceinline__ int owner(const int r) const { return r; }
-    __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (int8_t)who; }
+    __device__ __forceinline__ void put(const int c, const int who) const { CRL_CELLS_CHECK(c, 131); p[c] = (int8_t)who; }
 };
 // LDS cells carry an episode tag: byte = tag << OB | owner.  A cell counts as occupied only when its
 // tag equals the game's current tag, so "new_state" is tag+1 instead of clearing N*N bytes; a real clear
@@ -448,7 +461,7 @@ tron_step_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
     }
     tron_split_heads<P>(g, s);
     int term, wm;
-    const PlainBoard bd{board + bb * NN};
+    const PlainBoard bd{board + bb * NN CRL_CELLS_INIT(NN)};
     tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
     if (valid) {
 #pragma unroll
@@ -2739,9 +2752,10 @@ tron_observe_all_players_kernel(const int64_t B, const int16_t *__restrict__ hea
 struct DualBoard {                  // step on the LDS copy, mirror the trail writes to the canonical HBM board
     uint8_t *l;
     int8_t *g;
-    __device__ __forceinline__ int raw(const int c) const { return l[c]; }
+    CRL_CELLS_MEMBER
+    __device__ __forceinline__ int raw(const int c) const { CRL_CELLS_CHECK(c, 132); return l[c]; }
     __device__ __forceinline__ int owner(const int r) const { return r; }
-    __device__ __forceinline__ void put(const int c, const int who) const { l[c] = (uint8_t)who; g[c] = (int8_t)who; }
+    __device__ __forceinline__ void put(const int c, const int who) const { CRL_CELLS_CHECK(c, 133); l[c] = (uint8_t)who; g[c] = (int8_t)who; }
 };
 
 constexpr uint32_t kStepObserveNT = 0x80000000u;            // kernel-side flag bit next to CRL_STEP_AUTO_RESET
@@ -2811,7 +2825,7 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
         }
         tron_split_heads<P>(g, s);
         int term, wm;
-        const DualBoard bd{lds + e * SLAB, board + b * NN};
+        const DualBoard bd{lds + e * SLAB, board + b * NN CRL_CELLS_INIT(NN)};
         tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
         const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
         rflag[e] = do_reset ? 1 : 0;
@@ -2929,7 +2943,7 @@ tron_step_staged_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t
     if (stepper) {
         tron_split_heads<P>(g, s);
         int term, wm;
-        const DualBoard bd{lds + e * SLAB, board + b * NN};
+        const DualBoard bd{lds + e * SLAB, board + b * NN CRL_CELLS_INIT(NN)};
         tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
         const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
         rflag[e] = do_reset ? 1 : 0;
@@ -2996,7 +3010,7 @@ tron_step_observe_any_kernel(const crl_tron_cfg cfg, const TronGeom g, const int
         }
         tron_split_heads<P>(g, s);
         int term, wm;
-        const DualBoard bd{lds, gb};
+        const DualBoard bd{lds, gb CRL_CELLS_INIT(NN)};
         tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
         const bool do_reset = term && (flags & CRL_STEP_AUTO_RESET);
         s_reset = do_reset ? 1 : 0;
@@ -3051,16 +3065,18 @@ tron_step_observe_any_kernel(const crl_tron_cfg cfg, const TronGeom g, const int
 // then probes the LDS copy, and all threads write the P relabelled int64 copies (CyTronGrid.pyx:70-71, C remainder).
 struct Board64 {                    // in place on the caller's int64 board
     int64_t *p;
-    __device__ __forceinline__ int raw(const int c) const { return (int)p[c]; }
+    CRL_CELLS_MEMBER
+    __device__ __forceinline__ int raw(const int c) const { CRL_CELLS_CHECK(c, 134); return (int)p[c]; }
     __device__ __forceinline__ int owner(const int r) const { return r; }
-    __device__ __forceinline__ void put(const int c, const int who) const { p[c] = (int64_t)who; }
+    __device__ __forceinline__ void put(const int c, const int who) const { CRL_CELLS_CHECK(c, 135); p[c] = (int64_t)who; }
 };
 struct DualBoard64 {                // step on the LDS byte copy, mirror the trail writes to the caller's int64 board
     uint8_t *l;
     int64_t *g;
-    __device__ __forceinline__ int raw(const int c) const { return l[c]; }
+    CRL_CELLS_MEMBER
+    __device__ __forceinline__ int raw(const int c) const { CRL_CELLS_CHECK(c, 136); return l[c]; }
     __device__ __forceinline__ int owner(const int r) const { return r; }
-    __device__ __forceinline__ void put(const int c, const int who) const { l[c] = (uint8_t)who; g[c] = (int64_t)who; }
+    __device__ __forceinline__ void put(const int c, const int who) const { CRL_CELLS_CHECK(c, 137); l[c] = (uint8_t)who; g[c] = (int64_t)who; }
 };
 
 // the player vectors of ONE game by value (kernel arguments): what the single-state call passes instead of letting the
@@ -3101,10 +3117,10 @@ tron_next_state64_kernel(const TronGeom g, const int64_t B, int64_t *__restrict_
         tron_split_heads<P>(g, s);
         int term, wm;
         if (want_obs) {
-            const DualBoard64 bd{lds, gb};
+            const DualBoard64 bd{lds, gb CRL_CELLS_INIT(NN)};
             tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
         } else {
-            const Board64 bd{gb};
+            const Board64 bd{gb CRL_CELLS_INIT(NN)};
             tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
         }
 #pragma unroll

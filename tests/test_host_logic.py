@@ -168,7 +168,8 @@ def test_single_state_path_makes_no_copies():
         assert ".cpu()" not in code and "copy_(" not in code, path
     single = open(files[0]).read()
     # every public GPU call of a stepper ends in exactly one synchronise
-    for name in ("step_observe", "observe", "ranking", "reset", "step", "valid", "legal_ids", "is_valid"):
+    # (next_state64: its one-call form -- crl_tron_next_state_inplace64_host blocks by itself -- returns before the two-call form's sync)
+    for name in ("next_state64", "relative_board64", "observe", "ranking", "reset", "step", "valid", "legal_ids", "is_valid"):
         bodies = re.findall(r"    def %s\(self.*?(?=\n    def |\nclass |\Z)" % name, single, flags=re.S)
         assert bodies, name
         for body in bodies:
