@@ -2462,7 +2462,7 @@ tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_
 // an 8-entry byte table (cell value -> relative id); the P tables sit in LDS, a thread fetches its game's table (one
 // ds_read_b64) and relabels 4 cells per v_perm_b32, the board bytes being the selector.
 __global__ void __launch_bounds__(256)
-tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8_t *__restrict__ board,
+tron_observe_board_kernel(const int NN, const int P, const uint32_t inv_cp, const bool nt, const int64_t B, const int8_t *__restrict__ board,
                           const int8_t *__restrict__ player, int8_t *__restrict__ obs)
 {
     __shared__ uint2 lut[CRL_TRON_MAX_P];
@@ -2486,7 +2486,10 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
             // (TronGridEnvironment.py:393), the board goes through C's remainder (CyTronGrid.pyx:1 cdivision=True, :71).
             // Up to pr = P the operand v - (pr + 1) + P stays >= 0 and both agree (= observer pr mod P: the table);
             // beyond, low trail ids come out <= 0 -- reproduced by the arithmetic branch
-            const int pr = player[off / NN];
+            // the game of chunk i: i / (chunks per board) -- an exact 32-bit multiply-high where the chunk index fits (the
+            // 64-bit division it replaces was a third of this kernel's instructions)
+            const int64_t game = (i >> 32) == 0 && inv_cp ? (int64_t)__umulhi((uint32_t)i, inv_cp) : off / NN;
+            const int pr = player[game];
             const int pl = pr + 1;
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
             uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
@@ -2509,7 +2512,7 @@ tron_observe_board_kernel(const int NN, const int P, const int64_t B, const int8
                     o[q] = r;
                 }
             }
-            *reinterpret_cast<uint4 *>(obs + off) = make_uint4(o[0], o[1], o[2], o[3]);
+            crl_stream_store16(obs + off, make_uint4(o[0], o[1], o[2], o[3]), nt);
         } else {
             const int pl = (int)player[i / NN] + 1;
             const int c = board[i];
@@ -3529,7 +3532,12 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     hipStream_t s = (hipStream_t)stream;
     const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
     const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
-    hipLaunchKernelGGL(tron_observe_board_kernel, dim3(grid), dim3(256), 0, s, NN, cfg.P, B, board, player, obs_board);
+    // m = floor(2^32 / c) + 1 for c = chunks per board: umulhi(i, m) == i / c for every chunk id i with i * c < 2^32 (the
+    // error term m * c - 2^32 is at most c); batches beyond that keep the 64-bit division
+    const uint32_t cpb = (uint32_t)(NN / 16);
+    const uint32_t inv_cp = (NN % 16 == 0 && cpb > 1 && (uint64_t)items * cpb < ((uint64_t)1 << 32)) ? (uint32_t)(((uint64_t)1 << 32) / cpb) + 1u : 0u;
+    hipLaunchKernelGGL(tron_observe_board_kernel, dim3(grid), dim3(256), 0, s, NN, cfg.P, inv_cp, crl_stream_nt((int64_t)2 * NN * B, true), B,
+                       board, player, obs_board);
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, player, obs_heads, obs_dirs, obs_deaths);

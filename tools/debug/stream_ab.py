@@ -41,6 +41,8 @@ def main():
         buf = tb.observe_all()
         rec["observe_all_us"] = gpu_us(lambda: tb.observe_all(buf), calls)
         rec["rollout20_us"] = gpu_us(lambda: tb.rollout(20, 3), calls)
+        pl = torch.randint(0, 4, (B,), dtype=torch.int8, device="cuda")
+        rec["observe_us"] = gpu_us(lambda: tb.observe(pl), calls)
         nbytes = 5 * 400 * B
         rec["step_observe_TBs"] = round(nbytes / rec["step_observe_us"][0] / 1e6, 3)
         out["b%d" % B] = rec
