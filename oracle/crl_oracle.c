@@ -195,10 +195,14 @@ void orc_tron_rollout(int N, int P, int64_t B, uint64_t seed, uint64_t first_env
         uint32_t tc = st.tcount[b], ts = st.tstep[b];
         uint32_t g = (uint32_t)(first_env_id + (uint64_t)b);
         static const uint32_t POW3[8] = { 1u, 3u, 9u, 27u, 81u, 243u, 729u, 2187u };
+        uint32_t wq[2][4];                              /* the Philox block of the current 8 steps, players 0-3 / 4-7 */
         for (int t = 0; t < T; ++t) {
             for (int q = 0; q < (P + 3) / 4; ++q) {
-                uint32_t ctr[4] = { g, tc >> 3, (uint32_t)q, ORC_TAG_TRON }, w[4];
-                orc_philox4x32(ctr, key, w);
+                uint32_t *w = wq[q];
+                if (t == 0 || (tc & 7u) == 0u) {            /* one block serves 8 consecutive steps (the contract in the header): */
+                    uint32_t ctr[4] = { g, tc >> 3, (uint32_t)q, ORC_TAG_TRON };   /* recomputed only when tc >> 3 moves on */
+                    orc_philox4x32(ctr, key, w);
+                }
                 uint32_t j = tc & 7u, word = w[j >> 1];
                 for (int i = 0; i < 4 && q * 4 + i < P; ++i) {
                     uint32_t v = word * POW3[(j & 1u) * 4u + (uint32_t)i];
