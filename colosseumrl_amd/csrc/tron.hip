@@ -134,18 +134,25 @@ struct TronProbe {
     bool oob[P];
 };
 
-template <int P, typename BOARD>
+// EXACT (the int64 entries with the Cython signature only): the direction as CyTronGrid.pyx:32 computes it on C longs,
+// (directions[i] + action + 4) % 4 with C's remainder (cdivision=True) -- for the values TronGridEnvironment ever passes
+// (directions 0..3, actions -1 / 0 / +1) that is the `& 3` of the batched entries; for anything that sums below -4 the
+// remainder is NEGATIVE, none of :35-42's four branches fires, the player "moves" onto the cell it stands on (and dies by
+// its own id there, :51-57) and the negative direction is stored (:44).  Reproduced bit for bit (tests/golden/tron_wild64.npz).
+template <int P, typename BOARD, bool EXACT = false>
 __device__ __forceinline__ void tron_probe(const TronGeom &g, const BOARD &bd, const TronRegs<P> &s,
                                            const int (&act)[P], TronProbe<P> &pr)
 {
     const int N = g.N;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int dir = (s.d[i] + act[i]) & 3;          // act in {0, 1, 3}: forward, right, left (= -1 mod 4)
+        const int exact = EXACT ? (s.d[i] + act[i] + 4) % 4 : 0;
+        const bool stay = EXACT && exact < 0;
+        const int dir = EXACT ? exact : (s.d[i] + act[i]) & 3;  // act in {0, 1, 3}: forward, right, left (= -1 mod 4)
         // unit step of direction dir from two 4-entry byte tables (one v_bfe_i32 each): dx = 0,+1,0,-1  dy = -1,0,+1,0
-        const int sh8 = dir << 3;
-        pr.nx[i] = s.x[i] + __builtin_amdgcn_sbfe((int)0xff000100u, sh8, 8);
-        pr.ny[i] = s.y[i] + __builtin_amdgcn_sbfe((int)0x000100ffu, sh8, 8);
+        const int sh8 = (dir & 3) << 3;
+        pr.nx[i] = s.x[i] + (stay ? 0 : __builtin_amdgcn_sbfe((int)0xff000100u, sh8, 8));
+        pr.ny[i] = s.y[i] + (stay ? 0 : __builtin_amdgcn_sbfe((int)0x000100ffu, sh8, 8));
         pr.ndir[i] = dir;
         pr.oob[i] = ((unsigned)pr.nx[i] >= (unsigned)N) | ((unsigned)pr.ny[i] >= (unsigned)N);
         // in-board coordinates are < 2^15: the 24-bit multiply-add is a full-rate VALU op (a 32-bit one is not)
@@ -270,13 +277,13 @@ __device__ __forceinline__ void tron_resolve_lds(const BOARD &bd, TronRegs<P> &s
     }
 }
 
-template <int P, typename BOARD>
+template <int P, typename BOARD, bool EXACT = false>
 __device__ __forceinline__ void tron_step_core(const TronGeom &g, const BOARD &bd, const bool valid,
                                                TronRegs<P> &s, const int (&act)[P],
                                                int (&rew)[P], int &term, int &wmask)
 {
     TronProbe<P> pr;
-    tron_probe<P>(g, bd, s, act, pr);
+    tron_probe<P, BOARD, EXACT>(g, bd, s, act, pr);
     tron_resolve<P>(bd, valid, s, pr, rew, term, wmask);
 }
 
@@ -3121,10 +3128,10 @@ tron_next_state64_kernel(const TronGeom g, const int64_t B, int64_t *__restrict_
         int term, wm;
         if (want_obs) {
             const DualBoard64 bd{lds, gb CRL_CELLS_INIT(NN)};
-            tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
+            tron_step_core<P, DualBoard64, true>(g, bd, true, s, act, rew, term, wm);
         } else {
             const Board64 bd{gb CRL_CELLS_INIT(NN)};
-            tron_step_core<P>(g, bd, true, s, act, rew, term, wm);
+            tron_step_core<P, Board64, true>(g, bd, true, s, act, rew, term, wm);
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {

@@ -253,8 +253,10 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
  *                                           const long[::1] actions)
  *   CyTronGrid.pyx:65    relative_player_inplace(long[:, ::1] board, const long num_players, const long player)
  * int64, C-contiguous, the reference's layout (board [N][N]; heads / directions / deaths / actions [P]; actions in
- * {0 forward, +1 right, -1 left}), MUTATED IN PLACE, caller owns every buffer, no error path for the contents (as there;
- * directions + actions are taken mod 4 like crl_tron_step).  B games lie one behind the other ([B][N*N], [B][P]); the
+ * {0 forward, +1 right, -1 left}), MUTATED IN PLACE, caller owns every buffer, no error path for the contents (as there).
+ * The direction is computed as there, (directions[i] + action + 4) % 4 with C's remainder: sums below -4 give a negative
+ * direction, the player then runs into the cell it stands on and the negative direction is stored -- 240 direct calls of the
+ * reference function with such arguments are a golden fixture (values are read as 32-bit integers; heads must lie on the board).  B games lie one behind the other ([B][N*N], [B][P]); the
  * single-state drop-in class calls it with B = 1 on crl_host_alloc memory, so TronGridEnvironment.next_state neither
  * converts its four arrays to the batched steppers' int8 / int16 struct-of-arrays nor back.  The step touches the board where the
  * reference does: <= P probes, <= P trail stores.  Optional outputs (NULL to skip), what TronGridEnvironment.next_state

@@ -354,6 +354,44 @@ def gen_ttt(R):
         np.savez_compressed(os.path.join(OUT, "ttt_observe_%s.npz" % name), **ttt_observe_cases(R, which, 64, 5))
 
 
+def gen_tron_wild64(R):
+    """CyTronGrid.next_state_inplace called DIRECTLY (not through TronGridEnvironment, whose STRING_TO_ACTION only ever passes
+    -1 / 0 / +1) with actions and stored directions outside their usual ranges: the function computes
+    (directions[i] + action + 4) % 4 with C's remainder (cdivision=True), so sums below -4 give a NEGATIVE direction, none of
+    the four move branches fires, the player runs into the cell it stands on and the negative direction is stored.  States are
+    valid positions of random play (heads on the board, trails consistent): nothing here reads outside an array in the
+    reference.  For crl_tron_next_state_inplace64, which promises the Cython function's own behaviour."""
+    cy = R["cytron"]
+    rng = np.random.default_rng(2024)
+    out = {k: [] for k in ("pre_board", "pre_heads", "pre_dirs", "pre_deaths", "actions", "post_board", "post_heads", "post_dirs", "post_deaths")}
+    N, P = 12, 4
+    env = R["tron"]("%d;%d" % (N, P))
+    for game in range(40):
+        (board, heads, dirs, deaths), players = env.new_state()
+        for t in range(int(rng.integers(0, 12))):                # a few ordinary steps first
+            acts = [TRON_ACT[int(a)] for a in rng.integers(0, 3, size=P)]
+            (board, heads, dirs, deaths), players, _, term, _ = env.next_state((board, heads, dirs, deaths), list(range(P)), acts)
+            if term:
+                break
+        for rep in range(6):                                     # then chains of wild calls on the same arrays (directions carry over)
+            a = rng.integers(-9, 10, size=P).astype(np.int64)
+            d = dirs.copy()
+            if rep % 2:
+                d = d + 4 * rng.integers(-3, 3, size=P)          # stored directions outside 0..3 as well
+            b, h, k = board.copy(), heads.copy(), deaths.copy()
+            for key, v in (("pre_board", b.reshape(-1)), ("pre_heads", h), ("pre_dirs", d), ("pre_deaths", k), ("actions", a)):
+                out[key].append(np.array(v, np.int64))
+            cy.next_state_inplace(b, h, d, k, a)
+            for key, v in (("post_board", b.reshape(-1)), ("post_heads", h), ("post_dirs", d), ("post_deaths", k)):
+                out[key].append(np.array(v, np.int64))
+            board, heads, dirs, deaths = b, h, d, k
+    rec = {k: np.array(v, np.int16) for k, v in out.items()}
+    rec["N"], rec["P"] = np.int64(N), np.int64(P)
+    assert (rec["post_dirs"] < 0).any() and (np.abs(rec["actions"]) > 1).any()
+    np.savez_compressed(os.path.join(OUT, "tron_wild64.npz"), **rec)
+    print("tron_wild64:", len(out["actions"]), "calls,", int((rec["post_dirs"] < 0).sum()), "negative directions stored")
+
+
 def main(argv):
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.load()
@@ -362,6 +400,8 @@ def main(argv):
         gen_tron(R)
     if "tron_observe_wrap" in what:
         gen_tron_observe_wrap(R)
+    if "tron" in what or "tron_wild64" in what:
+        gen_tron_wild64(R)
     if "ttt" in what:
         gen_ttt(R)
     if "ttt" in what or "ttt_rewards" in what:

@@ -119,6 +119,22 @@ def test_next_state_inplace64_edge_cases_golden(golden, obs):
     assert np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
 
 
+@pytest.mark.parametrize("obs", [False, True])
+def test_next_state_inplace64_wild_actions_and_directions_golden(golden, obs):
+    """The Cython function called directly with actions / stored directions outside their usual ranges (the reference's C
+    remainder gives negative directions: the player runs into its own cell, the negative direction is stored): 240 calls of
+    the reference's CyTronGrid.next_state_inplace, chains on the same arrays included (tests/golden/tron_wild64.npz)."""
+    g = golden("tron_wild64")
+    N, P, E = int(g["N"]), int(g["P"]), len(g["actions"])
+    be = Inplace64(N, P, E)
+    be.set_state(g["pre_board"], g["pre_heads"], g["pre_dirs"], g["pre_deaths"])
+    be.step(g["actions"], obs)
+    board, heads, dirs, deaths = be.np("board", "heads", "dirs", "deaths")
+    assert np.array_equal(board, g["post_board"]) and np.array_equal(heads, g["post_heads"])
+    assert np.array_equal(dirs, g["post_dirs"]) and np.array_equal(deaths, g["post_deaths"])
+    assert (dirs < 0).sum() > 100                                 # the negative directions are really there
+
+
 @pytest.mark.parametrize("N,P,B,T", [(20, 4, 300, 40), (40, 4, 64, 60), (19, 3, 77, 40), (9, 8, 130, 30), (5, 2, 100, 20)])
 def test_next_state_inplace64_vs_oracle_random(N, P, B, T):
     """Seeded random play: the int64 in-place entry (with and without the fused observations) against the oracle's step
