@@ -173,13 +173,15 @@ class SingleTron(_Single):
             check(rc, "crl_tron_next_state_inplace64")
         self.sync()
 
-    def relative_board64(self, board, player_plus_1: int):
-        """``relative_player_inplace(copy of board, P, player_plus_1)`` (CyTronGrid.pyx:65-71): the relabelled int64 board."""
+    def relative_board64(self, board, player_plus_1: int, num_players: int = None):
+        """``relative_player_inplace(copy of board, num_players, player_plus_1)`` (CyTronGrid.pyx:65-71): the relabelled int64
+        board (`num_players` defaults to this game's)."""
         NN = self.NN
         dst = self.s64["obs"][:NN].reshape(self.N, self.N)
         np.copyto(dst, board, casting="unsafe")
         self.s64["player"][0] = player_plus_1
-        rc = self._lib.crl_tron_relative_player_inplace64(*self._a_rel64)
+        args = self._a_rel64 if num_players is None else self._a_rel64[:3] + (int(num_players),) + self._a_rel64[4:]
+        rc = self._lib.crl_tron_relative_player_inplace64(*args)
         if rc:
             check(rc, "crl_tron_relative_player_inplace64")
         self.sync()

@@ -119,6 +119,30 @@ def test_next_state_inplace64_edge_cases_golden(golden, obs):
     assert np.array_equal(term, g["terminal"]) and np.array_equal(win, g["winners"])
 
 
+def test_cytrongrid_stand_in_module_golden(golden):
+    """colosseumrl_amd.envs.tron.CyTronGrid: the reference's native module under its own two signatures, plain numpy arrays in
+    ordinary memory, mutated in place -- against calls of the reference's functions (order-dependence cases, wild actions /
+    directions, relabelling for observer ids of any size)."""
+    from colosseumrl_amd.envs.tron import CyTronGrid
+    for name, keys in (("tron_edge", ("pre_board", "pre_heads", "pre_dirs", "pre_deaths", "actions")),
+                       ("tron_wild64", ("pre_board", "pre_heads", "pre_dirs", "pre_deaths", "actions"))):
+        g = golden(name)
+        N = int(g["N"])
+        for i in range(len(g["actions"])):
+            board, heads, dirs, deaths, acts = (np.array(g[k][i], np.int64) for k in keys)
+            board = board.reshape(N, N)
+            assert CyTronGrid.next_state_inplace(board, heads, dirs, deaths, acts) is None
+            assert np.array_equal(board.reshape(-1), g["post_board"][i]) and np.array_equal(heads, g["post_heads"][i]), (name, i)
+            assert np.array_equal(dirs, g["post_dirs"][i]) and np.array_equal(deaths, g["post_deaths"][i]), (name, i)
+    for name in ("n20p4", "wrap_n20p4", "wrap_n9p6"):
+        g = golden("tron_observe_" + name)
+        N, P = int(g["N"]), int(g["P"])
+        for i in range(0, len(g["player"]), 3):
+            board = np.array(g["board"][i], np.int64).reshape(N, N)
+            CyTronGrid.relative_player_inplace(board, P, int(g["player"][i]) + 1)
+            assert np.array_equal(board.reshape(-1), g["obs_board"][i]), (name, i)
+
+
 @pytest.mark.parametrize("obs", [False, True])
 def test_next_state_inplace64_wild_actions_and_directions_golden(golden, obs):
     """The Cython function called directly with actions / stored directions outside their usual ranges (the reference's C
