@@ -97,7 +97,8 @@ class ShardedRollout:
         self.lo, self.hi = shard_bounds(self.total, self.rank, self.world)
         self.stepper = make_stepper(batch=self.hi - self.lo, first_env_id=self.lo)
         self._equal = self.total % self.world == 0          # equal shards: the local rows go into the collective as they are
-        self._recv = {}                                     # (dtype, row shape) -> (receive buffer, its per-rank pieces)
+        self._recv = {}                                     # (narrow rows?, all ranks?) -> (receive buffer, its per-rank pieces, its int16 view)
+        self._wire_view = None                              # (the stepper's packed rows, their int32 view)
 
     def rollout(self, steps: int, seed: int = 0, chunk: int = 512, events=None) -> int:
         """Exactly `steps` env-steps for every local game, as fused launches of <= chunk steps.  ``events`` = (start, stop)
@@ -135,7 +136,10 @@ class ShardedRollout:
         st = self.stepper
         if packed is not False and hasattr(st, "results_packed") and (packed is True or st.packed_rows_exact()):
             rows = st.results_packed(copy=False)            # int16 [n, 2m]; shipped as int32 [n, m] (NCCL has no int16)
-            return rows.view(torch.int32), True
+            cached = self._wire_view
+            if cached is None or cached[0] is not rows:     # (the stepper's live buffer: one view for all gathers, not one per call)
+                cached = self._wire_view = (rows, rows.view(torch.int32))
+            return cached[1], True
         return st.results(copy=False), False
 
     def gather(self, dst: Optional[int] = None, packed="auto", copy: bool = True) -> Optional[torch.Tensor]:
@@ -147,10 +151,13 @@ class ShardedRollout:
         the wide rows and int16 ``[total, 2m]`` for the 16-bit ones; column 0 is n_episodes and column 1 len_sum in both.
         ``copy=False`` returns the reused receive buffer (or, without a process group, the stepper's live rows), which
         the next gather / rollout overwrites -- the fast path bench.py times."""
+        if not self.dist:                                   # no process group: the stepper's own rows, no wire format in between
+            st = self.stepper
+            if packed is not False and hasattr(st, "results_packed") and (packed is True or st.packed_rows_exact()):
+                return st.results_packed(copy=copy)
+            return st.results(copy=copy)
         local, narrow = self._local_rows(packed)
-        if not self.dist:
-            got = local
-        elif not self._equal:
+        if not self._equal:
             got = gather_results(local, self.total, self.group, dst=dst)
             if got is None:
                 return None
@@ -161,14 +168,15 @@ class ShardedRollout:
             if buf is None and receiver:
                 n = local.shape[0]
                 out = torch.empty((self.world * n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-                buf = self._recv[key] = (out, [out[r * n: (r + 1) * n] for r in range(self.world)])
+                buf = self._recv[key] = (out, [out[r * n: (r + 1) * n] for r in range(self.world)], out.view(torch.int16) if narrow else out)
             if dst is None:
                 dist.all_gather_into_tensor(buf[0], local, group=self.group)
             else:
                 dist.gather(local, buf[1] if receiver else None, dst=_global_rank(self.group, dst), group=self.group)
                 if not receiver:
                     return None
-            got = buf[0]
+            got = buf[2]
+            return got.clone() if copy else got
         if narrow:
             got = got.view(torch.int16)
         return got.clone() if copy else got
