@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CRL_LIB_PATH") or os.path.join(PKG_DIR, "libcolosseum
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 # the revision of include/colosseum_hip.h this binding (struct layouts, argument lists, RNG contract) was written against
-CRL_ABI_VERSION = 110
+CRL_ABI_VERSION = 111
 CRL_STEP_AUTO_RESET = 1
 CRL_STEP_BYTES = 2
 CRL_STEP_STAGED = 4
@@ -98,6 +98,7 @@ PROTOTYPES = {
     "crl_ttt_valid": (_I, [_VP, _I64, _VP, _VP, _VP]),
     "crl_ttt_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP]),
     "crl_ttt_step_board": (_I, [_VP, _I64] + [_VP] * 9 + [_I, _U32, _VP]),
+    "crl_ttt_step_board_host": (_I, [_VP] + [_VP] * 9 + [_I, _U32, _VP, _VP, _U32, C.c_double]),
     "crl_ttt_observe_board": (_I, [_VP, _I64, _VP, _VP, _I, _VP, _VP, _VP]),
     "crl_ttt_rollout": (_I, [_VP, _I64, _U64, _U64, _I, _VP, _VP, _VP, TTTStats, _VP]),
     "crl_ttt_sample": (_I, [_VP, _I64, _U64, _U64, _VP, _VP, _I, _VP, _VP]),

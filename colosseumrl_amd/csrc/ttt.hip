@@ -615,23 +615,36 @@ __device__ __forceinline__ void ttt_write_relative(const uint32_t (&o)[P], const
     }
 }
 
+// one reference-layout state BY VALUE (kernel arguments): what the single-state call passes instead of letting the kernel
+// fetch board, winner, mover and action over PCIe first (crl_ttt_step_board_host)
+struct TttVec {
+    uint32_t occ[CRL_TTT_MAX_P];                               // the board as the masks ttt_masks_of_board would build
+    int32_t winner, to_move, action;
+};
+
 template <int P, int ND>
 __global__ void __launch_bounds__(256)
 ttt_step_board_kernel(const ttt_dirs dd, const int64_t B, int8_t *__restrict__ board, int8_t *__restrict__ winner,
                       int8_t *__restrict__ to_move, const int8_t *__restrict__ action, int8_t *__restrict__ reward,
                       uint8_t *__restrict__ terminal, int8_t *__restrict__ winners, uint32_t *__restrict__ valid,
-                      int8_t *__restrict__ obs, const int rel_mod, const uint32_t flags)
+                      int8_t *__restrict__ obs, const int rel_mod, const uint32_t flags,
+                      const TttVec vec, const bool by_value, uint32_t *flag, const uint32_t seq)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int8_t *cells = board + b * dd.n_cells;
     uint32_t o[P];
-    ttt_masks_of_board<P>(cells, dd.n_cells, o);
+    if (by_value) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) o[p] = vec.occ[p];
+    } else {
+        ttt_masks_of_board<P>(cells, dd.n_cells, o);
+    }
     uint32_t before = 0;
 #pragma unroll
     for (int p = 0; p < P; ++p) before |= o[p];
-    int w = winner[b], tm = to_move[b], r, t, ws;
-    const int pl = tm, act = action[b];
+    int w = by_value ? vec.winner : (int)winner[b], tm = by_value ? vec.to_move : (int)to_move[b], r, t, ws;
+    const int pl = tm, act = by_value ? vec.action : (int)action[b];
     ttt_step_core<P, ND>(dd, o, w, tm, act, r, t, ws);
     reward[b] = (int8_t)r;
     terminal[b] = (uint8_t)t;
@@ -651,6 +664,8 @@ ttt_step_board_kernel(const ttt_dirs dd, const int64_t B, int8_t *__restrict__ b
     to_move[b] = (int8_t)tm;
     if (valid) valid[b] = dd.full & ~all;          // valid_actions of the player to move next (:317-348)
     if (obs) ttt_write_relative<P>(o, dd.n_cells, tm, rel_mod, obs + b * dd.n_cells);
+    // (single-state call, B = 1: this thread wrote everything, so its release store publishes completion)
+    if (flag && b == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // valid_actions (empties mask) and / or state_to_observation (ids relative to player[b]) of reference-layout boards
@@ -887,27 +902,56 @@ int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t 
     return CRL_OK;
 }
 
+static int ttt_step_board_launch(const char *fn, const crl_ctx *ctx, int64_t B, int8_t *board, int8_t *winner, int8_t *to_move,
+                                 const int8_t *action, int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid,
+                                 int8_t *obs_board, int rel_mod, uint32_t flags, void *stream, const bool by_value, uint32_t *flag,
+                                 const uint32_t seq)
+{
+    CRL_REQUIRE(ctx != nullptr && ctx->game == CRL_GAME_TTT, "%s: ctx is not a tictactoe context", fn);
+    CRL_REQUIRE(B > 0 && B <= ((int64_t)1 << 31), "%s: B=%lld out of range", fn, (long long)B);
+    CRL_REQUIRE(board && winner && to_move, "%s: NULL state pointer", fn);
+    CRL_REQUIRE(action && reward && terminal && winners, "%s: NULL action/output pointer", fn);
+    CRL_REQUIRE(obs_board == nullptr || rel_mod >= 1, "%s: rel_mod must be >= 1 when obs_board is given", fn);
+    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "%s: unknown flags 0x%x", fn, flags);
+    const ttt_dirs dd = dirs_of(ctx);
+    const int rm = rel_mod < 1 ? 1 : rel_mod;
+    TttVec vec = {};
+    if (by_value) {                                             // host-visible state (crl_host_alloc): read here, passed as arguments
+        for (int c = 0; c < dd.n_cells; ++c) {
+            const int v = board[c];
+            if (v >= 0 && v < ctx->ttt.P) vec.occ[v] |= 1u << c;
+        }
+        vec.winner = winner[0]; vec.to_move = to_move[0]; vec.action = action[0];
+    }
+    TTT_DISPATCH_P(ctx->ttt.P, {
+        if (dd.n_dirs <= 4)
+            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags, vec, by_value, flag, seq);
+        else
+            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
+                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags, vec, by_value, flag, seq);
+    });
+    CRL_LAUNCH_CHECK();
+    return CRL_OK;
+}
+
 int crl_ttt_step_board(const crl_ctx *ctx, int64_t B, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
                        int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
                        uint32_t flags, void *stream)
 {
-    TTT_CTX_CHECK("crl_ttt_step_board");
-    CRL_REQUIRE(board && winner && to_move, "crl_ttt_step_board: NULL state pointer");
-    CRL_REQUIRE(action && reward && terminal && winners, "crl_ttt_step_board: NULL action/output pointer");
-    CRL_REQUIRE(obs_board == nullptr || rel_mod >= 1, "crl_ttt_step_board: rel_mod must be >= 1 when obs_board is given");
-    CRL_REQUIRE((flags & ~CRL_STEP_AUTO_RESET) == 0, "crl_ttt_step_board: unknown flags 0x%x", flags);
-    const ttt_dirs dd = dirs_of(ctx);
-    const int rm = rel_mod < 1 ? 1 : rel_mod;
-    TTT_DISPATCH_P(ctx->ttt.P, {
-        if (dd.n_dirs <= 4)
-            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 4>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags);
-        else
-            hipLaunchKernelGGL((ttt_step_board_kernel<PP, 13>), dim3(blocks_for(B, 256)), dim3(256), 0, (hipStream_t)stream, dd, B,
-                               board, winner, to_move, action, reward, terminal, winners, valid, obs_board, rm, flags);
-    });
-    CRL_LAUNCH_CHECK();
-    return CRL_OK;
+    return ttt_step_board_launch("crl_ttt_step_board", ctx, B, board, winner, to_move, action, reward, terminal, winners, valid,
+                                 obs_board, rel_mod, flags, stream, false, nullptr, 0u);
+}
+
+int crl_ttt_step_board_host(const crl_ctx *ctx, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
+                            int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
+                            uint32_t flags, void *stream, uint32_t *flag, uint32_t seq, double timeout_s)
+{
+    CRL_REQUIRE(flag != nullptr, "crl_ttt_step_board_host: flag is NULL");
+    const int rc = ttt_step_board_launch("crl_ttt_step_board_host", ctx, 1, board, winner, to_move, action, reward, terminal, winners,
+                                         valid, obs_board, rel_mod, flags, stream, true, flag, seq);
+    if (rc != CRL_OK) return rc;
+    return crl_spin_mapped(stream, flag, seq, timeout_s, "crl_ttt_step_board_host");
 }
 
 int crl_ttt_observe_board(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *player, int rel_mod,

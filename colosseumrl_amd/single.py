@@ -222,6 +222,10 @@ class SingleTTT(_Single):
         h, s = self._handle, self._stream
         self._a_step = (h, 1, d["board"], d["winner"], d["to_move"], d["action"], d["reward"], d["terminal"],
                         d["winners"], d["valid"], d["obs_board"], int(rel_mod), 0, s)
+        # the one-call form (crl_ttt_step_board_host): only where the mapped blocks have ONE address for host and GPU
+        self._unified = (d["board"].value == v["board"].ctypes.data and self._flag.d["seq"].value == self._flag.v["seq"].ctypes.data)
+        self._a_step_host = (h, d["board"], d["winner"], d["to_move"], d["action"], d["reward"], d["terminal"],
+                             d["winners"], d["valid"], d["obs_board"], int(rel_mod), 0, s, self._flag.d["seq"])
         self._a_valid = (h, 1, d["board"], None, int(rel_mod), None, d["valid"], s)
         self._a_obs = (h, 1, d["board"], d["player"], int(rel_mod), d["obs_board"], d["valid"], s)
 
@@ -234,6 +238,12 @@ class SingleTTT(_Single):
     def step(self, cell: int):
         """next_state + empties mask and observation for the player to move next, one launch."""
         self.v["action"][0] = cell
+        if self._unified:                                        # launch + completion in one call, the state by value
+            self._seq = seq = (self._seq + 1) & 0xFFFFFFFF or 1
+            rc = self._lib.crl_ttt_step_board_host(*self._a_step_host, seq, self.WAIT_TIMEOUT_S)
+            if rc:
+                check(rc, "crl_ttt_step_board_host")
+            return
         rc = self._lib.crl_ttt_step_board(*self._a_step)
         if rc:
             check(rc, "crl_ttt_step_board")

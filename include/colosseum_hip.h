@@ -69,8 +69,8 @@ const char *crl_last_error(void);
  * 100: round 1.  101: crl_tron_stats gained `packed`.  102: TicTacToe sampled agent draws 8 plies per Philox block.
  * 104: round 4.  105: crl_stream_wait_mapped.  106: crl_diag_issue_probe.  107: crl_blokus_fits.  108: crl_diag_bounds.
  * 109: crl_blokus_step / _step_observe place ANY action as the reference's next_state does (numpy index rules, extended ids,
- *      CRL_BLOKUS_*_ERROR codes in the reward slot).  110: crl_tron_next_state_inplace64 (+ _host) / _relative_player_inplace64. */
-#define CRL_ABI_VERSION 110
+ *      CRL_BLOKUS_*_ERROR codes in the reward slot).  110: crl_tron_next_state_inplace64 (+ _host) / _relative_player_inplace64.  111: crl_ttt_step_board_host. */
+#define CRL_ABI_VERSION 111
 int crl_version(void);
 /* number of visible HIP devices, or a negative code */
 int crl_device_count(void);
@@ -336,6 +336,14 @@ int crl_ttt_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t 
 int crl_ttt_step_board(const crl_ctx *ctx, int64_t B, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
                        int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
                        uint32_t flags, void *stream);
+/* The single-state form of crl_ttt_step_board, ONE BLOCKING call for a caller whose state lies in crl_host_alloc memory
+ * (B = 1; as crl_tron_next_state_inplace64_host: every pointer is such memory with one address for host and GPU): the
+ * state -- board, winner, mover, action -- travels BY VALUE in the kernel arguments (no PCIe read before the step) and the
+ * kernel publishes completion itself (`seq` into *flag, on which the host spins; timeout_s as crl_stream_wait_mapped).
+ * Results as crl_ttt_step_board, visible when the call returns. */
+int crl_ttt_step_board_host(const crl_ctx *ctx, int8_t *board, int8_t *winner, int8_t *to_move, const int8_t *action,
+                            int8_t *reward, uint8_t *terminal, int8_t *winners, uint32_t *valid, int8_t *obs_board, int rel_mod,
+                            uint32_t flags, void *stream, uint32_t *flag, uint32_t seq, double timeout_s);
 /* valid_actions (valid uint32 [B] empties mask; may be NULL) and / or state_to_observation (obs_board int8 [B][cells]
  * relative to player[b] modulo rel_mod, absolute ids when player == NULL; may be NULL) of reference-layout boards */
 int crl_ttt_observe_board(const crl_ctx *ctx, int64_t B, const int8_t *board, const int8_t *player, int rel_mod,

@@ -257,3 +257,30 @@ def test_step_observe_fused_matches_separate_calls(dims, K, P, B, rel_mod):
         assert torch.equal(out["valid"], b.valid_mask()), t
         assert torch.equal(out["board"], b.board(b.to_move, rel_mod)), t
     assert int(b.terminal.sum()) >= 0
+
+
+@pytest.mark.parametrize("dims,K,P,rel_mod", [((3, 3), 3, 2, 2), ((3, 5), 3, 3, 3), ((3, 3, 3), 3, 4, 4), ((5, 5), 4, 3, 3), ((4, 8), 4, 8, 8)])
+def test_single_state_one_call_form_matches_the_two_call_form(dims, K, P, rel_mod):
+    """crl_ttt_step_board_host (the state by value in the kernel arguments, completion published by the kernel, one blocking
+    call) against crl_ttt_step_board + crl_stream_wait_mapped on the same states: random games incl. occupied / empty / ''
+    actions and steps after the game has ended."""
+    from colosseumrl_amd.single import SingleTTT
+    rng = np.random.default_rng(sum(dims) + P)
+    one, two = SingleTTT(dims, K, P, rel_mod), SingleTTT(dims, K, P, rel_mod)
+    assert one._unified
+    two._unified = False
+    n = int(np.prod(dims))
+    for game in range(30):
+        board, winner, mover = np.full(n, -1, np.int8), None, 0
+        for ply in range(n + 4):
+            cell = int(rng.integers(-1, n))                       # -1 = '', occupied cells included
+            outs = []
+            for st in (one, two):
+                st.load(board, winner, mover)
+                st.step(cell)
+                v = st.v
+                outs.append((v["board"].copy(), int(v["winner"][0]), int(v["to_move"][0]), int(v["reward"][0]), int(v["terminal"][0]),
+                             int(v["winners"][0]), int(v["valid"][0]), v["obs_board"].copy()))
+            a, b = outs
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (game, ply, cell)
+            board, winner, mover = a[0], (None if a[1] < 0 else a[1]), a[2]
