@@ -2670,10 +2670,13 @@ tron_ranking_wide_kernel(const int NN, const uint32_t inv_cp, const int64_t B, c
 // board bytes (values 0..7) are its selector.  Pure streaming: N*N bytes in, P*N*N bytes out per game.
 template <int P>
 __global__ void __launch_bounds__(256)
-tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs, const bool nt)
+tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs, const bool nt,
+                        const bool wide)
 {
+    // `wide`: the relabelling does not depend on the game a cell belongs to, so the boards of the batch are ONE byte stream and
+    // go 16 bytes at a time whenever the stream (B * N * N bytes, hence every observer's plane) is a whole number of aligned
+    // chunks -- also for boards that are not, like the reference's default 19 x 19 (round 5: 36 -> 20 us at 65,536 games)
     const int64_t total = B * (int64_t)NN;
-    const bool wide = (NN & 15) == 0;
     const int64_t n_items = wide ? total / 16 : total;
     uint32_t lut_lo[P], lut_hi[P];
 #pragma unroll
@@ -2883,6 +2886,169 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
         const int64_t gofs = (g0 + e) * NN + off;
         if (rflag[e]) {                                         // new_state: the fresh board replaces the finished one
             v = tron_fresh_chunk16<P>(cfg, off);
+            *reinterpret_cast<uint4 *>(board + gofs) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            uint4 o;
+            o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
+            o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
+            o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
+            o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+            crl_stream_store16(obs_board + (int64_t)p * plane + gofs, o, nt);
+        }
+    }
+}
+
+// The same fused call for boards that are NOT whole 16-byte chunks -- the reference's default 19 x 19 (361 cells) among them --,
+// round 5.  A workgroup's G boards are ONE contiguous run of G * N * N bytes, a whole number of aligned chunks whatever N is
+// (G = 64 or 16), so they go HBM -> LDS -> HBM 16 bytes at a time as a flat stream: the relabelling of phase C does not care
+// which game a cell belongs to, only the stepping lanes (phase B, byte accesses at e * N * N) and the boards of the games that
+// were reset do -- a chunk may straddle two games there, and takes its fresh bytes per half.  Needs B % 16 == 0 (every
+// workgroup's run, and every observer's plane of the output, then starts on a 16-byte boundary); other batches keep the
+// one-game-per-workgroup kernel below.  65,536 games of 19 x 19: 161 us -> the fused kernel's rate.
+template <int P>
+__device__ __forceinline__ uint4 tron_fresh_flat16(const crl_tron_cfg &cfg, const int r, const int NN)
+{
+    // bytes j = 0..15 of a fresh-board stream starting at cell r of a game: cell (r + j) mod NN
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        int d = (int)cfg.start_heads[p] - r;
+        d += d < 0 ? NN : 0;
+        if (d < 16) {
+            const uint32_t byte = (uint32_t)(p + 1) << ((d & 3) * 8);
+            w[0] |= (d >> 2) == 0 ? byte : 0u;
+            w[1] |= (d >> 2) == 1 ? byte : 0u;
+            w[2] |= (d >> 2) == 2 ? byte : 0u;
+            w[3] |= (d >> 2) == 3 ? byte : 0u;
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int P, int G>
+__global__ void __launch_bounds__(256)
+tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t inv_nn, const int64_t B,
+                              const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
+                              int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                              int8_t *__restrict__ deaths, const int8_t *__restrict__ actions, uint32_t *__restrict__ tcount,
+                              int8_t *__restrict__ rewards, uint8_t *__restrict__ terminal, uint8_t *__restrict__ winners,
+                              int8_t *__restrict__ obs_board, int16_t *__restrict__ oh, int8_t *__restrict__ od,
+                              int8_t *__restrict__ ok, const uint32_t flags)
+{
+    static_assert(P <= 7, "the v_perm relabelling table holds cell values 0..7");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int NN = g.NN;
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);      // a multiple of 16 (B % 16 == 0)
+    const int chunks = (n_game * NN) >> 4;                      // ... so this is exact
+    uint8_t *rflag = lds + ((G * NN + 15) & ~15);               // [G + 1] this game was reset by the step ([n_game] = 0: read, never set)
+    const bool nt = (flags & kStepObserveNT) != 0;
+    const int e = threadIdx.x;
+    const bool stepper = e < G, valid = stepper && e < n_game;
+    const int64_t b = g0 + (valid ? e : 0);
+    TronRegs<P> s;
+    int act[P], rew[P];
+    uint32_t c_in = 0u;
+    if (stepper) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            s.h[p] = valid ? heads[p * B + b] : 0;
+            s.d[p] = valid ? dirs[p * B + b] : 0;
+            s.k[p] = valid ? deaths[p * B + b] : 1;
+            act[p] = (valid && actions) ? actions[p * B + b] : 0;
+        }
+        if (!actions) c_in = valid ? tcount[b] : 0u;
+    }
+    if (threadIdx.x == 0) rflag[G] = 0;
+    // ---- phase A: the workgroup's boards as one stream, HBM -> LDS, up to 4 loads in flight per thread
+    const int8_t *src = board + g0 * NN;
+    for (int base = threadIdx.x; base < chunks; base += 4 * 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * 256;
+            v[u] = *reinterpret_cast<const uint4 *>(src + ((c < chunks ? c : 0) << 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * 256;
+            if (c < chunks) *reinterpret_cast<uint4 *>(lds + (c << 4)) = v[u];
+        }
+    }
+    __syncthreads();
+    // ---- phase B: one lane per game plays the step on its LDS board (byte accesses at e * NN)
+    if (stepper) {
+        if (!actions) {
+            tron_sample_actions<P>((uint32_t)(first_env_id + (uint64_t)b), c_in, seed_lo, seed_hi, act);
+            if (valid) tcount[b] = c_in + 1u;
+        }
+        tron_split_heads<P>(g, s);
+        int term, wm;
+        const DualBoard bd{lds + (valid ? e : 0) * NN, board + b * NN CRL_CELLS_INIT(NN)};
+        tron_step_core<P>(g, bd, valid, s, act, rew, term, wm);
+        const bool do_reset = valid && term && (flags & CRL_STEP_AUTO_RESET);
+        rflag[e] = do_reset ? 1 : 0;
+        if (do_reset) tron_regs_to_start<P>(cfg, g, s);
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                rewards[p * B + b] = (int8_t)rew[p];
+                heads[p * B + b] = (int16_t)s.h[p];
+                dirs[p * B + b] = (int8_t)s.d[p];
+                deaths[p * B + b] = (int8_t)s.k[p];
+            }
+            terminal[b] = (uint8_t)term;
+            winners[b] = (uint8_t)wm;
+#pragma unroll
+            for (int p = 0; p < P; ++p)                         // TronGridEnvironment.py:392-396: rolled so index 0 is the observer
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const int src_p = (i + p) % P;
+                    oh[((int64_t)p * P + i) * B + b] = (int16_t)s.h[src_p];
+                    od[((int64_t)p * P + i) * B + b] = (int8_t)s.d[src_p];
+                    ok[((int64_t)p * P + i) * B + b] = (int8_t)s.k[src_p];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- phase C: stream the P relabelled copies out; the boards of reset games are replaced on the way
+    uint32_t lut_lo[P], lut_hi[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        lut_lo[p] = 0; lut_hi[p] = 0;
+#pragma unroll
+        for (int v = 1; v < 8; ++v) {
+            int n = v - (p + 1);
+            n = n < 0 ? n + P : n;
+            const uint32_t r = (v <= P) ? (uint32_t)(n + 1) : (uint32_t)v;
+            if (v < 4) lut_lo[p] |= r << (8 * v); else lut_hi[p] |= r << (8 * (v - 4));
+        }
+    }
+    const int64_t plane = B * (int64_t)NN;
+    for (int c = threadIdx.x; c < chunks; c += 256) {
+        const int byte0 = c << 4;
+        uint4 v = *reinterpret_cast<const uint4 *>(lds + byte0);
+        const int e0 = (int)__umulhi((uint32_t)byte0, inv_nn);  // game of the chunk's first byte (byte0 < 2^16 * ...: exact)
+        const int r = byte0 - e0 * NN;                          // ... and its cell there
+        const int first = NN - r;                               // bytes of the chunk that still belong to e0 (>= 16: all of them)
+        const bool f0 = rflag[e0] != 0, f1 = first < 16 && rflag[e0 + 1] != 0;
+        const int64_t gofs = g0 * NN + byte0;
+        if (f0 | f1) {                                          // new_state: the fresh board replaces the finished one
+            const uint4 fr = tron_fresh_flat16<P>(cfg, r, NN);
+            uint32_t m[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t mq = 0;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) mq |= ((4 * q + k2 < first) ? f0 : f1) ? (0xffu << (8 * k2)) : 0u;
+                m[q] = mq;
+            }
+            v.x = (v.x & ~m[0]) | (fr.x & m[0]); v.y = (v.y & ~m[1]) | (fr.y & m[1]);
+            v.z = (v.z & ~m[2]) | (fr.z & m[2]); v.w = (v.w & ~m[3]) | (fr.w & m[3]);
+            // (all 16 bytes are this workgroup's: the bytes of a neighbour that was not reset are rewritten with what phase B
+            //  left in LDS and in HBM alike)
             *reinterpret_cast<uint4 *>(board + gofs) = v;
         }
 #pragma unroll
@@ -3564,11 +3730,12 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe_all: boards must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
+    const bool wide = (B * (int64_t)NN) % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0);
+    const int64_t items = wide ? B * (int64_t)NN / 16 : B * (int64_t)NN;
     const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_all_kernel<PP>), dim3(grid), dim3(256), 0, s, NN, B, board, obs_board,
-                           crl_stream_nt((int64_t)(PP + 1) * NN * B, true));
+                           crl_stream_nt((int64_t)(PP + 1) * NN * B, true), wide);
         hipLaunchKernelGGL((tron_observe_all_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, obs_heads, obs_dirs, obs_deaths);
     });
@@ -3622,6 +3789,35 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
         }
         CRL_LAUNCH_CHECK();
         return CRL_OK;
+    }
+    // boards that are not whole 16-byte chunks (19 x 19, the reference's default, among them): the flat-stream kernel, when
+    // the batch is a multiple of 16 games and the buffers are aligned
+    {
+        const int Gf = (64 * NN + 64 + 32 <= 48 * 1024) ? 64 : (16 * NN + 64 + 32 <= 48 * 1024) ? 16 : 0;
+        if ((NN % 16) != 0 && cfg.P <= 7 && Gf > 0 && B % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0)) {
+            const uint32_t inv_nn = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)NN) + 1u;     // exact for byte offsets < 64 * NN
+            const size_t lds_bytes = (size_t)((Gf * NN + 15) & ~15) + Gf + 16;
+            const dim3 grid(blocks_for(B, Gf));
+            const uint32_t kflags = flags | (crl_stream_nt((int64_t)(cfg.P + 1) * NN * B, false) ? kStepObserveNT : 0u);
+            switch (cfg.P) {
+#define CRL_SOF_CASE(P_)                                                                                                   \
+            case P_:                                                                                                      \
+                if (Gf == 64)                                                                                             \
+                    hipLaunchKernelGGL((tron_step_observe_flat_kernel<P_, 64>), grid, dim3(256), lds_bytes, s, cfg, g, inv_nn, B, \
+                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
+                                       actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
+                else                                                                                                      \
+                    hipLaunchKernelGGL((tron_step_observe_flat_kernel<P_, 16>), grid, dim3(256), lds_bytes, s, cfg, g, inv_nn, B, \
+                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
+                                       actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
+                break;
+                CRL_SOF_CASE(1) CRL_SOF_CASE(2) CRL_SOF_CASE(3) CRL_SOF_CASE(4) CRL_SOF_CASE(5) CRL_SOF_CASE(6) CRL_SOF_CASE(7)
+#undef CRL_SOF_CASE
+                default: crl_set_error("tron: P=%d out of range", cfg.P); return CRL_EINVAL;
+            }
+            CRL_LAUNCH_CHECK();
+            return CRL_OK;
+        }
     }
     // every other shape: one game per workgroup, bytes (tron_step_observe_any_kernel)
     CRL_REQUIRE(B < ((int64_t)1 << 31), "crl_tron_step_observe: B too large for the one-game-per-workgroup kernel");

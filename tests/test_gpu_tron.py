@@ -524,7 +524,7 @@ def test_largest_board_and_single_game():
         assert np.array_equal(hip.tb.board.cpu().numpy(), ost.board) and np.array_equal(hip.tb.heads.cpu().numpy(), ost.heads)
 
 
-@pytest.mark.parametrize("N,P,B", [(20, 4, 5000), (9, 6, 777), (13, 8, 300), (40, 4, 1024)])
+@pytest.mark.parametrize("N,P,B", [(20, 4, 5000), (9, 6, 777), (13, 8, 300), (40, 4, 1024), (19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 8, 64)])
 def test_observe_all_matches_per_player_observe(N, P, B):
     """The fused all-observers pass (v_perm table for P <= 7, arithmetic for P = 8, byte path for odd boards)
     equals P single-observer calls, which equal the oracle."""
@@ -546,7 +546,11 @@ def test_observe_all_matches_per_player_observe(N, P, B):
 
 
 @pytest.mark.parametrize("N,P,B", [(20, 4, 5000 + 3), (40, 4, 1000), (12, 3, 300), (28, 7, 130), (8, 2, 65), (4, 2, 70),
-                                   (9, 6, 777), (13, 8, 300), (16, 8, 200)])
+                                   (9, 6, 777), (13, 8, 300), (16, 8, 200),
+                                   # boards that are not whole 16-byte chunks, batches of 16 k games: the flat-stream kernel (64 and
+                                   # 16 games per workgroup, last workgroup of 16 / 32 / 48 games), incl. the reference's default 19 x 19
+                                   (19, 4, 4096 + 16), (19, 3, 1040), (15, 4, 2048 + 48), (39, 4, 528), (9, 6, 784), (5, 2, 96), (21, 7, 400),
+                                   (19, 4, 4096 + 5)])
 def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
     """crl_tron_step_observe (one launch: [sample ->] next_state -> state_to_observation of all P players) equals
     crl_tron_sample + crl_tron_step + crl_tron_observe_all on a twin batch and the oracle stepped in lockstep: 64 and 16
