@@ -429,6 +429,47 @@ tron_reset_board_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t *
     }
 }
 
+// board part of new_state for boards that are NOT whole 16-byte chunks (19 x 19, the reference's default): the boards of the
+// batch are one byte stream, written 16 bytes at a time; a chunk that straddles two games takes the fresh cells of both
+// (tron_fresh_flat16, below), and under a mask its two halves are stored apart when only one of the games is reset.
+// The stream's last odd bytes (B * N * N % 16) go one by one.  (Round 5: 36 -> 10 us at 65,536 games of 19 x 19.)
+template <int P>
+__device__ __forceinline__ uint4 tron_fresh_flat16(const crl_tron_cfg &cfg, const int r, const int NN);
+
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_reset_board_flat_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t *__restrict__ mask, int8_t *__restrict__ board,
+                             const uint64_t inv_nn64)
+{
+    const int NN = cfg.N * cfg.N;
+    const int64_t total = B * (int64_t)NN, chunks = total >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t byte0 = i << 4;
+        const int64_t e0 = (int64_t)__umul64hi((uint64_t)byte0, inv_nn64);      // byte0 / NN (exact: byte0 * NN < 2^64)
+        const int r = (int)(byte0 - e0 * NN);
+        const int first = NN - r;                               // bytes of the chunk that belong to game e0 (>= 16: all)
+        const bool m0 = !mask || mask[e0] != 0;
+        const bool m1 = first >= 16 ? m0 : (!mask || mask[e0 + 1] != 0);
+        if (!(m0 | m1)) continue;
+        const uint4 fr = tron_fresh_flat16<P>(cfg, r, NN);
+        if (m0 & m1) {
+            *reinterpret_cast<uint4 *>(board + byte0) = fr;
+        } else {                                                // one of the two games only: its bytes one by one
+            const uint32_t w[4] = {fr.x, fr.y, fr.z, fr.w};
+            for (int j = m0 ? 0 : first; j < (m0 ? first : 16); ++j) board[byte0 + j] = (int8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        }
+    }
+    for (int64_t i = (chunks << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = (int64_t)__umul64hi((uint64_t)i, inv_nn64);
+        if (mask && !mask[e]) continue;
+        const int c = (int)(i - e * NN);
+        int8_t v = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) v = (cfg.start_heads[p] == c) ? (int8_t)(p + 1) : v;
+        board[i] = v;
+    }
+}
+
 template <int P>
 __global__ void __launch_bounds__(256)
 tron_reset_players_kernel(const crl_tron_cfg cfg, const int64_t B, const uint8_t *__restrict__ mask,
@@ -2470,8 +2511,11 @@ tron_sample_kernel(const int64_t B, const uint32_t seed_lo, const uint32_t seed_
 // ds_read_b64) and relabels 4 cells per v_perm_b32, the board bytes being the selector.
 __global__ void __launch_bounds__(256)
 tron_observe_board_kernel(const int NN, const int P, const uint32_t inv_cp, const bool nt, const int64_t B, const int8_t *__restrict__ board,
-                          const int8_t *__restrict__ player, int8_t *__restrict__ obs)
+                          const int8_t *__restrict__ player, int8_t *__restrict__ obs, const int mode, const uint64_t inv_nn64)
 {
+    // mode 1: boards of whole 16-byte chunks (a chunk belongs to one game); mode 2 (round 5): any other board -- the reference's
+    // default 19 x 19 --, the batch as ONE byte stream in aligned 16-byte chunks, a chunk that straddles two games relabelled for
+    // both observers and merged by a byte mask; mode 0: byte by byte (unaligned buffers, a stream that is not whole chunks)
     __shared__ uint2 lut[CRL_TRON_MAX_P];
     if (threadIdx.x < (unsigned)P) {
         uint32_t lo = 0, hi = 0;
@@ -2484,39 +2528,64 @@ tron_observe_board_kernel(const int NN, const int P, const uint32_t inv_cp, cons
     }
     __syncthreads();
     const int64_t total = B * (int64_t)NN;
-    const bool wide = (NN & 15) == 0;
-    const int64_t n_items = wide ? total / 16 : total;
+    const int64_t n_items = mode ? total / 16 : total;
+    // an observer id outside 0..P-1 is not refused by the reference: the rolled vectors use numpy's modulo
+    // (TronGridEnvironment.py:393), the board goes through C's remainder (CyTronGrid.pyx:1 cdivision=True, :71).
+    // Up to pr = P the operand v - (pr + 1) + P stays >= 0 and both agree (= observer pr mod P: the table);
+    // beyond, low trail ids come out <= 0 -- reproduced by the arithmetic branch
+    auto relabel = [&](const uint32_t (&w)[4], const int pr, uint32_t (&o)[4]) {
+        const int pl = pr + 1;
+        if (P <= 7 && pr <= P) {
+            int pm = pr % P;
+            pm = pm < 0 ? pm + P : pm;
+            const uint2 t = lut[pm];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(t.y, t.x, w[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int s8 = 0; s8 < 32; s8 += 8) {
+                    const int c = (int)(int8_t)((w[q] >> s8) & 0xffu);
+                    const int n = (c - pl + P) % P;                        // CyTronGrid.pyx:70-71, C remainder
+                    r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+                }
+                o[q] = r;
+            }
+        }
+    };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
-        if (wide) {
+        if (mode == 1) {
             const int64_t off = i * 16;
-            // an observer id outside 0..P-1 is not refused by the reference: the rolled vectors use numpy's modulo
-            // (TronGridEnvironment.py:393), the board goes through C's remainder (CyTronGrid.pyx:1 cdivision=True, :71).
-            // Up to pr = P the operand v - (pr + 1) + P stays >= 0 and both agree (= observer pr mod P: the table);
-            // beyond, low trail ids come out <= 0 -- reproduced by the arithmetic branch
-            // the game of chunk i: i / (chunks per board) -- an exact 32-bit multiply-high where the chunk index fits (the
-            // 64-bit division it replaces was a third of this kernel's instructions)
+            // the game of chunk i: i / (chunks per board) -- an exact 32-bit multiply-high where the chunk index fits
             const int64_t game = (i >> 32) == 0 && inv_cp ? (int64_t)__umulhi((uint32_t)i, inv_cp) : off / NN;
-            const int pr = player[game];
-            const int pl = pr + 1;
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
-            if (P <= 7 && pr <= P) {
-                int pm = pr % P;
-                pm = pm < 0 ? pm + P : pm;
-                const uint2 t = lut[pm];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+            relabel(w, player[game], o);
+            crl_stream_store16(obs + off, make_uint4(o[0], o[1], o[2], o[3]), nt);
+        } else if (mode == 2) {
+            const int64_t off = i * 16;
+            const int64_t e0 = (int64_t)__umul64hi((uint64_t)off, inv_nn64);    // off / NN (exact: off * NN < 2^64)
+            const int first = NN - (int)(off - e0 * NN);                        // bytes of the chunk that belong to game e0
+            const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+            const int pr0 = player[e0];
+            relabel(w, pr0, o);
+            if (first < 16) {
+                const int pr1 = player[e0 + 1];
+                if (pr1 != pr0) {
+                    uint32_t o1[4];
+                    relabel(w, pr1, o1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = __builtin_amdgcn_perm(t.y, t.x, w[q]);
-            } else {
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t m = 0;                                         // the bytes of dword q that belong to e0
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint32_t r = 0;
-#pragma unroll
-                    for (int s8 = 0; s8 < 32; s8 += 8) {
-                        const int c = (int)(int8_t)((w[q] >> s8) & 0xffu);
-                        const int n = (c - pl + P) % P;                        // CyTronGrid.pyx:70-71, C remainder
-                        r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+                        for (int k2 = 0; k2 < 4; ++k2) m |= (4 * q + k2 < first) ? (0xffu << (8 * k2)) : 0u;
+                        o[q] = (o[q] & m) | (o1[q] & ~m);
                     }
-                    o[q] = r;
                 }
             }
             crl_stream_store16(obs + off, make_uint4(o[0], o[1], o[2], o[3]), nt);
@@ -2637,6 +2706,81 @@ tron_ranking_wide_kernel(const int NN, const uint32_t inv_cp, const int64_t B, c
             }
             if (n) atomicAdd(&cnt[e][p], n);
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= n_game) return;
+    const int64_t b = g0 + threadIdx.x;
+    int score[P], k[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { score[p] = (int)cnt[threadIdx.x][p]; k[p] = deaths[p * B + b]; }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                // :492-495, ascending like np.where
+        const int via = k[i] > 0 ? k[i] - 1 : P - 1;            // python index -1 = the last player
+        int kvia = 0, other = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            kvia = (q == via) ? k[q] : kvia;
+            other = (k[i] > 0 && q == k[i] - 1) ? score[q] : other;   // alive: scores[-1] is a missing key -> 0
+        }
+        if (kvia == i + 1 && other < score[i]) score[i] = other;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                // :497-506 competition ranking
+        int higher = 0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) higher += score[q] > score[i];
+        rank[i * B + b] = (int8_t)higher;
+    }
+}
+
+// The same for boards that are NOT whole 16-byte chunks (19 x 19, the reference's default): a workgroup's 64 boards are one
+// contiguous, aligned run of bytes and go 16 at a time as a flat stream; a chunk that straddles two games splits its counts
+// by a byte mask.  (Round 5: 32 -> 8 us at 65,536 games of 19 x 19.)
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_ranking_flat_kernel(const int NN, const uint32_t inv_nn, const int64_t B, const int8_t *__restrict__ board,
+                         const int8_t *__restrict__ deaths, int8_t *__restrict__ rank)
+{
+    constexpr int G = 64;
+    __shared__ uint32_t cnt[G + 1][CRL_TRON_MAX_P];
+    for (int i = threadIdx.x; i < (G + 1) * CRL_TRON_MAX_P; i += 256) (&cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int64_t g0 = (int64_t)blockIdx.x * G;
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);
+    const int bytes = n_game * NN, chunks = bytes >> 4;
+    const int8_t *src = board + g0 * NN;                        // 64 * NN bytes per workgroup: a 16-byte boundary
+    for (int c = threadIdx.x; c < chunks; c += 256) {
+        const int byte0 = c << 4;
+        const int e0 = (int)__umulhi((uint32_t)byte0, inv_nn);
+        const int first = NN - (byte0 - e0 * NN);               // bytes of the chunk that belong to game e0 (>= 16: all)
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + byte0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t m[4];                                          // bit 7 of the bytes that belong to e0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t mq = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) mq |= (4 * q + k2 < first) ? (0x80u << (8 * k2)) : 0u;
+            m[q] = mq;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            uint32_t n0 = 0, n1 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = w[q] ^ (0x01010101u * (uint32_t)(p + 1));
+                const uint32_t eq = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & 0x80808080u;   // bit 7 per MATCHING byte
+                n0 += (uint32_t)__popc(eq & m[q]);
+                n1 += (uint32_t)__popc(eq & ~m[q]);
+            }
+            if (n0) atomicAdd(&cnt[e0][p], n0);
+            if (n1) atomicAdd(&cnt[e0 + 1][p], n1);
+        }
+    }
+    for (int i = (chunks << 4) + threadIdx.x; i < bytes; i += 256) {   // the last workgroup's odd bytes
+        const int e = (int)__umulhi((uint32_t)i, inv_nn);
+        const int c = src[i];
+        if (c >= 1 && c <= P) atomicAdd(&cnt[e][c - 1], 1u);
     }
     __syncthreads();
     if ((int)threadIdx.x >= n_game) return;
@@ -3447,10 +3591,13 @@ int crl_tron_reset(const crl_ctx *ctx, int64_t B, const uint8_t *mask,
     const int NN = cfg.N * cfg.N;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (NN % 16 == 0) && (((uintptr_t)board & 15) == 0);
-    const int64_t items = B * (int64_t)(wide ? NN / 16 : NN);
+    const bool flat = !wide && NN >= 16 && (((uintptr_t)board & 15) == 0);        // any other board: the batch as one byte stream
+    const int64_t items = flat ? (B * (int64_t)NN + 15) / 16 : B * (int64_t)(wide ? NN / 16 : NN);
     const unsigned grid = (unsigned)((items + 255) / 256 > 65536 * 4 ? 65536 * 4 : (items + 255) / 256);
+    const uint64_t inv_nn64 = ~(uint64_t)0 / (uint64_t)NN + 1u;                    // floor((2^64 - 1) / NN) + 1: exact quotients for byte offsets < 2^64 / NN
     TRON_DISPATCH_P(cfg.P, {
         if (wide) hipLaunchKernelGGL((tron_reset_board_kernel<PP, true>), dim3(grid), dim3(256), 0, s, cfg, B, mask, board);
+        else if (flat) hipLaunchKernelGGL((tron_reset_board_flat_kernel<PP>), dim3(grid), dim3(256), 0, s, cfg, B, mask, board, inv_nn64);
         else hipLaunchKernelGGL((tron_reset_board_kernel<PP, false>), dim3(grid), dim3(256), 0, s, cfg, B, mask, board);
         hipLaunchKernelGGL((tron_reset_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, cfg, B, mask, heads, dirs, deaths);
     });
@@ -3703,14 +3850,16 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe: boards must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t items = (NN % 16 == 0) ? B * (int64_t)NN / 16 : B * (int64_t)NN;
+    const bool aligned16 = ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0);
+    const int mode = (NN % 16 == 0) ? 1 : (aligned16 && NN >= 16 && (B * (int64_t)NN) % 16 == 0) ? 2 : 0;
+    const int64_t items = mode ? B * (int64_t)NN / 16 : B * (int64_t)NN;
     const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
     // m = floor(2^32 / c) + 1 for c = chunks per board: umulhi(i, m) == i / c for every chunk id i with i * c < 2^32 (the
     // error term m * c - 2^32 is at most c); batches beyond that keep the 64-bit division
     const uint32_t cpb = (uint32_t)(NN / 16);
-    const uint32_t inv_cp = (NN % 16 == 0 && cpb > 1 && (uint64_t)items * cpb < ((uint64_t)1 << 32)) ? (uint32_t)(((uint64_t)1 << 32) / cpb) + 1u : 0u;
+    const uint32_t inv_cp = (mode == 1 && cpb > 1 && (uint64_t)items * cpb < ((uint64_t)1 << 32)) ? (uint32_t)(((uint64_t)1 << 32) / cpb) + 1u : 0u;
     hipLaunchKernelGGL(tron_observe_board_kernel, dim3(grid), dim3(256), 0, s, NN, cfg.P, inv_cp, crl_stream_nt((int64_t)2 * NN * B, true), B,
-                       board, player, obs_board);
+                       board, player, obs_board, mode, ~(uint64_t)0 / (uint64_t)NN + 1u);
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_players_kernel<PP>), dim3(blocks_for(B, 256)), dim3(256), 0, s, B,
                            heads, dirs, deaths, player, obs_heads, obs_dirs, obs_deaths);
@@ -3907,6 +4056,9 @@ int crl_tron_ranking(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
         if (wide)
             hipLaunchKernelGGL((tron_ranking_wide_kernel<PP>), dim3(blocks_for(B, 64)), dim3(256), 0, (hipStream_t)stream,
                                NN, inv_cp, B, board, deaths, rank);
+        else if (NN >= 16 && NN <= 4096 && (((uintptr_t)board & 15) == 0))      // any other board up to 64 x 64: the flat stream
+            hipLaunchKernelGGL((tron_ranking_flat_kernel<PP>), dim3(blocks_for(B, 64)), dim3(256), 0, (hipStream_t)stream,
+                               NN, (uint32_t)(((uint64_t)1 << 32) / (uint64_t)NN) + 1u, B, board, deaths, rank);
         else
             hipLaunchKernelGGL((tron_ranking_kernel<PP>), dim3(blocks_for(B, 4)), dim3(256), 0, (hipStream_t)stream,
                                NN, B, board, deaths, rank);

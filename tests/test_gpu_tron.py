@@ -495,6 +495,36 @@ def test_ranking_golden(golden, name):
     assert np.array_equal(be.tb.ranking().cpu().numpy().T, g["rank"])
 
 
+@pytest.mark.parametrize("N,P,B", [(19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 4, 160), (5, 2, 96), (21, 7, 333), (4, 2, 64), (64, 4, 48)])
+def test_streaming_calls_on_boards_that_are_not_whole_chunks(N, P, B):
+    """crl_tron_reset (all games and masked), crl_tron_observe (a random observer per game, ids outside 0..P-1 among them) and
+    crl_tron_ranking on boards whose N * N is not a multiple of 16 -- the reference's default 19 x 19 among them --, which take
+    the batch as one byte stream in 16-byte chunks that straddle games; batches that are and are not whole chunks."""
+    import torch
+    rng = np.random.default_rng(N * 31 + B)
+    sh, sd = O.tron_start_positions(N, P)
+    hip, orc = HipTron(N, P, B, sh, sd), OracleTron(N, P, B, sh, sd)
+    for rnd in range(3):
+        for t in range(int(rng.integers(3, 12))):
+            a = rng.integers(-1, 2, size=(P, B)).astype(np.int8)
+            hip.step(a), orc.step(a)
+        s1, s2 = hip.state(), orc.state()
+        assert np.array_equal(s1["board"], s2["board"])
+        want = O.tron_ranking(N, P, s2["board"], s2["deaths"])
+        assert np.array_equal(hip.tb.ranking().cpu().numpy(), want), rnd
+        pl = rng.integers(-3, P + 4, size=B).astype(np.int8)
+        ob, oh, od, ok = hip.observe(pl)
+        eb, eh, ed, ek = orc.observe(pl)
+        assert np.array_equal(ob, eb) and np.array_equal(oh, eh) and np.array_equal(od, ed) and np.array_equal(ok, ek), rnd
+        mask = (rng.random(B) < (0.5 if rnd else 0.08)).astype(np.uint8)       # sparse and dense masks: chunk halves stored apart
+        hip.reset(mask), orc.reset(mask)
+        s1, s2 = hip.state(), orc.state()
+        for k in s1:
+            assert np.array_equal(s1[k], s2[k]), (k, rnd)
+    hip.reset(), orc.reset()
+    assert np.array_equal(hip.state()["board"], orc.state()["board"])
+
+
 def test_ranking_full_size_vs_oracle():
     from colosseumrl_amd.batched import TronBatch
     tb = TronBatch(20, 4, 65536)
