@@ -1159,7 +1159,24 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     uint4 cin[kCopyBatch];
     u32x4_a4 rin4[kRowsPerLane];
     uint32_t rin1[kRowsPerLane];
-    if (rows20) {
+    // Boards whose width is not a multiple of four (19 x 19, the reference's default; round 5) move by rows as well: row R of the
+    // wave's 16 * N starts at byte R * N of its run -- any alignment --, so a lane loads the six dwords around it and funnels
+    // them to the row's start (v_alignbyte); the copy back stores a row as leading bytes, aligned dwords, trailing bytes.  Not
+    // for the wave that holds the batch's last bytes when those are not a whole dword (it keeps the byte loop).
+    const bool rowsN = !rows20 && !wide && N >= 4 && N <= 20 && (((uintptr_t)board & 3) == 0) &&
+                       !(env0 + kWaveGames >= B && ((B * (int64_t)NN) & 3) != 0);
+    const int rows_inN = n_env * N;
+    uint32_t rwN[kRowsPerLane][6];
+    if (rowsN) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+            const int R = lane + k * CRL_WAVE;
+            const uint32_t boff = (uint32_t)((R < rows_inN ? R : 0) * N);
+            const int8_t *src = gslab_in + (boff & ~3u);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rwN[k][i] = *reinterpret_cast<const uint32_t *>(src + 4 * i);
+        }
+    } else if (rows20) {
 #pragma unroll
         for (int k = 0; k < kRowsPerLane; ++k) {
             const int R = lane + k * CRL_WAVE;
@@ -1185,14 +1202,16 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     const uint32_t old_n_ep = st.n_episodes[bb], old_len_sum = st.len_sum[bb];
     const uint32_t old_last_w = st.last_winners[bb];
     k = pvalid ? k : 1;                                         // a seat without a player counts as dead for good
-    if (rows20) {
+    if (rows20 || rowsN) {
         // the two wall rows and the junk dword of my game (three dwords per lane), then my rows of the wave's boards
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int dw = 3 * p + i;
-            *(lds_u32 *)(uintptr_t)(uint32_t)(mine + (dw < 6 ? 4 * dw : 21 * RS + 4 * (dw - 6))) = 0xffffffffu;
+            *(lds_u32 *)(uintptr_t)(uint32_t)(mine + (dw < 6 ? 4 * dw : (N + 1) * RS + 4 * (dw - 6))) = 0xffffffffu;
         }
         if (p == 0) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + pad.junk) = 0xffffffffu;
+    }
+    if (rows20) {
 #pragma unroll
         for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
             const int R = lane + k2 * CRL_WAVE;
@@ -1206,13 +1225,33 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
             *(lds_u32 *)(uintptr_t)(uint32_t)(a + 16) = have ? rin1[k2] : 0u;
             *(lds_u32 *)(uintptr_t)(uint32_t)(a + 20) = 0xffffffffu;
         }
-    } else {
+    } else if (!rowsN) {
         // walls everywhere (each lane a quarter of its game's slab), then the cells
         for (int off = 4 * p; off < pad.stride; off += 16) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (rows20) {
+    } else if (rowsN) {
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
+            const int R = lane + k2 * CRL_WAVE;
+            if (R < kWaveGames * N) {
+                const bool have = R < rows_inN;                 // rows of games beyond the batch: empty
+                const uint32_t m8 = ((uint32_t)((have ? R : 0) * N) & 3u);
+                const int e = (int)__umulhi((uint32_t)R, g.inv_n);      // R = N e + y
+                const int a = slab0 + e * pad.stride + (R - N * e + 1) * RS;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    uint32_t d = __builtin_amdgcn_alignbyte(rwN[k2][q + 1], rwN[k2][q], m8);
+                    d = have ? d : 0u;
+                    const int keep = N - 4 * q;                 // cells of this dword that are on the board; the rest is wall
+                    d = keep >= 4 ? d : (keep <= 0 ? 0xffffffffu : (d | (0xffffffffu << (8 * keep))));
+                    *(lds_u32 *)(uintptr_t)(uint32_t)(a + 4 * q) = d;
+                }
+                *(lds_u32 *)(uintptr_t)(uint32_t)(a + 20) = 0xffffffffu;
+            }
+        }
     } else if (wide) {
 #pragma unroll
         for (int k2 = 0; k2 < kCopyBatch; ++k2) {
@@ -1455,7 +1494,81 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);
     constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);
     int8_t *gslab = board + env0 * NN;
-    if (rows20) {
+    if (rowsN) {
+        // a row of N bytes back to byte R * N of the wave's run, whatever its alignment: the bytes up to the next dword
+        // boundary one by one, then aligned dwords (the row's dwords funnelled by that many bytes), then the rest one by one --
+        // every byte of the run is written by exactly one lane, no store touches a neighbour's bytes
+        const bool flat_out = n_env == kWaveGames && (((uintptr_t)board & 15) == 0);
+        uint32_t c[kRowsPerLane][5], trep[kRowsPerLane];
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
+            const int R = lane + k2 * CRL_WAVE;
+            const int Rc = R < kWaveGames * N ? R : 0;
+            const int e = (int)__umulhi((uint32_t)Rc, g.inv_n);
+            const int sb = slab0 + e * pad.stride;
+            const int a = sb + (Rc - N * e + 1) * RS;
+            trep[k2] = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) c[k2][q] = *(const lds_u32 *)(uintptr_t)(uint32_t)(a + 4 * q);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < kRowsPerLane; ++k2) {
+            const int R = lane + k2 * CRL_WAVE;
+            const uint32_t tr = trep[k2] * 0x01010101u;
+            uint32_t w[6];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const uint32_t diff = ((c[k2][q] >> OB) & TM) ^ tr;
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                w[q] = c[k2][q] & OM & ~(stale * 0xffu);
+            }
+            w[5] = 0u;
+            const int pre = (int)((4u - ((uint32_t)(R * N) & 3u)) & 3u);        // bytes up to the next dword boundary (N >= 4 > pre)
+            const int nb = (N - pre) >> 2, suf = (N - pre) & 3;
+            uint32_t sft[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) sft[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], (uint32_t)pre);
+            uint32_t tail = sft[0];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) tail = (q == nb) ? sft[q] : tail;
+            if (flat_out) {
+                // (a full wave with aligned boards) the rows are packed into ONE flat image of the wave's 16 boards first, in
+                // LDS, over the slabs -- every lane has read its rows by now --, where byte stores cost nothing; the image then
+                // leaves in aligned 16-byte chunks.  Stored straight to HBM the rows' odd leading and trailing bytes made the
+                // copy back 12 us of a 20-step launch at 19 x 19 (against 1.9 us at 20 x 20): partial-line writes.
+                if (R < kWaveGames * N) {
+                    const int fa = slab0 + R * N;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < pre) *(lds_u8 *)(uintptr_t)(uint32_t)(fa + j) = (uint8_t)((w[0] >> (8 * j)) & 0xffu);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        if (q < nb) *(lds_u32 *)(uintptr_t)(uint32_t)(fa + pre + 4 * q) = sft[q];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (j < suf) *(lds_u8 *)(uintptr_t)(uint32_t)(fa + pre + 4 * nb + j) = (uint8_t)((tail >> (8 * j)) & 0xffu);
+                }
+            } else if (R < rows_inN) {
+                int8_t *dst = gslab + R * N;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < pre) dst[j] = (int8_t)((w[0] >> (8 * j)) & 0xffu);
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+                    if (q < nb) *reinterpret_cast<uint32_t *>(dst + pre + 4 * q) = sft[q];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < suf) dst[pre + 4 * nb + j] = (int8_t)((tail >> (8 * j)) & 0xffu);
+            }
+        }
+        if (flat_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 7
+            for (int i = lane; i < NN; i += CRL_WAVE)           // 16 boards = N * N chunks of 16 bytes
+                *reinterpret_cast<crl_u32x4 *>(gslab + 16 * i) = *(const __attribute__((address_space(3))) crl_u32x4 *)(uintptr_t)(uint32_t)(slab0 + 16 * i);
+        }
+    } else if (rows20) {
         uint32_t c[kRowsPerLane][5], trep[kRowsPerLane];
 #pragma unroll
         for (int k2 = 0; k2 < kRowsPerLane; ++k2) {             // all LDS reads in flight, then the arithmetic

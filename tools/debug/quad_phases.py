@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Phase timeline of ONE launch of the lane-per-player byte kernel (diagnostic build: tools/lib_variant.sh stamps tron
 -DCRL_QUAD_STAMPS [-DCRL_QUAD_SKEW=n]; run with CRL_LIB_PATH=build/ab_stamps/libcolosseum_hip.so):
-when, relative to the first wave's entry, the waves enter, have their boards in LDS, finish stepping and end."""
+when, relative to the first wave's entry, the waves enter, have their boards in LDS, finish stepping and end.
+    python tools/debug/quad_phases.py [steps [board width]]"""
 import ctypes as C
 import os
 import sys
@@ -17,8 +18,9 @@ from colosseumrl_amd import _native  # noqa: E402
 from colosseumrl_amd.batched import TronBatch  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 20           # board width (<= 20: the kernel this tool stamps)
 lib = _native.lib()
-tb = TronBatch(20, 4, 65536)
+tb = TronBatch(N, 4, 65536)
 for _ in range(5):
     tb.rollout(T, 0)
 torch.cuda.synchronize()
