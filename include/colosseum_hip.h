@@ -238,8 +238,10 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
  * with actions == NULL meaning "draw them with the rollout's random agent at tcount[b] and advance tcount" (tcount may be
  * NULL when actions are given; it is not touched then).  The boards are read from HBM once (coalesced, into LDS),
  * stepped there, and the P relabelled copies streamed out: N*N bytes in + P*N*N bytes out per game.  Boards with
- * N*N % 16 != 0 (the reference's default 19x19 among them), P = 8, or too large for 16 LDS slabs take a second kernel
- * with one game per workgroup and byte accesses: still one launch, same results, actions == NULL allowed. */
+ * N*N % 16 != 0 (the reference's default 19x19 among them) take the same route as one flat byte stream per workgroup when the
+ * batch is a multiple of 16 games and the board buffers are 16-byte aligned; other batches of such boards, P = 8, or boards too
+ * large for 16 LDS slabs take a kernel with one game per workgroup and byte accesses: still one launch, same results,
+ * actions == NULL allowed. */
 int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t first_env_id,
                           int8_t *board, int16_t *heads, int8_t *dirs, int8_t *deaths,
                           const int8_t *actions, uint32_t *tcount,
