@@ -820,6 +820,17 @@ def step_api_rates(torch, device, copy_gbs, write_gbs=None):
     wall, gpu = rate(lambda: tb.ranking(), 200)
     out["tron_n20_ranking"] = {"games_per_s": B / wall, "gpu_us_per_call": gpu * 1e6}
     del tb, buf, acts
+    # the reference's DEFAULT board: 19 x 19 = 361 cells, not a whole number of 16-byte chunks (the flat-stream kernels)
+    t19 = TronBatch(19, P, B, device=device)
+    f19 = t19.step_observe(None, seed=7, out=None)
+    wall, gpu = rate(lambda: t19.step_observe(None, seed=7, out=f19), 300)
+    nb19 = (1 + P) * 361 * B
+    out["tron_n19_step_observe_fused"] = {"env_steps_per_s": B / wall, "gpu_us_per_call": gpu * 1e6, "GBs": nb19 / gpu / 1e9,
+                                          "frac_of_hbm_peak": nb19 / gpu / 1e9 / HBM_PEAK_GBS,
+                                          "what": "the same ONE launch on the reference's default 19x19 board (361 cells per game: chunks straddle games)"}
+    wall, gpu = rate(lambda: t19.rollout(20, 3), 300)
+    out["tron_n19_rollout20"] = {"env_steps_per_s": 20 * B / wall, "gpu_us_per_call": gpu * 1e6, "what": "a 20-step fused rollout launch at 19x19"}
+    del t19, f19
     Bt = 262144
     tt = TTTBatch((3, 5), 3, 3, Bt, device=device)
     a = torch.randint(0, 15, (Bt,), dtype=torch.int8, device=device)
@@ -1023,7 +1034,7 @@ def compact_summary(out):
     for name, rec in out.get("others", {}).items():
         sm[name] = wl(rec)
     sa = out.get("step_api", {})
-    pick = {"tron_step": "tron_n20_step_auto_reset", "tron_step_observe": "tron_n20_step_observe_fused",
+    pick = {"tron_step": "tron_n20_step_auto_reset", "tron_step_observe": "tron_n20_step_observe_fused", "tron19_step_observe": "tron_n19_step_observe_fused",
             "tron_observe_all": "tron_n20_observe_all", "ttt_step_observe": "ttt_3x5_step_observe_fused",
             "blokus_step_observe": "blokus_step_observe_fused", "blokus_valid_list": "blokus_valid_list"}
     if sa:
