@@ -3028,6 +3028,26 @@ struct DualBoard {                  // step on the LDS copy, mirror the trail wr
     __device__ __forceinline__ void put(const int c, const int who) const { CRL_CELLS_CHECK(c, 133); l[c] = (uint8_t)who; g[c] = (int8_t)who; }
 };
 
+// four cells of an observation for observer p: ONE v_perm_b32 through the 8-entry table when P <= 7; with eight players the
+// cell values 0..8 do not fit it and the bytes are relabelled by arithmetic (CyTronGrid.pyx:70-71)
+template <int P>
+__device__ __forceinline__ uint32_t tron_relabel4(const uint32_t w, const int p, const uint32_t lut_lo, const uint32_t lut_hi)
+{
+    if constexpr (P <= 7) {
+        return __builtin_amdgcn_perm(lut_hi, lut_lo, w);
+    } else {
+        uint32_t r = 0;
+#pragma unroll
+        for (int s8 = 0; s8 < 32; s8 += 8) {
+            const int c = (int)((w >> s8) & 0xffu);
+            int n = c - (p + 1);
+            n = n < 0 ? n + P : n;
+            r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
+        }
+        return r;
+    }
+}
+
 constexpr uint32_t kStepObserveNT = 0x80000000u;            // kernel-side flag bit next to CRL_STEP_AUTO_RESET
 
 template <int P, int G>
@@ -3040,7 +3060,6 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
                          int8_t *__restrict__ obs_board, int16_t *__restrict__ oh, int8_t *__restrict__ od,
                          int8_t *__restrict__ ok, const uint32_t flags)
 {
-    static_assert(P <= 7, "the v_perm relabelling table holds cell values 0..7");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int NN = g.NN, SLAB = NN + 16;                        // NN % 16 == 0: 16-byte LDS accesses stay aligned
     const int cp = NN >> 4;                                     // 16-byte chunks per board
@@ -3148,10 +3167,10 @@ tron_step_observe_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             uint4 o;
-            o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
-            o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
-            o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
-            o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+            o.x = tron_relabel4<P>(v.x, p, lut_lo[p], lut_hi[p]);
+            o.y = tron_relabel4<P>(v.y, p, lut_lo[p], lut_hi[p]);
+            o.z = tron_relabel4<P>(v.z, p, lut_lo[p], lut_hi[p]);
+            o.w = tron_relabel4<P>(v.w, p, lut_lo[p], lut_hi[p]);
             crl_stream_store16(obs_board + (int64_t)p * plane + gofs, o, nt);
         }
     }
@@ -3194,7 +3213,6 @@ tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const ui
                               int8_t *__restrict__ obs_board, int16_t *__restrict__ oh, int8_t *__restrict__ od,
                               int8_t *__restrict__ ok, const uint32_t flags)
 {
-    static_assert(P <= 7, "the v_perm relabelling table holds cell values 0..7");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int NN = g.NN;
     const int64_t g0 = (int64_t)blockIdx.x * G;
@@ -3311,10 +3329,10 @@ tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const ui
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             uint4 o;
-            o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
-            o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
-            o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
-            o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+            o.x = tron_relabel4<P>(v.x, p, lut_lo[p], lut_hi[p]);
+            o.y = tron_relabel4<P>(v.y, p, lut_lo[p], lut_hi[p]);
+            o.z = tron_relabel4<P>(v.z, p, lut_lo[p], lut_hi[p]);
+            o.w = tron_relabel4<P>(v.w, p, lut_lo[p], lut_hi[p]);
             crl_stream_store16(obs_board + (int64_t)p * plane + gofs, o, nt);
         }
     }
@@ -4027,7 +4045,7 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
     // everything else takes the same three kernels the separate entry points launch (identical results either way)
     const int slab = NN + 16;
     const int G = (64 * slab + 64 <= 48 * 1024) ? 64 : (16 * slab + 16 <= 48 * 1024) ? 16 : 0;
-    if ((NN % 16) == 0 && cfg.P <= 7 && G > 0) {
+    if ((NN % 16) == 0 && cfg.P <= 8 && G > 0) {
         // floor(2^32 / chunks per board) + 1: exact quotients for chunk ids < 2^16 (one chunk per board: unused)
         const uint32_t inv_cp = NN == 16 ? 0u : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(NN / 16)) + 1u;
         const size_t lds_bytes = (size_t)G * slab + G;
@@ -4045,7 +4063,7 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
                                    (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,     \
                                    actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
             break;
-            CRL_SO_CASE(1) CRL_SO_CASE(2) CRL_SO_CASE(3) CRL_SO_CASE(4) CRL_SO_CASE(5) CRL_SO_CASE(6) CRL_SO_CASE(7)
+            CRL_SO_CASE(1) CRL_SO_CASE(2) CRL_SO_CASE(3) CRL_SO_CASE(4) CRL_SO_CASE(5) CRL_SO_CASE(6) CRL_SO_CASE(7) CRL_SO_CASE(8)
 #undef CRL_SO_CASE
             default: crl_set_error("tron: P=%d out of range", cfg.P); return CRL_EINVAL;
         }
@@ -4056,7 +4074,7 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
     // the batch is a multiple of 16 games and the buffers are aligned
     {
         const int Gf = (64 * NN + 64 + 32 <= 48 * 1024) ? 64 : (16 * NN + 64 + 32 <= 48 * 1024) ? 16 : 0;
-        if ((NN % 16) != 0 && cfg.P <= 7 && Gf > 0 && B % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0)) {
+        if ((NN % 16) != 0 && cfg.P <= 8 && Gf > 0 && B % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0)) {
             const uint32_t inv_nn = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)NN) + 1u;     // exact for byte offsets < 64 * NN
             const size_t lds_bytes = (size_t)((Gf * NN + 15) & ~15) + Gf + 16;
             const dim3 grid(blocks_for(B, Gf));
@@ -4073,7 +4091,7 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
                                        (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
                                        actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
                 break;
-                CRL_SOF_CASE(1) CRL_SOF_CASE(2) CRL_SOF_CASE(3) CRL_SOF_CASE(4) CRL_SOF_CASE(5) CRL_SOF_CASE(6) CRL_SOF_CASE(7)
+                CRL_SOF_CASE(1) CRL_SOF_CASE(2) CRL_SOF_CASE(3) CRL_SOF_CASE(4) CRL_SOF_CASE(5) CRL_SOF_CASE(6) CRL_SOF_CASE(7) CRL_SOF_CASE(8)
 #undef CRL_SOF_CASE
                 default: crl_set_error("tron: P=%d out of range", cfg.P); return CRL_EINVAL;
             }

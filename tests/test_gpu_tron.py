@@ -580,7 +580,9 @@ def test_observe_all_matches_per_player_observe(N, P, B):
                                    # boards that are not whole 16-byte chunks, batches of 16 k games: the flat-stream kernel (64 and
                                    # 16 games per workgroup, last workgroup of 16 / 32 / 48 games), incl. the reference's default 19 x 19
                                    (19, 4, 4096 + 16), (19, 3, 1040), (15, 4, 2048 + 48), (39, 4, 528), (9, 6, 784), (5, 2, 96), (21, 7, 400),
-                                   (19, 4, 4096 + 5)])
+                                   (19, 4, 4096 + 5),
+                                   # eight players: the fused kernels relabel by arithmetic (cell values 0..8 do not fit the permute table)
+                                   (20, 8, 1024 + 7), (19, 8, 1024), (40, 8, 160)])
 def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
     """crl_tron_step_observe (one launch: [sample ->] next_state -> state_to_observation of all P players) equals
     crl_tron_sample + crl_tron_step + crl_tron_observe_all on a twin batch and the oracle stepped in lockstep: 64 and 16
