@@ -20,6 +20,8 @@ bad, t0 = 0, time.time()
 for case in range(n_cases):
     N, P, B = int(rng.integers(4, 41)), int(rng.integers(2, 9)), int(rng.integers(1, 2500))
     P = min(P, 4) if N == 4 else P
+    if rng.random() < 0.35:
+        B = (B // 16 + 1) * 16                                  # whole 16-game groups: the flat-stream kernels of boards like 19 x 19
     T, seed, first = int(rng.integers(1, 40)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
     a, b, c = (TronBatch(N, P, B, first_env_id=first) for _ in range(3))
     step_kernel = ("auto", "bytes", "staged")[case % 3]        # crl_tron_step's interchangeable kernels (staged: where the board allows)
