@@ -382,7 +382,9 @@ def test_rollout_full_size_properties(N, T):
     assert torch.equal(half.n_episodes, tb.n_episodes[B // 2:])
 
 
-@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (20, (20, 12), "qbits"), (40, (32,), "auto"), (40, (32,), "bytes"), (40, (300,), "auto"), (40, (300,), "bits")])
+@pytest.mark.parametrize("N,chunks,kernel", [(20, (32,), "auto"), (20, (20, 12), "quad"), (20, (20, 12), "bits"), (20, (20, 12), "bytes"), (20, (20, 12), "qbits"), (40, (32,), "auto"), (40, (32,), "bytes"), (40, (300,), "auto"), (40, (300,), "bits"),
+                                                 # the reference's default 19 x 19 (rows at any alignment, flat copy back) and 15 x 15
+                                                 (19, (20, 17), "auto"), (15, (20, 9), "quad")])
 def test_rollout_full_size_vs_oracle(N, chunks, kernel):
     """BASELINE config 2 / the config-5 shard at FULL size (B = 65,536, P = 4) against the oracle itself, not only through
     invariants: every state array and every statistic, bit for bit (the oracle needs ~10-100 ms per launch on 8 threads).
