@@ -3810,7 +3810,13 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const bool small = cfg.N <= kLdsMaxNSmall;
     const int RS = small ? kRowBytesSmall : kRowBytesLarge;
     const TronPad pad = pad_of(cfg, RS);
-    const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
+    // Short launches on boards above 20x20 with at most 4 players stay in global memory unless a kernel is pinned: the
+    // bitboard kernel's fixed cost (boards to bits, replay on byte slabs, boards back) is 64-109 us at 65,536 games of
+    // 24x24..40x40 against 28-60 us for one step of the global kernel, which adds 3-4 us per step where the bitboards add 0.5:
+    // they cross at ~24 steps (profiles/r5_shape_sweep.txt)
+    const bool short_large = !small && cfg.P <= 4 && T <= 20 &&
+                             !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS));
+    const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !short_large && cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
     // default: bitboards where they buy residency (boards above 20x20 fit 4x the games per CU); on small boards the
     // byte kernel already has every game resident and no replay to pay for
     const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || (!small && T >= 256));

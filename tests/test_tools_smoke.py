@@ -57,6 +57,8 @@ GPU_RUNS = [
     (["tools/debug/host_latency.py"], "region raw"),
     (["tools/debug/step_ab.py", "quick"], "staged_over_bytes"),
     (["tools/debug/dropin_breakdown.py", "200"], "env_next_state"),
+    (["tools/debug/shape_sweep.py", "19,24", "4", "4096,4099"], " 24  4    4099"),
+    (["tools/debug/shape_sweep.py", "kernels", "24", "1,8", "4096"], "N=24 global"),
     (["examples/dropin_game.py", "tron", "1"], "ranking"),
     (["examples/dropin_game.py", "blokus", "2"], "ranking"),
     (["examples/dropin_game.py", "tictactoe_4p", "3"], "ranking"),
