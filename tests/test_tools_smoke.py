@@ -59,6 +59,7 @@ GPU_RUNS = [
     (["tools/debug/dropin_breakdown.py", "200"], "env_next_state"),
     (["tools/debug/shape_sweep.py", "19,24", "4", "4096,4099"], " 24  4    4099"),
     (["tools/debug/shape_sweep.py", "kernels", "24", "1,8", "4096"], "N=24 global"),
+    (["tools/debug/shape_sweep.py", "others", "quick"], "    257 |"),
     (["examples/dropin_game.py", "tron", "1"], "ranking"),
     (["examples/dropin_game.py", "blokus", "2"], "ranking"),
     (["examples/dropin_game.py", "tictactoe_4p", "3"], "ranking"),

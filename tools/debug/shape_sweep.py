@@ -4,8 +4,11 @@ kernels?  Prints, per (N, P, B), microseconds per call (median of back-to-back l
 20-step rollout, a 512-step rollout (per step), step, step_observe, observe_all, observe, ranking and reset.
     python tools/debug/shape_sweep.py [N,N,...] [P,P,...] [B,B,...] [json path]
     python tools/debug/shape_sweep.py kernels [N,N,...] [T,T,...] [B]
+    python tools/debug/shape_sweep.py others [quick]
 `kernels`: the interchangeable rollout kernels ("auto" = the library's choice, "qbits", "bits", "bytes", "global") against the
-launch length at P = 4 -- where the fixed cost of an LDS-resident launch (copy in, replay, copy out) is worth it."""
+launch length at P = 4 -- where the fixed cost of an LDS-resident launch (copy in, replay, copy out) is worth it.
+`others`: TicTacToe over ten board shapes and Blokus over batch sizes, whole and ragged batches (no cliffs: +10-15 % for a
+ragged batch's extra workgroup)."""
 import json
 import os
 import sys
@@ -16,7 +19,54 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from colosseumrl_amd.batched import TronBatch
 
+def timed(fn, reps=10, rounds=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 arg = sys.argv[1:]
+if arg and arg[0] == "others":
+    from colosseumrl_amd.batched import TTTBatch, BlokusBatch
+    dev = torch.device("cuda", 0)
+    QUICK = len(arg) > 1 and arg[1] == "quick"
+    print("TTT: dims k P B | roll8 roll512/step step_observe sample+step")
+    SHAPES = (((3, 3), 3, 2), ((3, 5), 3, 3), ((3, 3, 3), 3, 4), ((5, 5), 4, 3), ((4, 4), 3, 2), ((4, 4), 4, 2), ((6, 5), 4, 3),
+              ((4, 8), 4, 4), ((2, 4, 4), 3, 3), ((5, 6), 5, 2))
+    for dims, k, P in (SHAPES[:2] if QUICK else SHAPES):
+        for B in ((4096, 4097) if QUICK else (262144, 262145, 1000)):
+            st = TTTBatch(dims, k, P, B, device=dev)
+            r8 = timed(lambda: st.rollout(8, 1))
+            r512 = timed(lambda: st.rollout(512, 1), reps=2, rounds=3) / 512
+            so = timed(lambda: st.step_observe(None, 1, True))
+            ss = timed(lambda: st.step(st.sample(1), auto_reset=True))
+            print("%-10s k%d P%d %7d | %8.1f %8.4f %8.1f %8.1f" % (dims, k, P, B, r8, r512, so, ss), flush=True)
+            del st
+    print("Blokus: B | roll8 roll64/step step_observe valid_list select")
+    for B in ((256, 257) if QUICK else (16384, 16385, 16387, 1000, 4096, 65536)):
+        st = BlokusBatch(B, device=dev)
+        st.rollout(24, 3)
+        r8 = timed(lambda: st.rollout(8, 1), reps=3, rounds=3)
+        r64 = timed(lambda: st.rollout(64, 1), reps=1, rounds=3) / 64
+        so = timed(lambda: st.step_observe(None, 1, True), reps=5, rounds=3)
+        out = torch.empty((B, 2048), dtype=torch.int32, device=dev)
+        vl = timed(lambda: st.valid_list(2048, None, out), reps=5, rounds=3)
+        rank = torch.zeros((B,), dtype=torch.int32, device=dev)
+        se = timed(lambda: st.select(rank), reps=5, rounds=3)
+        print("%7d | %8.1f %8.2f %8.1f %8.1f %8.1f" % (B, r8, r64, so, vl, se), flush=True)
+        del st, out
+    sys.exit(0)
 if arg and arg[0] == "kernels":
     dev = torch.device("cuda", 0)
     Ns = [int(x) for x in (arg[1] if len(arg) > 1 else "20,21,24,28,32,39,40").split(",")]
@@ -48,23 +98,6 @@ PS = [int(x) for x in (arg[1] if len(arg) > 1 else "2,3,4,6,8").split(",")]
 BS = [int(x) for x in (arg[2] if len(arg) > 2 else "65536,65553").split(",")]
 OUT = arg[3] if len(arg) > 3 else None
 dev = torch.device("cuda", 0)
-
-
-def timed(fn, reps=10, rounds=5):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(rounds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
-    ts.sort()
-    return ts[len(ts) // 2]
 
 
 rows = []
