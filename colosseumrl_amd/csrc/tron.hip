@@ -2628,7 +2628,7 @@ tron_observe_board_kernel(const int NN, const int P, const uint32_t inv_cp, cons
 {
     // mode 1: boards of whole 16-byte chunks (a chunk belongs to one game); mode 2 (round 5): any other board -- the reference's
     // default 19 x 19 --, the batch as ONE byte stream in aligned 16-byte chunks, a chunk that straddles two games relabelled for
-    // both observers and merged by a byte mask; mode 0: byte by byte (unaligned buffers, a stream that is not whole chunks)
+    // both observers and merged by a byte mask, the last bytes of a stream that is not whole chunks one by one; mode 0: byte by byte (unaligned buffers)
     __shared__ uint2 lut[CRL_TRON_MAX_P];
     if (threadIdx.x < (unsigned)P) {
         uint32_t lo = 0, hi = 0;
@@ -2708,6 +2708,14 @@ tron_observe_board_kernel(const int NN, const int P, const uint32_t inv_cp, cons
             const int n = (c - pl + P) % P;                                    // C remainder, as above
             obs[i] = (int8_t)(c > 0 ? n + 1 : c);
         }
+    }
+    // mode 2 on a stream that is not whole chunks (a batch that is not a multiple of 16 games): its last bytes one by one
+    if (mode == 2 && blockIdx.x == 0 && (int64_t)threadIdx.x < total - n_items * 16) {
+        const int64_t i = n_items * 16 + threadIdx.x;
+        const int pl = (int)player[i / NN] + 1;
+        const int c = board[i];
+        const int n = (c - pl + P) % P;
+        obs[i] = (int8_t)(c > 0 ? n + 1 : c);
     }
 }
 
@@ -3988,9 +3996,9 @@ int crl_tron_observe(const crl_ctx *ctx, int64_t B, const int8_t *board, const i
     CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe: boards must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const bool aligned16 = ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0);
-    const int mode = (NN % 16 == 0) ? 1 : (aligned16 && NN >= 16 && (B * (int64_t)NN) % 16 == 0) ? 2 : 0;
+    const int mode = (NN % 16 == 0) ? 1 : (aligned16 && NN >= 16) ? 2 : 0;
     const int64_t items = mode ? B * (int64_t)NN / 16 : B * (int64_t)NN;
-    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256 < 1 ? 1 : (items + 255) / 256);
     // m = floor(2^32 / c) + 1 for c = chunks per board: umulhi(i, m) == i / c for every chunk id i with i * c < 2^32 (the
     // error term m * c - 2^32 is at most c); batches beyond that keep the 64-bit division
     const uint32_t cpb = (uint32_t)(NN / 16);

@@ -497,7 +497,8 @@ def test_ranking_golden(golden, name):
     assert np.array_equal(be.tb.ranking().cpu().numpy().T, g["rank"])
 
 
-@pytest.mark.parametrize("N,P,B", [(19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 4, 160), (5, 2, 96), (21, 7, 333), (4, 2, 64), (64, 4, 48)])
+@pytest.mark.parametrize("N,P,B", [(19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 4, 160), (5, 2, 96), (21, 7, 333), (4, 2, 64), (64, 4, 48),
+                                   (19, 4, 1), (17, 4, 7), (5, 2, 1), (23, 8, 65)])
 def test_streaming_calls_on_boards_that_are_not_whole_chunks(N, P, B):
     """crl_tron_reset (all games and masked), crl_tron_observe (a random observer per game, ids outside 0..P-1 among them) and
     crl_tron_ranking on boards whose N * N is not a multiple of 16 -- the reference's default 19 x 19 among them --, which take
