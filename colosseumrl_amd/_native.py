@@ -24,6 +24,7 @@ CRL_ROLLOUT_BYTES = 4
 CRL_ROLLOUT_BITS = 8
 CRL_ROLLOUT_QUAD = 16
 CRL_ROLLOUT_QBITS = 32
+CRL_ROLLOUT_GQUAD = 64
 
 _lib = None
 _lock = threading.Lock()

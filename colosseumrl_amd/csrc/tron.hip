@@ -13,20 +13,22 @@
 // heads) and patches same-step interactions in registers, so it costs one round of loads and one
 // round of stores instead of P dependent round trips.
 //
-// Five interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
+// Six interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
 //   * lane per PLAYER, four lanes per game (at most 4 players; the defaults where they apply): the quad shares what is
 //     per game by DPP (alive count, random stream, reset), the reference's sequential order is resolved only on the
 //     ~1 % of wave-steps where players interact.  64 games per workgroup, 4 waves per SIMD:
 //       - tron_rollout_quad_kernel, LDS byte slabs, boards up to 20x20;
-//       - tron_rollout_qbits_kernel, LDS bitboards + replay epilogue, boards up to 40x40 (default for 21..40).
+//       - tron_rollout_qbits_kernel, LDS bitboards + replay epilogue, boards up to 40x40 (default for 21..40);
+//       - tron_rollout_gquad_kernel, boards in global memory, no tags, no copies: no fixed cost per launch (launches too
+//         short to earn the LDS kernels' copies back; boards above 40x40).
 //   * lane per GAME (more than 4 players; or pinned):
 //       - LDS byte slabs (boards up to 20x20: 256 games per workgroup; up to 40x40: 64): every wave copies its boards
 //         into LDS once, plays all T steps there (wall-bordered slabs, heads as LDS addresses, episode-tagged cells
 //         with a rolling one-row rewrite instead of board clears), and writes the boards back once;
 //       - LDS bitboards + replay (above 20x20, T >= 256): occupancy only while playing, deaths as lane masks; the
 //         unfinished episode is replayed on byte slabs at the end to recover owners.
-//   * global-memory (boards above 40x40): boards stay in HBM / Infinity Cache, same tagged cells, tags stripped
-//     in place at the end.
+//   * global-memory, lane per game (more than 4 players or long launches on boards above 44x44): boards stay in HBM /
+//     Infinity Cache, same tagged cells, tags stripped in place at the end.
 // plus crl_tron_ranking (compute_ranking, TronGridEnvironment.py:483-508), one wave per game.
 #include "crl_common.hpp"
 #include <hip/hip_ext.h>
@@ -1662,6 +1664,212 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the stores of this wave have left
 #endif
     QUAD_STAMP(3);
+}
+
+// ---- one lane per player on boards in GLOBAL memory (any board size, P <= 4) --------------------------------------
+// What tron_rollout_quad_kernel is to the byte-slab kernel, this is to tron_rollout_kernel: a lane plays ONE player -- one
+// byte probe, die or move, one byte store per step --, the quad shares what is per game (alive count by two DPP adds, the
+// random stream of tron_quad_actions, the reset), and the reference's sequential order (CyTronGrid.pyx:15-62) is resolved,
+// redundantly in the quad's four lanes on DPP-gathered copies, only in the wave-steps where a target meets another player's
+// head or target.  65,536 games are 4,096 waves (4 per SIMD) instead of 1,024: a step is bound by the latency of its probe,
+// and four times the waves hide four times as much of it.  No tags and no pass over the boards at either end of the launch:
+// a game that ends is rewritten with the start layout by the WHOLE wave (16-byte stores between the board's unaligned ends),
+// so a launch costs what its steps cost -- which is what short launches on boards that do not fit the byte slabs want
+// (crl_tron_rollout: boards above 20x20 up to ~96 steps, boards above 40x40 always; profiles/r5_shape_sweep.txt).
+// Cross-lane traffic through memory (a cell one lane stamps is probed by another lane of the wave in a later step; a reset's
+// stores come from all lanes) relies on what the lane-per-game kernel relies on: one wave's vector memory operations reach
+// its CU's cache in program order.
+template <int P>
+__global__ void __launch_bounds__(256)
+tron_rollout_gquad_kernel(const crl_tron_cfg cfg, const TronGeom g, const int64_t B,
+                          const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                          int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                          int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    static_assert(P <= 4, "one lane per player, four lanes per game");
+    constexpr int kGames = 64, kWaveGames = 16;
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN;
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int p = lane & 3;                                     // my player
+    const int slot = threadIdx.x >> 2;
+    const int64_t b = (int64_t)blockIdx.x * kGames + slot;
+    const bool gvalid = b < B;
+    const bool seat = p < P;                                    // this lane has a player at all
+    const bool pvalid = gvalid && seat;
+    const int64_t bb = gvalid ? b : 0;
+    const int64_t env0 = (int64_t)blockIdx.x * kGames + wave * kWaveGames;   // first game of this wave
+    uint8_t *gb = reinterpret_cast<uint8_t *>(board) + bb * NN;  // my game's board
+    // (unconditional loads from a clamped index, as in the byte-slab kernel)
+    const int64_t pb = (int64_t)(seat ? p : 0) * B + bb;
+    const int h_in = heads[pb];
+    const int d_in = dirs[pb];
+    int k = deaths[pb];
+    const int old_ret = st.ret_sum[pb];
+    const uint32_t old_wins = st.win_count[pb];
+    uint32_t tc = st.tcount[bb], ts = st.tstep[bb];
+    const uint32_t old_n_ep = st.n_episodes[bb], old_len_sum = st.len_sum[bb];
+    const uint32_t old_last_w = st.last_winners[bb];
+    k = pvalid ? k : 1;                                         // a seat without a player counts as dead for good
+    int fh = cfg.start_heads[0], fd = cfg.start_dirs[0];
+    fh = (p == 1) ? cfg.start_heads[1] : fh; fd = (p == 1) ? cfg.start_dirs[1] : fd;
+    fh = (p == 2) ? cfg.start_heads[2] : fh; fd = (p == 2) ? cfg.start_dirs[2] : fd;
+    fh = (p == 3) ? cfg.start_heads[3] : fh; fd = (p == 3) ? cfg.start_dirs[3] : fd;
+    fh = seat ? fh : 0;
+    const int fy = (int)__umulhi((uint32_t)fh, g.inv_n), fx = fh - fy * N;
+    const int fresh_a = pvalid ? 1 : 0;
+    // a head that is not a cell of the board never equals a target: seats without a player carry one of their own
+    const int no_head = -6 - p, no_tgt = -2 - p;
+    int h = seat ? min(max(h_in, 0), NN - 1) : no_head;
+    int hy = seat ? (int)__umulhi((uint32_t)h, g.inv_n) : 0, hx = seat ? h - hy * N : 0;
+    int d = d_in & 3;
+    uint32_t alive_steps = 0, wn = 0, marks = 0;                // as in tron_rollout_quad_kernel
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+    __syncthreads();                                            // action table
+    uint32_t a_lo = 0, a_hi = 0;
+    auto refill = [&](const uint32_t group) { tron_quad_actions(gid, group, p, seed_lo, seed_hi, act_lut, a_lo, a_hi); };
+    refill(tc >> 5);
+    uint32_t acts = ((tc & 16u) ? a_hi : a_lo) >> ((tc & 15u) * 2u);   // bits 1:0 = this step's action code (0, 1, 3)
+    uint32_t dry2 = 32u - 2u * (tc & 15u);                      // `acts` runs dry after dry2 / 2 steps of this launch
+    int neg2 = -(int)dry2;
+    const uint32_t tc_in = tc;
+    int a = (k == 0) ? 1 : 0;
+    for (int t = 0; t < T; ++t) {
+        const bool run = a != 0;
+        const int dir = (d + (int)(acts & 3u)) & 3;
+        const int sh8 = dir << 3;
+        const int nx = hx + __builtin_amdgcn_sbfe((int)0xff000100u, sh8, 8);
+        const int ny = hy + __builtin_amdgcn_sbfe((int)0x000100ffu, sh8, 8);
+        const bool oob = ((unsigned)nx >= (unsigned)N) | ((unsigned)ny >= (unsigned)N);
+        const int tgt = (int)(__umul24((unsigned)ny, (unsigned)N) + (unsigned)nx);
+        const bool look = run & !oob;
+        CRL_BOUNDS_LT(look ? tgt : 0, NN, 138);                 // the probe stays on my game's board
+        const int raw = gb[look ? tgt : 0];                     // (a player that does not look reads cell 0 and ignores it)
+        // does anything in this wave need the reference's sequential order?  (tron_rollout_quad_kernel, on cell indices)
+        const int tq = look ? tgt : no_tgt;
+        const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
+        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
+        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        // the common path: each player on its own
+        const int h0 = h, hx0 = hx, hy0 = hy, d0 = d, k0 = k;     // (k == 0 exactly while my player is alive)
+        bool dead = run & (oob | (raw != 0));                   // :47-57
+        bool moved = run ^ dead;                                // :60-62
+        k = dead ? (oob ? p + 1 : raw) : k;
+        d = run ? dir : d;                                      // :44
+        h = moved ? tgt : h; hx = moved ? nx : hx; hy = moved ? ny : hy;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
+            // rare: the quad's four players in the reference's order from the pre-step state, redundantly in its four lanes
+            TronRegs<4> s;
+            TronProbe<4> pr;
+            const int oobi = oob ? 1 : 0;
+            s.h[0] = tron_quad<0x00>(h0); s.h[1] = tron_quad<0x55>(h0); s.h[2] = tron_quad<0xAA>(h0); s.h[3] = tron_quad<0xFF>(h0);
+            s.x[0] = tron_quad<0x00>(hx0); s.x[1] = tron_quad<0x55>(hx0); s.x[2] = tron_quad<0xAA>(hx0); s.x[3] = tron_quad<0xFF>(hx0);
+            s.y[0] = tron_quad<0x00>(hy0); s.y[1] = tron_quad<0x55>(hy0); s.y[2] = tron_quad<0xAA>(hy0); s.y[3] = tron_quad<0xFF>(hy0);
+            s.d[0] = tron_quad<0x00>(d0); s.d[1] = tron_quad<0x55>(d0); s.d[2] = tron_quad<0xAA>(d0); s.d[3] = tron_quad<0xFF>(d0);
+            s.k[0] = tron_quad<0x00>(k0); s.k[1] = tron_quad<0x55>(k0); s.k[2] = tron_quad<0xAA>(k0); s.k[3] = tron_quad<0xFF>(k0);
+            pr.tgt[0] = tron_quad<0x00>(tgt); pr.tgt[1] = tron_quad<0x55>(tgt); pr.tgt[2] = tron_quad<0xAA>(tgt); pr.tgt[3] = tron_quad<0xFF>(tgt);
+            pr.raw[0] = tron_quad<0x00>(raw); pr.raw[1] = tron_quad<0x55>(raw); pr.raw[2] = tron_quad<0xAA>(raw); pr.raw[3] = tron_quad<0xFF>(raw);
+            pr.ndir[0] = tron_quad<0x00>(dir); pr.ndir[1] = tron_quad<0x55>(dir); pr.ndir[2] = tron_quad<0xAA>(dir); pr.ndir[3] = tron_quad<0xFF>(dir);
+            pr.nx[0] = tron_quad<0x00>(nx); pr.nx[1] = tron_quad<0x55>(nx); pr.nx[2] = tron_quad<0xAA>(nx); pr.nx[3] = tron_quad<0xFF>(nx);
+            pr.ny[0] = tron_quad<0x00>(ny); pr.ny[1] = tron_quad<0x55>(ny); pr.ny[2] = tron_quad<0xAA>(ny); pr.ny[3] = tron_quad<0xFF>(ny);
+            const int o0 = tron_quad<0x00>(oobi), o1 = tron_quad<0x55>(oobi), o2 = tron_quad<0xAA>(oobi), o3 = tron_quad<0xFF>(oobi);
+            pr.oob[0] = o0 != 0; pr.oob[1] = o1 != 0; pr.oob[2] = o2 != 0; pr.oob[3] = o3 != 0;
+            int rew4[4], term4, wm4;
+            const PlainBoard nowhere{nullptr CRL_CELLS_INIT(NN)};
+            tron_resolve<4>(nowhere, false, s, pr, rew4, term4, wm4);   // valid = false: no stores here (below, with everybody's)
+            int hS = s.h[0], xS = s.x[0], yS = s.y[0], dS = s.d[0], kS = s.k[0];
+            hS = (p == 1) ? s.h[1] : hS; xS = (p == 1) ? s.x[1] : xS; yS = (p == 1) ? s.y[1] : yS; dS = (p == 1) ? s.d[1] : dS; kS = (p == 1) ? s.k[1] : kS;
+            hS = (p == 2) ? s.h[2] : hS; xS = (p == 2) ? s.x[2] : xS; yS = (p == 2) ? s.y[2] : yS; dS = (p == 2) ? s.d[2] : dS; kS = (p == 2) ? s.k[2] : kS;
+            hS = (p == 3) ? s.h[3] : hS; xS = (p == 3) ? s.x[3] : xS; yS = (p == 3) ? s.y[3] : yS; dS = (p == 3) ? s.d[3] : dS; kS = (p == 3) ? s.k[3] : kS;
+            moved = hS != h0;                                   // (a head is never its owner's own target)
+            h = hS; hx = xS; hy = yS; d = dS;
+            k = kS;                                             // (also a dead player's entry, overwritten by a head-on killer: :56-57)
+        }
+        // TronGridEnvironment.py:309-321 for the game: alive players over the quad
+        a = (run && k == 0) ? 1 : 0;
+        int alive = a + tron_quad<0xB1>(a);
+        alive += tron_quad<0x4E>(alive);
+        alive_steps += (uint32_t)a;
+        neg2 += 2;
+        const bool over = alive <= 1;                           // (a game beyond the batch is "over" at every step)
+        // the trail -- unless the game ends with this step: its board is about to be rewritten as a whole
+        if (moved && !over && gvalid) {
+            CRL_BOUNDS_LT(h, NN, 139);                          // ... and so does the trail store
+            gb[h] = (uint8_t)(p + 1);
+        }
+        if (over) {
+            asm("v_add3_u32 %0, %0, %1, %2" : "+v"(wn) : "v"(a), "s"(0x10000u));
+            asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add3_u32 %0, %0, %2, %3" : "+v"(marks) : "v"(dry2), "v"(neg2), "v"(a));
+            h = seat ? fh : no_head; hx = fx; hy = fy; d = fd;
+            k = pvalid ? 0 : 1;
+            a = fresh_a;
+        }
+        // new_state for the games of this wave that ended: the whole wave writes each one's start board
+        uint64_t ending = __builtin_amdgcn_ballot_w64(over && gvalid && p == 0);
+        while (ending) {
+            const int l = (int)__builtin_ctzll(ending);
+            ending &= ending - 1;
+            uint8_t *eb = reinterpret_cast<uint8_t *>(board) + (env0 + (l >> 2)) * NN;
+            const int lead = min((int)((16u - (uint32_t)((uintptr_t)eb & 15u)) & 15u), NN);
+            const int chunks = (NN - lead) >> 4, tail0 = lead + (chunks << 4);
+            for (int c = lane; c < chunks; c += CRL_WAVE)
+                *reinterpret_cast<uint4 *>(eb + lead + (c << 4)) = tron_fresh_chunk16<P>(cfg, lead + (c << 4));
+            const int odd = lane < lead ? lane : (lane - lead < NN - tail0 ? tail0 + lane - lead : -1);   // (lead + tail < 31 bytes)
+            if (odd >= 0) {
+                int v = 0;
+#pragma unroll
+                for (int q = 0; q < P; ++q) v = (cfg.start_heads[q] == odd) ? q + 1 : v;
+                eb[odd] = (uint8_t)v;
+            }
+        }
+        acts >>= 2;
+        if (neg2 == 0) {                                        // a quad shares its step counter: whole quads take this branch
+            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for
+            if ((c & 16u) == 0u) refill(c >> 5);
+            acts = (c & 16u) ? a_hi : a_lo;
+            dry2 += 32u;
+            neg2 = -32;
+        }
+    }
+    // ---- per-player state and statistics (my columns), per-game statistics (lane 0 of the quad)
+    const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
+    const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
+    tc = tc_in + (uint32_t)T;
+    const uint32_t ts_at_entry = ts;
+    ts = n_ep ? (uint32_t)(T - done_last) : ts_at_entry + (uint32_t)T;
+    const int last_len = (n_ep > 1u) ? done_last - done_prev : (int)ts_at_entry + done_last;
+    int lw = (last_alive & 1) << p;
+    lw |= tron_quad<0xB1>(lw);
+    lw |= tron_quad<0x4E>(lw);
+    const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;   // alive +1, dead -1, alive at a terminal step +10
+    int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    uint16_t *pk = st.packed ? st.packed + b * kTronPackedRow<P> : nullptr;
+    if (pvalid) {
+        heads[p * B + b] = (int16_t)h;
+        dirs[p * B + b] = (int8_t)d;
+        deaths[p * B + b] = (int8_t)k;
+        const int rs = old_ret + ret;
+        const uint32_t wc = old_wins + wins;
+        st.ret_sum[p * B + b] = rs;
+        st.win_count[p * B + b] = wc;
+        if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+        if (pk) pk[4 + p] = (uint16_t)rs;
+    }
+    if (gvalid && p == 0) {
+        const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + (ts_at_entry + (uint32_t)T - ts);
+        st.tcount[b] = tc;
+        st.tstep[b] = ts;
+        st.n_episodes[b] = ne;
+        st.len_sum[b] = ls;
+        if (n_ep > 0) {
+            st.last_winners[b] = (uint8_t)lw;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+        if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+        if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
+    }
 }
 
 // ---- replay of unfinished episodes on byte slabs (epilogue of both bitboard kernels) --------------------------------
@@ -3806,7 +4014,7 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
-    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS | CRL_ROLLOUT_GQUAD)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
@@ -3818,13 +4026,35 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const bool small = cfg.N <= kLdsMaxNSmall;
     const int RS = small ? kRowBytesSmall : kRowBytesLarge;
     const TronPad pad = pad_of(cfg, RS);
-    // Short launches on boards above 20x20 with at most 4 players stay in global memory unless a kernel is pinned: the
-    // bitboard kernel's fixed cost (boards to bits, replay on byte slabs, boards back) is 64-109 us at 65,536 games of
-    // 24x24..40x40 against 28-60 us for one step of the global kernel, which adds 3-4 us per step where the bitboards add 0.5:
-    // they cross at ~24 steps (profiles/r5_shape_sweep.txt)
-    const bool short_large = !small && cfg.P <= 4 && T <= 20 &&
-                             !(flags & (CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS));
-    const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !short_large && cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
+    // The lane-per-player kernel on boards in GLOBAL memory has no fixed cost (no copy in / out, no tags to strip, no replay):
+    // a launch costs what its steps cost, 2-4.5 us each at 65,536 games of 20x20..40x40 (a probe pulls a cache line per byte).
+    // So, unless a kernel is pinned, it takes (profiles/r5_shape_sweep.txt, `kernels`):
+    //  * a ONE-step launch on boards up to 20x20 (11 us against the byte-slab kernel's 13-16);
+    //  * short launches on boards 21..40 wide, where the bitboard kernel's copy in + replay + copy out is 64-110 us (134-355 us
+    //    on boards that are not whole dwords a row): up to 28 steps (56 on the latter);
+    //  * boards above 40x40, which nothing else plays out of LDS: always up to 44x44, up to 200 steps up to 56x56 and up to
+    //    64 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a finished
+    //    board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch.
+    // More than four players: the lane-per-game kernels.
+    const bool no_pin = !(flags & (CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS));
+    const bool lds_fit = cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
+    const bool wide_rows = (cfg.N & 3) == 0;
+    const bool gquad_pays = small ? T == 1
+                          : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 28 : 56)
+                          : (cfg.N <= 44 || T <= (cfg.N <= 56 ? 200 : 64));
+    const bool use_gquad = cfg.P <= 4 && ((flags & CRL_ROLLOUT_GQUAD) || (no_pin && (gquad_pays || (!lds_fit && cfg.N <= kLdsMaxNLarge))));
+    const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !use_gquad && lds_fit;
+    if (use_gquad) {
+        constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, as below)
+        for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
+            TRON_DISPATCH_P4(cfg.P, {
+                launch(tron_rollout_gquad_kernel<PP>, dim3(blocks_for(B, 64)), dim3(256), (size_t)0, t0 + kQuadMaxT >= T, cfg, g, B,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0), board, heads, dirs, deaths, st);
+            });
+            CRL_LAUNCH_CHECK();
+        }
+        return CRL_OK;
+    }
     // default: bitboards where they buy residency (boards above 20x20 fit 4x the games per CU); on small boards the
     // byte kernel already has every game resident and no replay to pay for
     const bool use_bits = lds_ok && !(flags & CRL_ROLLOUT_BYTES) && ((flags & CRL_ROLLOUT_BITS) || (!small && T >= 256));

@@ -52,15 +52,18 @@ extern "C" {
 #define CRL_STEP_BYTES      2u  /* byte probes in HBM, one lane per game, nothing staged */
 #define CRL_STEP_STAGED     4u  /* boards read once, coalesced, into LDS (boards of whole 16-byte chunks that fit; else ignored) */
 /* flags for crl_tron_rollout */
-#define CRL_ROLLOUT_NO_LDS  2u  /* force the global-memory kernel even when the boards would fit in LDS */
+#define CRL_ROLLOUT_NO_LDS  2u  /* force the lane-per-game global-memory kernel even when the boards would fit in LDS */
 #define CRL_ROLLOUT_BYTES   4u  /* force the lane-per-game byte-per-cell LDS kernel */
 #define CRL_ROLLOUT_BITS    8u  /* force the lane-per-game bitboard LDS kernel with replay epilogue (default for boards 21..40 wide with P > 4 and T >= 256) */
 #define CRL_ROLLOUT_QUAD   16u  /* the lane-per-player kernel (four lanes per game): boards up to 20x20 with at most 4 players.
                                  * It is the default there; elsewhere the flag is ignored */
 #define CRL_ROLLOUT_QBITS  32u  /* the lane-per-player bitboard kernel with replay epilogue (at most 4 players, boards up to
-                                 * 40x40): the default for boards 21..40 wide in launches of more than 20 steps (shorter ones
-                                 * stay in global memory: the kernel's fixed cost is worth ~24 steps there); with more than 4
-                                 * players the flag is ignored */
+                                 * 40x40): the default for boards 21..40 wide in launches of more than 28 steps (shorter ones
+                                 * stay in global memory: the kernel's fixed cost is worth that many steps there); with more
+                                 * than 4 players the flag is ignored */
+
+#define CRL_ROLLOUT_GQUAD  64u  /* one lane per player on boards in GLOBAL memory (any board size, at most 4 players; with more
+                                 * the flag is ignored): the default wherever the boards are not played out of LDS */
 
 typedef struct crl_ctx crl_ctx;   /* opaque, immutable after creation */
 
@@ -185,9 +188,12 @@ typedef struct {
  *   a = mulhi32(v, 3): 0 -> forward, 1 -> right, 2 -> left        (base-3 digits of the fraction W/2^32)
  * Boards up to 40x40 are played out of LDS (one copy in / one copy out per launch): boards up to 20x20 on a
  * byte-per-cell slab (one lane per player when P <= 4, else one lane per game), larger ones on an occupancy bitboard
- * (one lane per player when P <= 4 and T > 20; else one lane per game and T >= 256) whose unfinished episode is replayed with
- * owners at the end of the launch; boards above 40x40, launches of at most 20 steps on boards above 20x20 with P <= 4, or
- * flags & CRL_ROLLOUT_NO_LDS, use the global-memory kernel.  CRL_ROLLOUT_BYTES / _BITS /
+ * (one lane per player when P <= 4; else one lane per game and T >= 256) whose unfinished episode is replayed with
+ * owners at the end of the launch.  Boards above 40x40 stay in global memory -- and so do, with P <= 4, launches too short
+ * to earn an LDS kernel's copies back (one step on boards up to 20x20, up to 28 steps on boards 21..40 wide, 56 where a row
+ * is not whole dwords): one lane per player (CRL_ROLLOUT_GQUAD; no fixed cost per launch) or one lane per game
+ * (CRL_ROLLOUT_NO_LDS; episode tags, one pass over the boards per launch: P > 4, and long launches on boards above 44x44).
+ * CRL_ROLLOUT_BYTES / _BITS /
  * _QUAD / _QBITS pin one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
  * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player; callers
  * that upload hand-made states run crl_tron_check_state first (heads outside the board are clamped onto it, so a

@@ -49,6 +49,8 @@ def test_tron_batches_beyond_4_gib(N, P, B):
     check("rollout 150")
     both(lambda t, lo, hi: t.rollout(9, seed, kernel="global"))
     check("rollout 9 global")
+    both(lambda t, lo, hi: t.rollout(11, seed, kernel="gquad"))
+    check("rollout 11 gquad")
     # per-step API
     outs = {}
     def so(t, lo, hi):

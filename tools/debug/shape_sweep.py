@@ -5,7 +5,7 @@ kernels?  Prints, per (N, P, B), microseconds per call (median of back-to-back l
     python tools/debug/shape_sweep.py [N,N,...] [P,P,...] [B,B,...] [json path]
     python tools/debug/shape_sweep.py kernels [N,N,...] [T,T,...] [B]
     python tools/debug/shape_sweep.py others [quick]
-`kernels`: the interchangeable rollout kernels ("auto" = the library's choice, "qbits", "bits", "bytes", "global") against the
+`kernels`: the interchangeable rollout kernels ("auto" = the library's choice, "qbits", "bits", "bytes", "global", "gquad") against the
 launch length at P = 4 -- where the fixed cost of an LDS-resident launch (copy in, replay, copy out) is worth it.
 `others`: TicTacToe over ten board shapes and Blokus over batch sizes, whole and ragged batches (no cliffs: +10-15 % for a
 ragged batch's extra workgroup)."""
@@ -74,7 +74,7 @@ if arg and arg[0] == "kernels":
     Bk = int(arg[3]) if len(arg) > 3 else 65536
     for N in Ns:
         st = TronBatch(N, 4, Bk, device=dev)
-        for kern in ("auto", "qbits", "bits", "bytes", "global"):
+        for kern in ("auto", "qbits", "bits", "bytes", "global", "gquad"):
             row = []
             for T in Ts:
                 for _ in range(2):

@@ -17,12 +17,12 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
-    N = int(rng.integers(4, 41))
+    N = int(rng.integers(4, 41)) if rng.random() < 0.9 else int(rng.integers(41, 70))    # (above 40x40: the global-memory kernels)
     P = int(rng.integers(2, 9))
     while P * 2 > N * 2:                      # (start ring needs room)
         P -= 1
     B = int(rng.integers(1, 3000))
-    chunks = [int(rng.integers(1, 700)) for _ in range(int(rng.integers(1, 4)))]
+    chunks = [int(rng.integers(1, 700)) if rng.random() < 0.7 else int(rng.integers(1, 30)) for _ in range(int(rng.integers(1, 4)))]
     if rng.random() < 0.15:
         chunks.append(int(rng.integers(16384, 20000)))
         B = min(B, 300)
@@ -35,7 +35,7 @@ for case in range(n_cases):
     O.tron_reset(ost, sh, sd)
     for T in chunks:
         O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=16)
-    for kernel in ("auto", "quad", "qbits", "bytes", "bits", "global"):
+    for kernel in ("auto", "quad", "qbits", "bytes", "bits", "global", "gquad"):
         tb = TronBatch(N, P, B, first_env_id=first)
         for T in chunks:
             tb.rollout(T, seed, kernel=kernel)
