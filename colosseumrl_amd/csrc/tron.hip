@@ -2031,8 +2031,29 @@ __device__ __forceinline__ void tron_replay_copy_out(int8_t *__restrict__ gslab,
             *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
+        // rows that are not whole dwords: the games' boards are still one run of bytes, and it leaves in aligned 16-byte chunks
+        // where its start allows (a chunk is gathered cell by cell out of the slabs: a row ends, a game ends inside it) -- a
+        // byte per lane and store made the copy back 380 store instructions per wave at 39x39, 64 bytes each
         const int cells = n_games * NN;
-        for (int i = tid; i < cells; i += nthreads) {
+        const int full = (N >= 2 && (((uintptr_t)gslab & 15) == 0)) ? cells & ~15 : 0;
+        for (int off = tid * 16; off < full; off += nthreads * 16) {
+            int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            const int r = off - e * NN;
+            int y = (int)__umulhi((uint32_t)r, g.inv_n), x = r - y * N;
+            int a = lds0 + e * pad.stride + (y + 1) * RS + x;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                w[k >> 2] |= (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)a << (8 * (k & 3));
+                ++x; ++a;
+                if (x == N) {                                   // next row; behind the last one, the next game's first
+                    x = 0; ++y; a += RS - N;
+                    if (y == N) { y = 0; ++e; a = lds0 + e * pad.stride + RS; }
+                }
+            }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (int i = full + tid; i < cells; i += nthreads) {
             const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
             const int c = i - e * NN;
             const int y = (int)__umulhi((uint32_t)c, g.inv_n);
@@ -2365,7 +2386,7 @@ __global__ void __launch_bounds__(256, 4)
 tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const TronBits bits, const int64_t B,
                           const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
                           int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
-                          int8_t *__restrict__ deaths, const crl_tron_stats st)
+                          int8_t *__restrict__ deaths, const crl_tron_stats st, const int split_replay)
 {
     static_assert(P <= 4, "one lane per player, four lanes per game");
     constexpr int kGames = 64, kWaveGames = 16;
@@ -2380,6 +2401,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     __shared__ uint32_t wall_words[kSlab / 4];
     __shared__ uint32_t r_tc[kGames];                           // hand-over to the replay: step counter at the end,
     __shared__ int r_steps[kGames];                             // steps to replay (-1: T steps from the incoming state)
+    QUAD_STAMP(0);
     tron_fill_action_lut(act_lut);
     const int N = g.N, NN = g.NN, S = N + 1;
     const uint32_t bstep4 = (uint32_t)((-S) & 0xff) | (1u << 8) | ((uint32_t)S << 16) | (0xffu << 24);
@@ -2479,13 +2501,57 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
                 }
             }
         } else {
-            for (int e = 0; e < n_env; ++e)
-                for (int c = lane; c < NN; c += CRL_WAVE) {
-                    const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-                    const int bit = (y + 1) * S + (c - y * N);
-                    if (gslab[(int64_t)e * NN + c] != 0)
-                        atomicOr((unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2)), 1u << (bit & 31));
+            // rows that are not whole dwords (round 5): the wave's 16 boards are still ONE run of bytes that starts on a 16-byte
+            // boundary (env0 is a multiple of 16), so it is read in aligned 16-byte chunks; bit (y + 1) S + x = cell + y + S, so the
+            // four cells of a dword are four contiguous bits -- split by one extra bit where the dword runs into the next row --,
+            // and only a dword that straddles two GAMES (16 per wave) goes cell by cell.  (Byte by byte this copy took 120 us of
+            // a launch at 39x39, against 20 us at 40x40.)
+            const int bytes = n_env * NN, full = N >= 4 ? bytes & ~15 : 0;     // (N < 4: a dword could cross two rows -- cell by cell)
+            auto slab_word = [&](const int e, const int bit) {
+                return (unsigned int *)(lds + (slab0 - lds0) + e * bits.stride + ((bit >> 5) << 2));
+            };
+#pragma unroll 4
+            for (int off = lane * 16; off < full; off += CRL_WAVE * 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const int e0 = (int)__umulhi((uint32_t)off, pad.inv_nn);
+                const int r = off - e0 * NN;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int c = r + 4 * q, e = e0;
+                    if (c >= NN) { c -= NN; e += 1; }
+                    if (w[q] == 0u) continue;
+                    if (c + 3 < NN) {
+                        const uint32_t nz = (((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u;
+                        const uint32_t nib = (uint32_t)(((nz >> 7) * 0x10204080u) >> 28);
+                        const int y = (int)__umulhi((uint32_t)c, g.inv_n), x = c - y * N;
+                        const int left = N - x;                  // cells of this dword that are still in row y
+                        const uint32_t lo = left >= 4 ? 0xfu : ((1u << left) - 1u);
+                        const int bit = (y + 1) * S + x;
+                        const uint64_t two = ((uint64_t)(nib & lo) << (bit & 31)) | ((uint64_t)(nib & ~lo) << ((bit & 31) + 1));
+                        unsigned int *wp = slab_word(e, bit);
+                        atomicOr(wp, (unsigned int)two);
+                        atomicOr(wp + 1, (unsigned int)(two >> 32));
+                    } else {
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) {
+                            int cc = c + k2, ee = e;
+                            if (cc >= NN) { cc -= NN; ee += 1; }
+                            if ((w[q] >> (8 * k2)) & 0xffu) {
+                                const int y = (int)__umulhi((uint32_t)cc, g.inv_n);
+                                const int bit = (y + 1) * S + (cc - y * N);
+                                atomicOr(slab_word(ee, bit), 1u << (bit & 31));
+                            }
+                        }
+                    }
                 }
+            }
+            for (int cc0 = full + lane; cc0 < bytes; cc0 += CRL_WAVE) {     // (a wave with fewer than 16 games: the last bytes of its run)
+                const int e = (int)__umulhi((uint32_t)cc0, pad.inv_nn), c = cc0 - e * NN;
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                const int bit = (y + 1) * S + (c - y * N);
+                if (gslab[cc0] != 0) atomicOr(slab_word(e, bit), 1u << (bit & 31));
+            }
         }
     }
     // ---- my player: the head as a BIT address (8 * slab address + bit index; a step is +-1 or +-S)
@@ -2512,6 +2578,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
     uint32_t alive_steps = 0, wn = 0, marks = 0, ok_at2 = 0;    // as in tron_rollout_quad_kernel; ok_at2: the spare is
                                                                 // completely fresh once 2 * (steps done) reaches it
     __syncthreads();                                            // action table
+    QUAD_STAMP(1);
     uint32_t a_lo = 0, a_hi = 0;
     auto refill = [&](const uint32_t group) { tron_quad_actions(gid, group, p, seed_lo, seed_hi, act_lut, a_lo, a_hi); };
     refill(tc_in >> 5);
@@ -2701,6 +2768,7 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         if ((T & 3) > 1) one_step(std::integral_constant<int, 1>{}, std::false_type{}, false);
         if ((T & 3) > 2) one_step(std::integral_constant<int, 2>{}, std::false_type{}, false);
     }
+    QUAD_STAMP(2);
     // ---- statistics (my player's columns; the game's by lane 0 of the quad) and the hand-over to the replay
     const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
     const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
@@ -2738,6 +2806,8 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
         if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
     }
+    // the replay as a kernel of its own behind this one (tron_replay_kernel: what it needs is in tcount / tstep by now)
+    if (split_replay) { QUAD_STAMP(3); return; }
     __syncthreads();                                            // bit slabs are dead from here; byte slabs reuse the LDS
 
     // ---- replay of the unfinished episodes on byte slabs: rebuilds board / heads / dirs / deaths (helpers above).  Four
@@ -2772,6 +2842,162 @@ tron_rollout_qbits_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPa
         tron_replay_copy_out<RS>(board + gbase * NN, n_turn, lds0, pad, g, (int)threadIdx.x, 256);
         __syncthreads();
     }
+#ifdef CRL_QUAD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    QUAD_STAMP(3);
+}
+
+// (2c) the same replay with ONE LANE PER PLAYER: the wave's 64 lanes are 16 games x 4 seats, as in the lane-per-player kernels.
+// With a lane per game a wave replays its 16 games on a quarter of its lanes, ~300 vector instructions per step (four players'
+// probes, resolution and trail stores unrolled) -- 38 us of pure instruction issue for 65,536 games of ~30 replayed steps;
+// here a lane plays its own player (one probe, die or move, one store) and the reference's order is resolved, on DPP-gathered
+// copies, only in the wave-steps where a target meets another player's head or target.  A single episode: no tags, no reset,
+// cells hold the plain owner.  Every lane runs `replay_len` iterations and takes part in the last steps_r of them.
+template <int RS>
+__device__ __forceinline__ void tron_replay_quad(const crl_tron_cfg &cfg, const TronGeom &g, const TronPad &pad, const int P,
+                                                 const int bmine, const uint8_t *act_lut, const bool gvalid, const bool from_start,
+                                                 const int steps_r, const int replay_len, const uint32_t tc_end, const uint32_t gid,
+                                                 const uint32_t seed_lo, const uint32_t seed_hi, const int64_t bg, const int64_t B,
+                                                 int16_t *__restrict__ heads, int8_t *__restrict__ dirs, int8_t *__restrict__ deaths)
+{
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    const int N = g.N, NN = g.NN;
+    const int p = (int)(threadIdx.x & 3);
+    const bool seat = p < P, pvalid = gvalid && seat;
+    const int junk = bmine + pad.junk + p;                      // four junk bytes per slab: one per lane of the quad
+    const int64_t bbg = gvalid ? bg : 0;
+    const int64_t pb = (int64_t)(seat ? p : 0) * B + bbg;
+    int fh = cfg.start_heads[0], fd = cfg.start_dirs[0];
+    fh = (p == 1) ? cfg.start_heads[1] : fh; fd = (p == 1) ? cfg.start_dirs[1] : fd;
+    fh = (p == 2) ? cfg.start_heads[2] : fh; fd = (p == 2) ? cfg.start_dirs[2] : fd;
+    fh = (p == 3) ? cfg.start_heads[3] : fh; fd = (p == 3) ? cfg.start_dirs[3] : fd;
+    int hc = seat ? fh : 0, d = fd & 3, k = pvalid ? 0 : 1;
+    if (!from_start) {                                          // (whole quads: a game's four lanes share from_start)
+        hc = min(max((int)heads[pb], 0), NN - 1);
+        d = dirs[pb] & 3;
+        k = pvalid ? (int)deaths[pb] : 1;
+    }
+    const int y0 = (int)__umulhi((uint32_t)hc, g.inv_n);
+    int h = pvalid ? bmine + (y0 + 1) * RS + (hc - y0 * N) : junk;     // the head as an LDS address
+    const int first_r = replay_len - steps_r;                   // this game joins at iteration first_r
+    uint32_t c = tc_end - (uint32_t)replay_len;
+    uint32_t a_lo = 0, a_hi = 0, acts = 0;
+    const uint32_t stamp = (uint32_t)(p + 1);
+    for (int t = 0; t < replay_len; ++t, ++c) {
+        if (t == 0 || (c & 15u) == 0u) {                        // (whole quads take this branch together: they share c)
+            if (t == 0 || (c & 31u) == 0u) tron_quad_actions(gid, c >> 5, p, seed_lo, seed_hi, act_lut, a_lo, a_hi);
+            acts = ((c & 16u) ? a_hi : a_lo) >> ((c & 15u) * 2u);
+        }
+        const bool on = gvalid && t >= first_r;
+        const bool run = on && k == 0;
+        const int dir = (d + (int)(acts & 3u)) & 3;
+        const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir << 3, 8);
+        const int tq = run ? tgt : junk;
+        CRL_BOUNDS_IN(tq, bmine, bmine + pad.stride, 141);      // the probe stays inside my game's slab (junk bytes included)
+        const uint32_t raw = *(const lds_u8 *)(uintptr_t)(uint32_t)tq;
+        const int x1 = tq ^ tron_quad<0x39>(h), x2 = tq ^ tron_quad<0x4E>(h), x3 = tq ^ tron_quad<0x93>(h);
+        const int y1 = tq ^ tron_quad<0x39>(tq), y2 = tq ^ tron_quad<0x4E>(tq);
+        const uint32_t near = min(min(min(min((uint32_t)x1, (uint32_t)x2), (uint32_t)x3), (uint32_t)y1), (uint32_t)y2);
+        const int h_was = h, d_was = d, k_was = k;
+        // the common path: each player on its own (correct unless players interact)
+        const bool dead = run & (raw != 0u);                    // :47-57 (a wall reads 0xff)
+        const bool moved = run ^ dead;                          // :60-62
+        k = dead ? (raw == (uint32_t)kWallCell ? p + 1 : (int)raw) : k;
+        d = run ? dir : d;                                      // :44
+        h = moved ? tgt : h;
+        CRL_BOUNDS_IN(moved ? h : junk, bmine, bmine + pad.stride, 142);
+        *(lds_u8 *)(uintptr_t)(uint32_t)(moved ? h : junk) = (uint8_t)stamp;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
+            // rare: take the common path's stamp back (the cell was empty), then the quad's four players in the reference's order
+            // from the pre-step state, redundantly in its four lanes (tron_rollout_quad_kernel)
+            if (moved) *(lds_u8 *)(uintptr_t)(uint32_t)tgt = (uint8_t)0;
+            TronRegs<4> s;
+            TronProbe<4> pr;
+            uint32_t stamp4[4];
+            const int kk = on ? k_was : 1;                      // a game that has not joined yet: nobody runs
+            s.h[0] = tron_quad<0x00>(h_was); s.h[1] = tron_quad<0x55>(h_was); s.h[2] = tron_quad<0xAA>(h_was); s.h[3] = tron_quad<0xFF>(h_was);
+            s.d[0] = tron_quad<0x00>(d_was); s.d[1] = tron_quad<0x55>(d_was); s.d[2] = tron_quad<0xAA>(d_was); s.d[3] = tron_quad<0xFF>(d_was);
+            s.k[0] = tron_quad<0x00>(kk); s.k[1] = tron_quad<0x55>(kk); s.k[2] = tron_quad<0xAA>(kk); s.k[3] = tron_quad<0xFF>(kk);
+            pr.tgt[0] = tron_quad<0x00>(tgt); pr.tgt[1] = tron_quad<0x55>(tgt); pr.tgt[2] = tron_quad<0xAA>(tgt); pr.tgt[3] = tron_quad<0xFF>(tgt);
+            pr.raw[0] = tron_quad<0x00>((int)raw); pr.raw[1] = tron_quad<0x55>((int)raw); pr.raw[2] = tron_quad<0xAA>((int)raw); pr.raw[3] = tron_quad<0xFF>((int)raw);
+            pr.ndir[0] = tron_quad<0x00>(dir); pr.ndir[1] = tron_quad<0x55>(dir); pr.ndir[2] = tron_quad<0xAA>(dir); pr.ndir[3] = tron_quad<0xFF>(dir);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stamp4[q] = (uint32_t)(q + 1);
+            LdsBoard<3> bd{0u};
+            bd.within(bmine, bmine + pad.stride);
+            const int junk0 = bmine + pad.junk;
+            tron_resolve_lds<4>(bd, s, pr, stamp4, junk0);      // trail writes of all four players from every lane: identical
+            int hS = s.h[0], dS = s.d[0], kS = s.k[0];
+            hS = (p == 1) ? s.h[1] : hS; dS = (p == 1) ? s.d[1] : dS; kS = (p == 1) ? s.k[1] : kS;
+            hS = (p == 2) ? s.h[2] : hS; dS = (p == 2) ? s.d[2] : dS; kS = (p == 2) ? s.k[2] : kS;
+            hS = (p == 3) ? s.h[3] : hS; dS = (p == 3) ? s.d[3] : dS; kS = (p == 3) ? s.k[3] : kS;
+            h = (on && seat) ? hS : h_was;
+            d = on ? dS : d_was;
+            k = on ? kS : k_was;
+        }
+        acts >>= 2;
+    }
+    if (pvalid) {
+        const int rel = h - bmine;
+        const int row = rel / RS;
+        heads[p * B + bg] = (int16_t)((row - 1) * N + (rel - row * RS));
+        dirs[p * B + bg] = (int8_t)d;
+        deaths[p * B + bg] = (int8_t)k;
+    }
+}
+
+// The replay of tron_rollout_qbits_kernel as a kernel of its own (round 5).  Inside the bitboard kernel the replay runs in four
+// turns per workgroup -- one wave replays 16 games on byte slabs that take the place of the workgroup's bit slabs while the other
+// three wait --, and the phase stamps (tools/debug/quad_phases.py <T> 40 qbits) put it at 50-75 us of a launch at 40x40 whatever
+// T is, against 20 us for the copy in and 0.27 us per step.  Here every wave of 16 games is its own workgroup with its own byte
+// slabs (29.6 KB at 40x40: five per CU), so the chip replays 1,280 waves at a time instead of 1,024 quarter-time ones -- with a
+// lane per PLAYER (tron_replay_quad): a lane per game left the replay bound by instruction issue on a quarter of the lanes.  What the
+// replay needs it finds where the bitboard kernel has just put it: tcount (the step counter at the end) and tstep (steps into
+// the unfinished episode: below T exactly when the game was reset during the launch, else it resumes from the incoming state).
+template <int P, bool LARGE>
+__global__ void __launch_bounds__(64)
+tron_replay_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
+                   const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                   int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                   int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    constexpr int kWaveGames = 16;
+    constexpr int RS = LARGE ? kRowBytesLarge : kRowBytesSmall;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN;
+    const int lane = threadIdx.x;
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const int64_t gbase = (int64_t)blockIdx.x * kWaveGames;     // first game of this wave
+    const int n_turn = (int)((B - gbase) < kWaveGames ? (B - gbase > 0 ? B - gbase : 0) : kWaveGames);
+    const int gl = lane >> 2;                                   // a lane per player: game gl of the wave, seat lane & 3
+    const bool lvalid = gl < n_turn;
+    const int64_t bg = gbase + gl;
+    const uint32_t tc_end = lvalid ? st.tcount[bg] : 0u;
+    const int ts = lvalid ? (int)st.tstep[bg] : 0;
+    tron_replay_fresh_slabs<RS>(lds0, pad, N, kWaveGames, lane, CRL_WAVE);
+    __syncthreads();
+    if (lane < kWaveGames) tron_replay_stamp_heads<P, RS>(cfg, g, lds0 + lane * pad.stride);
+    __syncthreads();
+    const bool from_start = ts < T;                             // else: from the state the launch came in with
+    const int steps_r = lvalid ? (from_start ? ts : T) : 0;
+    int replay_len = steps_r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) replay_len = max(replay_len, __shfl_xor(replay_len, off, CRL_WAVE));
+    const int bmine = lds0 + gl * pad.stride;
+    if (__builtin_amdgcn_ballot_w64(lvalid && !from_start)) {   // somebody resumes from the incoming board
+        tron_replay_copy_in<RS>(board + gbase * NN, n_turn, lds0, pad, g, lane);
+        // (a slab of a game that was reset was overwritten too: one lane of its quad lays it out again)
+        if (lvalid && from_start && (lane & 3) == 0) tron_replay_refresh_slab<P, RS>(cfg, g, bmine);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    tron_replay_quad<RS>(cfg, g, pad, P, bmine, act_lut, lvalid, from_start, steps_r, replay_len, tc_end,
+                         (uint32_t)(first_env_id + (uint64_t)(lvalid ? bg : 0)), seed_lo, seed_hi, bg, B, heads, dirs, deaths);
+    __syncthreads();
+    tron_replay_copy_out<RS>(board + gbase * NN, n_turn, lds0, pad, g, lane, CRL_WAVE);
 }
 
 // state sanity for hand-made states: heads inside the board and on their owner's cell
@@ -4030,8 +4256,8 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     // a launch costs what its steps cost, 2-4.5 us each at 65,536 games of 20x20..40x40 (a probe pulls a cache line per byte).
     // So, unless a kernel is pinned, it takes (profiles/r5_shape_sweep.txt, `kernels`):
     //  * a ONE-step launch on boards up to 20x20 (11 us against the byte-slab kernel's 13-16);
-    //  * short launches on boards 21..40 wide, where the bitboard kernel's copy in + replay + copy out is 64-110 us (134-355 us
-    //    on boards that are not whole dwords a row): up to 28 steps (56 on the latter);
+    //  * short launches on boards 21..40 wide, where the bitboard kernel's copy in + replay kernel is 45-90 us (70-170 us on
+    //    boards that are not whole dwords a row): up to 20 steps (32 on the latter);
     //  * boards above 40x40, which nothing else plays out of LDS: always up to 44x44, up to 200 steps up to 56x56 and up to
     //    64 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a finished
     //    board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch.
@@ -4040,7 +4266,7 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const bool lds_fit = cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
     const bool wide_rows = (cfg.N & 3) == 0;
     const bool gquad_pays = small ? T == 1
-                          : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 28 : 56)
+                          : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 20 : 32)
                           : (cfg.N <= 44 || T <= (cfg.N <= 56 ? 200 : 64));
     const bool use_gquad = cfg.P <= 4 && ((flags & CRL_ROLLOUT_GQUAD) || (no_pin && (gquad_pays || (!lds_fit && cfg.N <= kLdsMaxNLarge))));
     const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !use_gquad && lds_fit;
@@ -4086,16 +4312,28 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
         qb.stride = bits.stride - 16 + CRL_QBITS_PAD;
         const size_t lds_q = std::max((size_t)64 * qb.stride, (size_t)16 * pad.stride);
         constexpr int kQuadMaxT = 16383;                        // (16-bit episode / win / step counts per launch, see below)
+#ifndef CRL_QBITS_SPLIT_REPLAY
+#define CRL_QBITS_SPLIT_REPLAY 1    /* the replay as a kernel of its own behind the bitboard kernel (0: inside it, four turns per workgroup) */
+#endif
+        const int split = CRL_QBITS_SPLIT_REPLAY;
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
             const int tt = std::min(kQuadMaxT, T - t0);
             TRON_DISPATCH_P4(cfg.P, {
                 const bool last = t0 + kQuadMaxT >= T;
                 if (small)
-                    launch(tron_rollout_qbits_kernel<PP, false>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last, cfg, g, pad, qb, B,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                    launch(tron_rollout_qbits_kernel<PP, false>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last && !split, cfg, g, pad, qb, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st, split);
                 else
-                    launch(tron_rollout_qbits_kernel<PP, true>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last, cfg, g, pad, qb, B,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                    launch(tron_rollout_qbits_kernel<PP, true>, dim3(blocks_for(B, 64)), dim3(256), lds_q, last && !split, cfg, g, pad, qb, B,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st, split);
+                if (split) {
+                    if (small)
+                        launch(tron_replay_kernel<PP, false>, dim3(blocks_for(B, 16)), dim3(64), (size_t)16 * pad.stride, last, cfg, g, pad, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                    else
+                        launch(tron_replay_kernel<PP, true>, dim3(blocks_for(B, 16)), dim3(64), (size_t)16 * pad.stride, last, cfg, g, pad, B,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
+                }
             });
             CRL_LAUNCH_CHECK();
         }

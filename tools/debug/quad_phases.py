@@ -2,7 +2,9 @@
 """Phase timeline of ONE launch of the lane-per-player byte kernel (diagnostic build: tools/lib_variant.sh stamps tron
 -DCRL_QUAD_STAMPS [-DCRL_QUAD_SKEW=n]; run with CRL_LIB_PATH=build/ab_stamps/libcolosseum_hip.so):
 when, relative to the first wave's entry, the waves enter, have their boards in LDS, finish stepping and end.
-    python tools/debug/quad_phases.py [steps [board width]]"""
+    python tools/debug/quad_phases.py [steps [board width [kernel]]]
+(board widths 21..40 with kernel "qbits": the same four stamps in the lane-per-player bitboard kernel -- entry, bits laid out,
+steps done, end of the replay)"""
 import ctypes as C
 import os
 import sys
@@ -18,15 +20,16 @@ from colosseumrl_amd import _native  # noqa: E402
 from colosseumrl_amd.batched import TronBatch  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 20           # board width (<= 20: the kernel this tool stamps)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 20           # board width
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else ("quad" if N <= 20 else "qbits")
 lib = _native.lib()
 tb = TronBatch(N, 4, 65536)
 for _ in range(5):
-    tb.rollout(T, 0)
+    tb.rollout(T, 0, kernel=KERNEL)
 torch.cuda.synchronize()
 buf = (C.c_uint64 * (4096 * 4))()
 for trial in range(3):
-    tb.rollout(T, 0)
+    tb.rollout(T, 0, kernel=KERNEL)
     torch.cuda.synchronize()
     assert lib.crl_diag_quad_stamps(buf, 4096 * 4) == 0
     st = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 4).astype(np.int64)
