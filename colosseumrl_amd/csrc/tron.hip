@@ -1884,16 +1884,26 @@ template <int RS>
 __device__ __forceinline__ void tron_replay_fresh_slabs(const int lds0, const TronPad &pad, const int N, const int n_slabs,
                                                         const int tid, const int nthreads)
 {
+    // a thread takes one slab and every `parts`-th dword COLUMN of it: the value of a column is the same in all N board rows
+    // (cells 0, walls 0xff behind column N - 1), so it is computed once and stored down the rows -- two instructions per
+    // dword (round 5: a division and the row / column tests per dword made this 3 us of a one-wave workgroup's replay)
+    constexpr int kRowDwords = RS / 4;
     const int parts = nthreads / n_slabs, slab = tid % n_slabs;
     const int base = lds0 + slab * pad.stride, sd = pad.stride >> 2;
-    for (int d = tid / n_slabs; d < sd; d += parts) {
-        const int byte = d * 4;
-        const int row = byte / RS, col = byte - row * RS;
-        const int left = N - col;                               // cells from this dword to the row's end
-        uint32_t v = 0xffffffffu;
-        if (row >= 1 && row <= N) v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
-        *(lds_u32 *)(uintptr_t)(uint32_t)(base + byte) = v;
+    for (int j = tid / n_slabs; j < kRowDwords; j += parts) {
+        const int left = N - 4 * j;                             // cells from this dword to the row's end
+        const uint32_t v = (left >= 4) ? 0u : (left <= 0 ? 0xffffffffu : 0xffffffffu << (8 * left));
+        int a = base + 4 * j;
+        *(lds_u32 *)(uintptr_t)(uint32_t)a = 0xffffffffu;       // row 0: wall
+        for (int row = 1; row <= N; ++row) {
+            a += RS;
+            *(lds_u32 *)(uintptr_t)(uint32_t)a = v;
+        }
+        *(lds_u32 *)(uintptr_t)(uint32_t)(a + RS) = 0xffffffffu;    // row N + 1: wall
     }
+    // what lies behind row N + 1 (the junk dword, padding)
+    for (int d = (N + 2) * kRowDwords + tid / n_slabs; d < sd; d += parts)
+        *(lds_u32 *)(uintptr_t)(uint32_t)(base + 4 * d) = 0xffffffffu;
 }
 
 // the P start heads of new_state stamped into the slab at `base`

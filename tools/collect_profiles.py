@@ -2,7 +2,9 @@
 """Copy the summaries tools/profile_bench.sh left under gpurun_out/prof_<tag>/ into profiles/<prefix>_* and, for
 bench workloads, write profiles/traffic_<workload>.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes,
 FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950).
-usage: tools/collect_profiles.py <tag> <prefix> [<workload> <kernel substring> <steps_per_launch> [<games>]]"""
+usage: tools/collect_profiles.py <tag> <prefix> [<workload> <kernel substring> <steps_per_launch> [<games> [<companion substring>]]]
+`companion`: a second kernel that belongs to the same launch (tron_replay_kernel behind tron_rollout_qbits_kernel): its bytes and
+instruction counts are added to the launch's, and it is named in the record."""
 import glob
 import json
 import os
@@ -80,6 +82,17 @@ if len(sys.argv) > 3:
            "source": "profiles/%s_rocprofv3_summary.json" % prefix}
     if games:
         rec["games"] = games
+    if len(sys.argv) > 7:                                # the launch's second kernel: one dispatch of it per dispatch of the first
+        kern = sys.argv[7]
+        cname, cfetch = find("FETCH_SIZE")
+        _, cwrite = find("WRITE_SIZE")
+        rec["companion"] = {"kernel": cname.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip(),
+                            "FETCH_SIZE_KB": cfetch, "WRITE_SIZE_KB": cwrite}
+        rec["hbm_bytes_per_launch"] += int((2 * cfetch + cwrite) * 1024)
+        for key, counter in (("valu_insts_per_launch", "SQ_INSTS_VALU"), ("salu_insts_per_launch", "SQ_INSTS_SALU"), ("lds_insts_per_launch", "SQ_INSTS_LDS")):
+            extra = opt(counter)
+            if extra is not None and rec[key] is not None:
+                rec[key] += extra
     path = os.path.join(dst, "traffic_%s.json" % workload)
     try:
         out = json.load(open(path))

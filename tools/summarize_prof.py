@@ -42,7 +42,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     if acc:
         print("== %s (per-dispatch averages) ==" % d)
     for k, cs in acc.items():
-        if not any(w in k for w in ("rollout", "step", "observe", "valid", "sample", "ranking", "reset", "list", "select")):
+        if not any(w in k for w in ("rollout", "replay", "step", "observe", "valid", "sample", "ranking", "reset", "list", "select")):
             continue
         line = {c: sum(v) / len(v) for c, v in cs.items()}
         print(k[:80], json.dumps({c: round(x, 1) for c, x in line.items()}))
