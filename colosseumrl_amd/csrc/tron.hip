@@ -3380,13 +3380,19 @@ tron_ranking_flat_kernel(const int NN, const uint32_t inv_nn, const int64_t B, c
 template <int P>
 __global__ void __launch_bounds__(256)
 tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict__ board, int8_t *__restrict__ obs, const bool nt,
-                        const bool wide)
+                        const int wide)
 {
     // `wide`: the relabelling does not depend on the game a cell belongs to, so the boards of the batch are ONE byte stream and
     // go 16 bytes at a time whenever the stream (B * N * N bytes, hence every observer's plane) is a whole number of aligned
-    // chunks -- also for boards that are not, like the reference's default 19 x 19 (round 5: 36 -> 20 us at 65,536 games)
+    // chunks (1) -- also for boards that are not, like the reference's default 19 x 19 (round 5: 36 -> 20 us at 65,536 games).
+    // (2): aligned buffers, but a stream that is NOT whole chunks (a batch that is not a multiple of 16 games of such a board):
+    // observer p's plane then starts p * total bytes in, off the 16-byte grid by its own amount.  Every plane is still written in
+    // aligned chunks: the chunk at plane offset d_p + 16 i (d_p = the plane's bytes up to its first boundary) is bytes
+    // 16 i + d_p .. + 15 of the input, i.e. input chunks i and i + 1 funnelled by d_p bytes; the < 16 leading and < 32 trailing
+    // bytes of each plane go one by one (workgroup 0).  0: byte by byte (unaligned buffers).
     const int64_t total = B * (int64_t)NN;
-    const int64_t n_items = wide ? total / 16 : total;
+    const int64_t n_full = total / 16;
+    const int64_t n_items = wide ? n_full : total;
     uint32_t lut_lo[P], lut_hi[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -3399,44 +3405,74 @@ tron_observe_all_kernel(const int NN, const int64_t B, const int8_t *__restrict_
             if (v < 4) lut_lo[p] |= r << (8 * v); else lut_hi[p] |= r << (8 * (v - 4));
         }
     }
+    auto relabel_byte = [&](const int c, const int p) -> int {
+        int n = c - (p + 1);
+        n = n < 0 ? n + P : n;
+        return c > 0 ? n + 1 : c;
+    };
+    auto relabel16 = [&](const uint4 v, const int p) -> uint4 {
+        uint4 o;
+        if (P <= 7) {
+            o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
+            o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
+            o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
+            o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
+        } else {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w}, r4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int s8 = 0; s8 < 32; s8 += 8) r |= (uint32_t)(relabel_byte((int)((w[q] >> s8) & 0xffu), p) & 0xff) << s8;
+                r4[q] = r;
+            }
+            o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        }
+        return o;
+    };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
-        if (wide) {
+        if (wide == 1) {
             const int64_t off = i * 16;
             const uint4 v = *reinterpret_cast<const uint4 *>(board + off);
 #pragma unroll
+            for (int p = 0; p < P; ++p) crl_stream_store16(obs + (int64_t)p * total + off, relabel16(v, p), nt);
+        } else if (wide == 2) {
+            const int64_t off = i * 16;
+            const bool more = i + 1 < n_full;                    // (the next chunk is a whole one too)
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(board + off);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(board + (more ? off + 16 : off));
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
             for (int p = 0; p < P; ++p) {
-                uint4 o;
-                if (P <= 7) {
-                    o.x = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.x);
-                    o.y = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.y);
-                    o.z = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.z);
-                    o.w = __builtin_amdgcn_perm(lut_hi[p], lut_lo[p], v.w);
-                } else {
-                    uint32_t w[4] = {v.x, v.y, v.z, v.w}, r4[4];
+                const int d = (int)((16u - (uint32_t)(((int64_t)p * total) & 15)) & 15u);     // (uniform)
+                if (d == 0) {
+                    crl_stream_store16(obs + (int64_t)p * total + off, relabel16(v0, p), nt);
+                } else if (more) {
+                    const int dq = d >> 2;
+                    const uint32_t r = (uint32_t)(d & 3);
+                    uint32_t x[5];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t r = 0;
-#pragma unroll
-                        for (int s8 = 0; s8 < 32; s8 += 8) {
-                            const int c = (int)((w[q] >> s8) & 0xffu);
-                            int n = c - (p + 1);
-                            n = n < 0 ? n + P : n;
-                            r |= (uint32_t)((c > 0 ? n + 1 : c) & 0xff) << s8;
-                        }
-                        r4[q] = r;
-                    }
-                    o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+                    for (int j = 0; j < 5; ++j) x[j] = dq == 0 ? w[j] : dq == 1 ? w[j + 1] : dq == 2 ? w[j + 2] : w[j + 3];
+                    const uint4 f = make_uint4(__builtin_amdgcn_alignbyte(x[1], x[0], r), __builtin_amdgcn_alignbyte(x[2], x[1], r),
+                                               __builtin_amdgcn_alignbyte(x[3], x[2], r), __builtin_amdgcn_alignbyte(x[4], x[3], r));
+                    crl_stream_store16(obs + (int64_t)p * total + off + d, relabel16(f, p), nt);
                 }
-                crl_stream_store16(obs + (int64_t)p * total + off, o, nt);
             }
         } else {
             const int c = board[i];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                int n = c - (p + 1);
-                n = n < 0 ? n + P : n;
-                obs[(int64_t)p * total + i] = (int8_t)(c > 0 ? n + 1 : c);
-            }
+            for (int p = 0; p < P; ++p) obs[(int64_t)p * total + i] = (int8_t)relabel_byte(c, p);
+        }
+    }
+    if (wide == 2 && blockIdx.x == 0) {
+        // what the chunks left of every plane: its first d_p bytes and the bytes behind its last whole chunk
+        for (int t = threadIdx.x; t < P * 48; t += blockDim.x) {
+            const int p = t / 48, j = t - p * 48;
+            const int d = (int)((16u - (uint32_t)(((int64_t)p * total) & 15)) & 15u);
+            const int64_t stored = d == 0 ? n_full : (n_full > 0 ? n_full - 1 : 0);
+            const int64_t idx = j < d ? (int64_t)j : (int64_t)d + 16 * stored + (j - d);
+            if (idx < total && (j < d || idx >= (int64_t)d + 16 * stored))
+                obs[(int64_t)p * total + idx] = (int8_t)relabel_byte((int)board[idx], p);
         }
     }
 }
@@ -4502,9 +4538,10 @@ int crl_tron_observe_all(const crl_ctx *ctx, int64_t B, const int8_t *board, con
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0), "crl_tron_observe_all: boards must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = (B * (int64_t)NN) % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0);
+    const bool aligned = ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0);
+    const int wide = !aligned ? 0 : (B * (int64_t)NN) % 16 == 0 ? 1 : 2;     // 2: the observers' planes are off the 16-byte grid
     const int64_t items = wide ? B * (int64_t)NN / 16 : B * (int64_t)NN;
-    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256);
+    const unsigned grid = (unsigned)((items + 255) / 256 > 16384 ? 16384 : (items + 255) / 256 < 1 ? 1 : (items + 255) / 256);
     TRON_DISPATCH_P(cfg.P, {
         hipLaunchKernelGGL((tron_observe_all_kernel<PP>), dim3(grid), dim3(256), 0, s, NN, B, board, obs_board,
                            crl_stream_nt((int64_t)(PP + 1) * NN * B, true), wide);

@@ -557,7 +557,8 @@ def test_largest_board_and_single_game():
         assert np.array_equal(hip.tb.board.cpu().numpy(), ost.board) and np.array_equal(hip.tb.heads.cpu().numpy(), ost.heads)
 
 
-@pytest.mark.parametrize("N,P,B", [(20, 4, 5000), (9, 6, 777), (13, 8, 300), (40, 4, 1024), (19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 8, 64)])
+@pytest.mark.parametrize("N,P,B", [(20, 4, 5000), (9, 6, 777), (13, 8, 300), (40, 4, 1024), (19, 4, 4096), (19, 4, 4099), (15, 3, 1008), (39, 8, 64),
+                                   (5, 2, 1), (19, 4, 1), (7, 3, 3), (21, 7, 1001), (5, 4, 2), (19, 4, 65553)])
 def test_observe_all_matches_per_player_observe(N, P, B):
     """The fused all-observers pass (v_perm table for P <= 7, arithmetic for P = 8, byte path for odd boards)
     equals P single-observer calls, which equal the oracle."""
