@@ -3691,7 +3691,7 @@ __device__ __forceinline__ uint4 tron_fresh_flat16(const crl_tron_cfg &cfg, cons
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int P, int G>
+template <int P, int G, bool RAGGED = false>
 __global__ void __launch_bounds__(256)
 tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const uint32_t inv_nn, const int64_t B,
                               const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id,
@@ -3704,8 +3704,9 @@ tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const ui
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int NN = g.NN;
     const int64_t g0 = (int64_t)blockIdx.x * G;
-    const int n_game = (int)((B - g0) < G ? (B - g0) : G);      // a multiple of 16 (B % 16 == 0)
-    const int chunks = (n_game * NN) >> 4;                      // ... so this is exact
+    const int n_game = (int)((B - g0) < G ? (B - g0) : G);      // a multiple of 16 (B % 16 == 0) unless RAGGED
+    const int run_bytes = n_game * NN;
+    const int chunks = run_bytes >> 4;                          // ... so this is exact (RAGGED: the whole chunks of the last workgroup's run)
     uint8_t *rflag = lds + ((G * NN + 15) & ~15);               // [G + 1] this game was reset by the step ([n_game] = 0: read, never set)
     const bool nt = (flags & kStepObserveNT) != 0;
     const int e = threadIdx.x;
@@ -3740,6 +3741,8 @@ tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const ui
             if (c < chunks) *reinterpret_cast<uint4 *>(lds + (c << 4)) = v[u];
         }
     }
+    if constexpr (RAGGED)                                       // the bytes behind the run's last whole chunk
+        for (int i = (chunks << 4) + (int)threadIdx.x; i < run_bytes; i += 256) lds[i] = (uint8_t)src[i];
     __syncthreads();
     // ---- phase B: one lane per game plays the step on its LDS board (byte accesses at e * NN)
     if (stepper) {
@@ -3790,6 +3793,76 @@ tron_step_observe_flat_kernel(const crl_tron_cfg cfg, const TronGeom g, const ui
         }
     }
     const int64_t plane = B * (int64_t)NN;
+    if constexpr (RAGGED) {
+        // A batch that is not a multiple of 16 games: observer p's plane starts p * B * N * N bytes in, off the 16-byte grid by
+        // its own amount, and the last workgroup's run is not whole chunks.  C1: the fresh boards of the games that were reset
+        // are patched into the LDS image (and stored to `board`, whose chunks ARE aligned); C2: every plane goes out in ALIGNED
+        // chunks all the same -- the chunk at run offset d_p + 16 k is LDS chunks k and k + 1 funnelled by d_p bytes -- and the
+        // < 16 bytes at either end of the run one by one.
+        const int chunks_up = (run_bytes + 15) >> 4;
+        for (int c = threadIdx.x; c < chunks_up; c += 256) {
+            const int byte0 = c << 4;
+            const int e0 = (int)__umulhi((uint32_t)byte0, inv_nn);
+            const int r = byte0 - e0 * NN, first = NN - r;
+            const bool f0 = rflag[e0] != 0, f1 = first < 16 && e0 + 1 < n_game && rflag[e0 + 1] != 0;
+            if (f0 | f1) {
+                uint4 v = *reinterpret_cast<const uint4 *>(lds + byte0);
+                const uint4 fr = tron_fresh_flat16<P>(cfg, r, NN);
+                uint32_t m[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t mq = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) mq |= ((4 * q + k2 < first) ? f0 : f1) ? (0xffu << (8 * k2)) : 0u;
+                    m[q] = mq;
+                }
+                v.x = (v.x & ~m[0]) | (fr.x & m[0]); v.y = (v.y & ~m[1]) | (fr.y & m[1]);
+                v.z = (v.z & ~m[2]) | (fr.z & m[2]); v.w = (v.w & ~m[3]) | (fr.w & m[3]);
+                *reinterpret_cast<uint4 *>(lds + byte0) = v;    // (the LDS image is whole chunks long)
+                if (byte0 + 16 <= run_bytes) {
+                    *reinterpret_cast<uint4 *>(board + g0 * NN + byte0) = v;
+                } else {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    for (int j = 0; byte0 + j < run_bytes; ++j) board[g0 * NN + byte0 + j] = (int8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int8_t *dst = obs_board + (int64_t)p * plane + g0 * NN;                     // this run in observer p's plane
+            const int d = (int)((16u - (uint32_t)(((int64_t)p * plane) & 15)) & 15u);   // its bytes up to the first 16-byte boundary
+            const int lead = d < run_bytes ? d : run_bytes;
+            const int K = (run_bytes - lead) >> 4;                                      // aligned chunks inside the run
+            const int dq = d >> 2;
+            const uint32_t rr = (uint32_t)(d & 3);
+            for (int k = threadIdx.x; k < K; k += 256) {
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(lds + (k << 4));
+                uint4 f = v0;
+                if (d != 0) {                                   // (uniform)
+                    const uint4 v1 = *reinterpret_cast<const uint4 *>(lds + ((k + 1) << 4));
+                    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    uint32_t x[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) x[j] = dq == 0 ? w[j] : dq == 1 ? w[j + 1] : dq == 2 ? w[j + 2] : w[j + 3];
+                    f = make_uint4(__builtin_amdgcn_alignbyte(x[1], x[0], rr), __builtin_amdgcn_alignbyte(x[2], x[1], rr),
+                                   __builtin_amdgcn_alignbyte(x[3], x[2], rr), __builtin_amdgcn_alignbyte(x[4], x[3], rr));
+                }
+                uint4 o;
+                o.x = tron_relabel4<P>(f.x, p, lut_lo[p], lut_hi[p]);
+                o.y = tron_relabel4<P>(f.y, p, lut_lo[p], lut_hi[p]);
+                o.z = tron_relabel4<P>(f.z, p, lut_lo[p], lut_hi[p]);
+                o.w = tron_relabel4<P>(f.w, p, lut_lo[p], lut_hi[p]);
+                crl_stream_store16(dst + lead + (k << 4), o, nt);
+            }
+            // the run's bytes in front of its first and behind its last aligned chunk (< 16 each)
+            const int tail0 = lead + (K << 4);
+            const int t = (int)threadIdx.x;
+            const int idx = t < lead ? t : (t - lead < run_bytes - tail0 ? tail0 + t - lead : -1);
+            if (idx >= 0) dst[idx] = (int8_t)(tron_relabel4<P>((uint32_t)lds[idx], p, lut_lo[p], lut_hi[p]) & 0xffu);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < chunks; c += 256) {
         const int byte0 = c << 4;
         uint4 v = *reinterpret_cast<const uint4 *>(lds + byte0);
@@ -4603,25 +4676,25 @@ int crl_tron_step_observe(const crl_ctx *ctx, int64_t B, uint64_t seed, uint64_t
     // the batch is a multiple of 16 games and the buffers are aligned
     {
         const int Gf = (64 * NN + 64 + 32 <= 48 * 1024) ? 64 : (16 * NN + 64 + 32 <= 48 * 1024) ? 16 : 0;
-        if ((NN % 16) != 0 && cfg.P <= 8 && Gf > 0 && B % 16 == 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0)) {
+        if ((NN % 16) != 0 && cfg.P <= 8 && Gf > 0 && ((((uintptr_t)board | (uintptr_t)obs_board) & 15) == 0)) {
+            const bool ragged = B % 16 != 0;                    // (round 5: the planes off the 16-byte grid, the last run not whole chunks)
             const uint32_t inv_nn = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)NN) + 1u;     // exact for byte offsets < 64 * NN
             const size_t lds_bytes = (size_t)((Gf * NN + 15) & ~15) + Gf + 16;
             const dim3 grid(blocks_for(B, Gf));
             const uint32_t kflags = flags | (crl_stream_nt((int64_t)(cfg.P + 1) * NN * B, false) ? kStepObserveNT : 0u);
             switch (cfg.P) {
+#define CRL_SOF_LAUNCH(P_, G_, R_)                                                                                        \
+                    hipLaunchKernelGGL((tron_step_observe_flat_kernel<P_, G_, R_>), grid, dim3(256), lds_bytes, s, cfg, g, inv_nn, B, \
+                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
+                                       actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags)
 #define CRL_SOF_CASE(P_)                                                                                                   \
             case P_:                                                                                                      \
-                if (Gf == 64)                                                                                             \
-                    hipLaunchKernelGGL((tron_step_observe_flat_kernel<P_, 64>), grid, dim3(256), lds_bytes, s, cfg, g, inv_nn, B, \
-                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
-                                       actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
-                else                                                                                                      \
-                    hipLaunchKernelGGL((tron_step_observe_flat_kernel<P_, 16>), grid, dim3(256), lds_bytes, s, cfg, g, inv_nn, B, \
-                                       (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, board, heads, dirs, deaths,   \
-                                       actions, tcount, rewards, terminal, winners, obs_board, obs_heads, obs_dirs, obs_deaths, kflags); \
+                if (Gf == 64) { if (ragged) CRL_SOF_LAUNCH(P_, 64, true); else CRL_SOF_LAUNCH(P_, 64, false); }           \
+                else { if (ragged) CRL_SOF_LAUNCH(P_, 16, true); else CRL_SOF_LAUNCH(P_, 16, false); }                    \
                 break;
                 CRL_SOF_CASE(1) CRL_SOF_CASE(2) CRL_SOF_CASE(3) CRL_SOF_CASE(4) CRL_SOF_CASE(5) CRL_SOF_CASE(6) CRL_SOF_CASE(7) CRL_SOF_CASE(8)
 #undef CRL_SOF_CASE
+#undef CRL_SOF_LAUNCH
                 default: crl_set_error("tron: P=%d out of range", cfg.P); return CRL_EINVAL;
             }
             CRL_LAUNCH_CHECK();

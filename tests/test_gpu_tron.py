@@ -585,6 +585,8 @@ def test_observe_all_matches_per_player_observe(N, P, B):
                                    # 16 games per workgroup, last workgroup of 16 / 32 / 48 games), incl. the reference's default 19 x 19
                                    (19, 4, 4096 + 16), (19, 3, 1040), (15, 4, 2048 + 48), (39, 4, 528), (9, 6, 784), (5, 2, 96), (21, 7, 400),
                                    (19, 4, 4096 + 5),
+                                   # ... and batches that are not a multiple of 16 games of such boards (the observers' planes off the 16-byte grid)
+                                   (19, 4, 20000 + 9), (15, 3, 1001), (39, 4, 100 + 3), (19, 8, 1024 + 9), (5, 2, 7), (19, 4, 1), (21, 7, 70),
                                    # eight players: the fused kernels relabel by arithmetic (cell values 0..8 do not fit the permute table)
                                    (20, 8, 1024 + 7), (19, 8, 1024), (40, 8, 160)])
 def test_step_observe_fused_matches_three_calls_and_oracle(N, P, B):
