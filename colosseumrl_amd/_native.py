@@ -25,6 +25,7 @@ CRL_ROLLOUT_BITS = 8
 CRL_ROLLOUT_QUAD = 16
 CRL_ROLLOUT_QBITS = 32
 CRL_ROLLOUT_GQUAD = 64
+CRL_ROLLOUT_PAIR = 128
 
 _lib = None
 _lock = threading.Lock()

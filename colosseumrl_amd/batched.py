@@ -36,7 +36,7 @@ def _stream():
 
 _ROLLOUT_KERNEL_FLAGS = {"auto": 0, "bits": _native.CRL_ROLLOUT_BITS, "bytes": _native.CRL_ROLLOUT_BYTES,
                          "global": _native.CRL_ROLLOUT_NO_LDS, "quad": _native.CRL_ROLLOUT_QUAD,
-                         "qbits": _native.CRL_ROLLOUT_QBITS, "gquad": _native.CRL_ROLLOUT_GQUAD}
+                         "qbits": _native.CRL_ROLLOUT_QBITS, "gquad": _native.CRL_ROLLOUT_GQUAD, "pair": _native.CRL_ROLLOUT_PAIR}
 
 
 _STEP_KERNEL_FLAGS = {"auto": 0, "bytes": _native.CRL_STEP_BYTES, "staged": _native.CRL_STEP_STAGED}
@@ -208,7 +208,7 @@ class TronBatch(_Waitable):
 
     # -- T fused random-agent steps with auto-reset
     def rollout(self, steps: int, seed: int = 0, use_lds: bool = True, kernel: str = "auto", events=None):
-        """``kernel``: "auto" (library's choice), "quad" / "qbits" / "bits" / "bytes" (pin one of the LDS kernels), "gquad" / "global"
+        """``kernel``: "auto" (library's choice), "quad" / "pair" / "qbits" / "bits" / "bytes" (pin one of the LDS kernels), "gquad" / "global"
         (boards in global memory: one lane per player / per game);
         ``use_lds=False`` is the older spelling of "global".  All kernels give identical results.
         ``events``: an optional pair (start, stop) of ``torch.cuda.Event(enable_timing=True)`` -- either may be None -- that

@@ -13,12 +13,13 @@
 // heads) and patches same-step interactions in registers, so it costs one round of loads and one
 // round of stores instead of P dependent round trips.
 //
-// Six interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
+// Seven interchangeable rollout kernels (T fused steps, random agent, auto-reset; crl_tron_rollout picks one):
 //   * lane per PLAYER, four lanes per game (at most 4 players; the defaults where they apply): the quad shares what is
 //     per game by DPP (alive count, random stream, reset), the reference's sequential order is resolved only on the
 //     ~1 % of wave-steps where players interact.  64 games per workgroup, 4 waves per SIMD:
 //       - tron_rollout_quad_kernel, LDS byte slabs, boards up to 20x20;
-//       - tron_rollout_qbits_kernel, LDS bitboards + replay epilogue, boards up to 40x40 (default for 21..40);
+//       - tron_rollout_pair_kernel, the same with TWO lanes per game (one or two players);
+//       - tron_rollout_qbits_kernel, LDS bitboards + replay kernel, boards up to 40x40 (default for 21..40);
 //       - tron_rollout_gquad_kernel, boards in global memory, no tags, no copies: no fixed cost per launch (launches too
 //         short to earn the LDS kernels' copies back; boards above 40x40).
 //   * lane per GAME (more than 4 players; or pinned):
@@ -1664,6 +1665,299 @@ tron_rollout_quad_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the stores of this wave have left
 #endif
     QUAD_STAMP(3);
+}
+
+// ---- two lanes per game: the byte-slab kernel for ONE or TWO players (round 5) ---------------------------------------------
+// tron_rollout_quad_kernel gives every game four lanes; a two-player game leaves half of them idle (its launches cost what a
+// four-player game's cost).  Here a wave holds 32 games, two lanes each: same slabs, tags, rolling row rewrite and copy loops, the
+// DPP traffic of a quad reduced to one swap with the neighbour (target against the other head / the other target, alive count,
+// winners), the fix-up on a DPP-gathered pair.  64 games per workgroup of 128 threads (34 KB of LDS at 20x20): four per CU,
+// two waves per SIMD -- a step is then bound by its own dependent chain rather than by issue, and carries twice the games.
+// The random stream (include/colosseum_hip.h): lane q of the pair computes Philox block 2 (c >> 4) + q once per 16 steps, turns
+// it into the block's 8 code bytes, gathers player 0's and player 1's two bits of each (16 bits apiece), and the pair swaps
+// halves: every lane ends up with its own player's 16 actions in one register.
+__device__ __forceinline__ uint32_t tron_pair_actions(const uint32_t gid, const uint32_t group16, const int p, const uint32_t seed_lo,
+                                                      const uint32_t seed_hi, const uint8_t *act_lut)
+{
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    const philox_out r = philox4x32_10<true>(gid, 2u * group16 + (uint32_t)p, 0u, CRL_TAG_TRON, k0, k1);
+    uint32_t code[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t frac, first;
+        crl_mul_wide<true>(81u, r.w[i], frac, first);
+        code[2 * i] = act_lut[first];
+        code[2 * i + 1] = act_lut[__umulhi(frac, 81u)];
+    }
+    const uint32_t w0 = code[0] | code[1] << 8 | code[2] << 16 | code[3] << 24;    // steps 0-3 of my block: a code byte each
+    const uint32_t w1 = code[4] | code[5] << 8 | code[6] << 16 | code[7] << 24;    // steps 4-7
+    auto gather = [](const uint32_t w, const int q) -> uint32_t {      // player q's two bits of four code bytes -> one byte
+        const uint32_t v = (w >> (2 * q)) & 0x03030303u;
+        const uint32_t t = v | (v >> 6);
+        return (t | (t >> 12)) & 0xffu;
+    };
+    const uint32_t mine0 = gather(w0, 0) | gather(w1, 0) << 8;          // player 0's eight actions of my block
+    const uint32_t mine1 = gather(w0, 1) | gather(w1, 1) << 8;          // player 1's
+    // (both swaps run in both lanes, THEN the lane picks: see tron_quad_actions)
+    const uint32_t other0 = (uint32_t)tron_quad<0xB1>((int)mine0), other1 = (uint32_t)tron_quad<0xB1>((int)mine1);
+    // lane 0 holds the even block (steps 0-7 of the group), lane 1 the odd one (steps 8-15)
+    return p == 0 ? (mine0 | other0 << 16) : (other1 | mine1 << 16);
+}
+
+template <int RS>
+__global__ void __launch_bounds__(128, 6)
+tron_rollout_pair_kernel(const crl_tron_cfg cfg, const TronGeom g, const TronPad pad, const int64_t B,
+                         const uint32_t seed_lo, const uint32_t seed_hi, const uint64_t first_env_id, const int T,
+                         int8_t *__restrict__ board, int16_t *__restrict__ heads, int8_t *__restrict__ dirs,
+                         int8_t *__restrict__ deaths, const crl_tron_stats st)
+{
+    constexpr int kGames = 64, kWaveGames = 32;
+    constexpr int kRowDwords = RS / 4;
+    constexpr uint32_t step4 = (uint32_t)((-RS) & 0xff) | (1u << 8) | ((uint32_t)RS << 16) | (0xffu << 24);
+    constexpr int OB = 3;
+    constexpr uint32_t kTags = (1u << (8 - OB)) - 1u;           // the all-ones tag is never used: 0xff stays "wall"
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t act_lut[84];
+    tron_fill_action_lut(act_lut);
+    const int N = g.N, NN = g.NN, P = cfg.P;                    // P <= 2
+    const int lane = threadIdx.x & (CRL_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int p = lane & 1;                                     // my player
+    const int slot = threadIdx.x >> 1;                          // my game's slab in this workgroup
+    const int64_t b = (int64_t)blockIdx.x * kGames + slot;
+    const bool gvalid = b < B;
+    const bool pvalid = gvalid && p < P;
+    const int64_t bb = gvalid ? b : 0;
+    const int64_t env0 = (int64_t)blockIdx.x * kGames + wave * kWaveGames;   // first game of this wave
+    const int n_env = (int)((B - env0) < kWaveGames ? (B - env0 > 0 ? B - env0 : 0) : kWaveGames);
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_u8 *)lds;
+    const int mine = lds0 + slot * pad.stride;
+    const int slab0 = lds0 + wave * kWaveGames * pad.stride;
+    const bool wide = (N & 3) == 0 && N >= 8;
+    const int8_t *gslab_in = board + (n_env > 0 ? env0 : 0) * NN;
+    const int bytes_in = n_env * NN;
+    const int64_t pb = (int64_t)(p < P ? p : 0) * B + bb;
+    const int h_in = heads[pb];
+    const int d_in = dirs[pb];
+    int k = deaths[pb];
+    const int old_ret = st.ret_sum[pb];
+    const uint32_t old_wins = st.win_count[pb];
+    uint32_t tc = st.tcount[bb], ts = st.tstep[bb];
+    const uint32_t old_n_ep = st.n_episodes[bb], old_len_sum = st.len_sum[bb];
+    const uint32_t old_last_w = st.last_winners[bb];
+    k = pvalid ? k : 1;
+    // walls everywhere (each lane half of its game's slab), then the cells
+    for (int off = 4 * p; off < pad.stride; off += 8) *(lds_u32 *)(uintptr_t)(uint32_t)(mine + off) = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wide) {
+#pragma unroll 4
+        for (int off = lane * 16; off < bytes_in; off += CRL_WAVE * 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(gslab_in + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            const int sb = slab0 + e * pad.stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]) = w[q];
+        }
+    } else {
+        for (int i = lane; i < bytes_in; i += CRL_WAVE) {
+            const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
+            const int c = i - e * NN;
+            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+            *(lds_u8 *)(uintptr_t)(uint32_t)(slab0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab_in[i];
+        }
+    }
+    // ---- my player: head as an LDS address, the start layout for resets
+    const int junk = mine + pad.junk + p;
+    int fh = cfg.start_heads[0], fd = cfg.start_dirs[0];
+    fh = (p == 1) ? cfg.start_heads[1] : fh; fd = (p == 1) ? cfg.start_dirs[1] : fd;
+    const int fy = (int)__umulhi((uint32_t)(fh < 0 ? 0 : fh), g.inv_n);
+    const int fresh_h = (p < P) ? mine + (fy + 1) * RS + (fh - fy * N) : junk;
+    const int fresh_d8 = fd << 3;
+    const int fresh_a = (p < P) ? 1 : 0;
+    int h, d8 = (d_in & 3) << 3;
+    {
+        const int hc = min(max(h_in, 0), NN - 1);
+        const int y = (int)__umulhi((uint32_t)hc, g.inv_n);
+        h = pvalid ? mine + (y + 1) * RS + (hc - y * N) : junk;
+    }
+    // my share of a fresh row: three of its six dwords
+    static_assert(kRowDwords == 6, "the row rewrite of the pair kernel shares out six dwords");
+    uint32_t rp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 3 * p + i;
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w |= (4 * j + c < N) ? 0u : (0xffu << (8 * c));
+        rp[i] = w;
+    }
+    int sweep = mine + RS + 12 * p;
+    const int sweep_end = mine + (N + 1) * RS + 12 * p, sweep_first = mine + RS + 12 * p;
+    uint32_t tagbits = 0, stamp = (uint32_t)(p + 1);
+    uint32_t alive_steps = 0, wn = 0, marks = 0;
+    if (!gvalid) k = 1;
+    const uint32_t gid = (uint32_t)(first_env_id + (uint64_t)bb);
+    __syncthreads();                                            // action table; slabs written by other lanes
+    uint32_t acts = tron_pair_actions(gid, tc >> 4, p, seed_lo, seed_hi, act_lut) >> ((tc & 15u) * 2u);
+    uint32_t dry2 = 32u - 2u * (tc & 15u);
+    int neg2 = -(int)dry2;
+    const uint32_t tc_in = tc;
+    int a = (k == 0) ? 1 : 0;
+    for (int t = 0; t < T; ++t) {
+        const bool run = a != 0;
+        const int dir8 = (int)((acts << 3) + (uint32_t)d8);
+        const int tgt = h + __builtin_amdgcn_sbfe((int)step4, dir8, 8);
+        const int tq = run ? tgt : junk;
+        uint32_t raw;
+        CRL_BOUNDS_IN(tq, mine, mine + pad.stride, 143);
+        asm volatile("ds_read_u8 %0, %1" : "=v"(raw) : "v"(tq) : "memory");
+        const int x1 = tq ^ tron_quad<0xB1>(h), y1 = tq ^ tron_quad<0xB1>(tq);
+        uint32_t near = min((uint32_t)x1, (uint32_t)y1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw), "+v"(near) : : "memory");
+        const uint32_t m = min(raw ^ tagbits, raw ^ 0xf8u);
+        const bool dead = run & ((m - 1u) < 7u);
+        const bool moved = run ^ dead;
+        const int h_was = h;
+        k = dead ? (int)m : k;
+        d8 = run ? dir8 : d8;
+        h = moved ? tgt : h;
+        CRL_BOUNDS_IN(h, mine, mine + pad.stride, 144);
+        *(lds_u8 *)(uintptr_t)(uint32_t)h = (uint8_t)stamp;
+        bool alive_now = moved;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(near == 0u) != 0ull, 0)) {
+            if (moved) *(lds_u8 *)(uintptr_t)(uint32_t)tgt = (uint8_t)0;
+            TronRegs<2> s;
+            TronProbe<2> pr;
+            uint32_t stamp2[2];
+            const int h0 = h_was;
+            const int d0 = (run ? (dir8 - (int)(acts << 3)) >> 3 : d8 >> 3) & 3, dir = (dir8 >> 3) & 3, kk = run ? 0 : k;
+            s.h[0] = tron_quad<0xA0>(h0); s.h[1] = tron_quad<0xF5>(h0);
+            s.d[0] = tron_quad<0xA0>(d0); s.d[1] = tron_quad<0xF5>(d0);
+            s.k[0] = tron_quad<0xA0>(kk); s.k[1] = tron_quad<0xF5>(kk);
+            pr.tgt[0] = tron_quad<0xA0>(tgt); pr.tgt[1] = tron_quad<0xF5>(tgt);
+            pr.raw[0] = tron_quad<0xA0>((int)raw); pr.raw[1] = tron_quad<0xF5>((int)raw);
+            pr.ndir[0] = tron_quad<0xA0>(dir); pr.ndir[1] = tron_quad<0xF5>(dir);
+            stamp2[0] = tagbits | 1u; stamp2[1] = tagbits | 2u;
+            LdsBoard<OB> bd{tagbits};
+            bd.within(mine, mine + pad.stride);
+            tron_resolve_lds<2>(bd, s, pr, stamp2, junk);
+            const int hS = p ? s.h[1] : s.h[0], dS = p ? s.d[1] : s.d[0], kS = p ? s.k[1] : s.k[0];
+            h = (p < P) ? hS : junk;
+            d8 = dS << 3;
+            k = kS;
+            alive_now = kS == 0;
+        }
+        a = alive_now ? 1 : 0;
+        const int alive = a + tron_quad<0xB1>(a);
+        alive_steps += (uint32_t)a;
+        neg2 += 2;
+        if (alive <= 1) {                                       // (a game beyond the batch is "over" at every step)
+            tagbits += 1u << OB;
+            tagbits = (tagbits == (kTags << OB)) ? 0u : tagbits;
+            stamp = tagbits | (uint32_t)(p + 1);
+            *(lds_u32 *)(uintptr_t)(uint32_t)sweep = rp[0];
+            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 4) = rp[1];
+            *(lds_u32 *)(uintptr_t)(uint32_t)(sweep + 8) = rp[2];
+            sweep += RS;
+            sweep = (sweep == sweep_end) ? sweep_first : sweep;
+            *(lds_u8 *)(uintptr_t)(uint32_t)fresh_h = (uint8_t)stamp;
+            asm("v_add3_u32 %0, %0, %1, %2" : "+v"(wn) : "v"(a), "s"(0x10000u));
+            asm("v_lshl_add_u32 %0, %0, 16, %1\n\tv_add3_u32 %0, %0, %2, %3" : "+v"(marks) : "v"(dry2), "v"(neg2), "v"(a));
+            h = fresh_h; d8 = fresh_d8;
+            a = fresh_a;
+        }
+        acts >>= 2;
+        if (neg2 == 0) {                                        // a pair shares its step counter: whole pairs take this branch
+            const uint32_t c = tc_in + (dry2 >> 1);             // the step the new actions are for (a multiple of 16)
+            acts = tron_pair_actions(gid, c >> 4, p, seed_lo, seed_hi, act_lut);
+            dry2 += 32u;
+            neg2 = -32;
+        }
+    }
+    const uint32_t n_ep = wn >> 16, wins = wn & 0xffffu;
+    const int done_last = (int)((marks & 0xffffu) >> 1), done_prev = (int)(marks >> 17), last_alive = (int)(marks & 1u);
+    tc = tc_in + (uint32_t)T;
+    const uint32_t ts_at_entry = ts;
+    ts = n_ep ? (uint32_t)(T - done_last) : ts_at_entry + (uint32_t)T;
+    const int last_len = (n_ep > 1u) ? done_last - done_prev : (int)ts_at_entry + done_last;
+    k = a ? 0 : (k == 7 ? p + 1 : k);
+    const int d = (d8 >> 3) & 3;
+    // ---- epilogue: the junk dword hands this board's tag to its copier, boards LDS -> HBM without tags
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (p == 0) *(lds_u8 *)(uintptr_t)(uint32_t)(mine + pad.junk) = (uint8_t)(tagbits >> OB);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr uint32_t OM = 0x01010101u * ((1u << OB) - 1u);
+    constexpr uint32_t TM = 0x01010101u * ((1u << (8 - OB)) - 1u);
+    int8_t *gslab = board + env0 * NN;
+    if (wide) {
+        const int bytes = n_env * NN;
+#pragma unroll 4
+        for (int off = lane * 16; off < bytes; off += CRL_WAVE * 16) {
+            const int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
+            int o[4];
+            tron_piece_offsets<RS>((off - e * NN) >> 2, N >> 2, pad.inv_nq, o);
+            const int sb = slab0 + e * pad.stride;
+            const uint32_t trep = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk) * 0x01010101u;
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t c4 = *(const lds_u32 *)(uintptr_t)(uint32_t)(sb + o[q]);
+                const uint32_t diff = ((c4 >> OB) & TM) ^ trep;
+                const uint32_t stale = ((diff + 0x7f7f7f7fu) >> 7) & 0x01010101u;
+                w[q] = c4 & OM & ~(stale * 0xffu);
+            }
+            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (int i = lane; i < n_env * NN; i += CRL_WAVE) {
+            const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
+            const int c = i - e * NN;
+            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+            const int sb = slab0 + e * pad.stride;
+            const uint32_t tb = (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)(sb + pad.junk) << OB;
+            const uint32_t rawc = *(const lds_u8 *)(uintptr_t)(uint32_t)(sb + (y + 1) * RS + (c - y * N));
+            gslab[i] = (int8_t)((((rawc ^ tb) >> OB) == 0) ? (rawc & ((1u << OB) - 1u)) : 0u);
+        }
+    }
+    // ---- per-player state and statistics (my columns), per-game statistics (lane 0 of the pair)
+    int lw = (last_alive & 1) << p;
+    lw |= tron_quad<0xB1>(lw);
+    const int ret = 2 * (int)alive_steps - T + 9 * (int)wins;
+    int32_t *row = st.results ? st.results + b * (3 + 2 * P) : nullptr;
+    uint16_t *pk = st.packed ? st.packed + b * ((4 + P + 1) & ~1) : nullptr;
+    if (pvalid) {
+        const int rel = h - mine;
+        const int rowi = rel / RS;
+        heads[p * B + b] = (int16_t)((rowi - 1) * N + (rel - rowi * RS));
+        dirs[p * B + b] = (int8_t)d;
+        deaths[p * B + b] = (int8_t)k;
+        const int rs = old_ret + ret;
+        const uint32_t wc = old_wins + wins;
+        st.ret_sum[p * B + b] = rs;
+        st.win_count[p * B + b] = wc;
+        if (row) { row[3 + p] = (int32_t)wc; row[3 + P + p] = rs; }
+        if (pk) pk[4 + p] = (uint16_t)rs;
+    }
+    if (gvalid && p == 0) {
+        const uint32_t ne = old_n_ep + n_ep, ls = old_len_sum + (ts_at_entry + (uint32_t)T - ts);
+        st.tcount[b] = tc;
+        st.tstep[b] = ts;
+        st.n_episodes[b] = ne;
+        st.len_sum[b] = ls;
+        if (n_ep > 0) {
+            st.last_winners[b] = (uint8_t)lw;
+            st.last_len[b] = (uint16_t)last_len;
+        }
+        if (row) { row[0] = (int32_t)ne; row[1] = (int32_t)ls; row[2] = n_ep > 0 ? lw : (int32_t)old_last_w; }
+        if (pk) { pk[0] = (uint16_t)ne; pk[1] = (uint16_t)ls; pk[2] = (uint16_t)(n_ep > 0 ? (uint32_t)lw : old_last_w); pk[3] = (uint16_t)ts; }
+    }
 }
 
 // ---- one lane per player on boards in GLOBAL memory (any board size, P <= 4) --------------------------------------
@@ -4359,7 +4653,7 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     CRL_REQUIRE(st.tcount && st.tstep && st.n_episodes && st.win_count && st.len_sum && st.ret_sum &&
                 st.last_winners && st.last_len, "crl_tron_rollout: NULL stats pointer");
     CRL_REQUIRE(T >= 0 && T <= (1 << 24), "crl_tron_rollout: T=%d out of range", T);
-    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS | CRL_ROLLOUT_GQUAD)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
+    CRL_REQUIRE((flags & ~(CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS | CRL_ROLLOUT_GQUAD | CRL_ROLLOUT_PAIR)) == 0, "crl_tron_rollout: unknown flags 0x%x", flags);
     const crl_tron_cfg &cfg = ctx->tron;
     const int NN = cfg.N * cfg.N;
     CRL_REQUIRE((NN % 16 != 0) || (((uintptr_t)board & 15) == 0), "crl_tron_rollout: board must be 16-byte aligned");
@@ -4381,7 +4675,10 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     //    64 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a finished
     //    board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch.
     // More than four players: the lane-per-game kernels.
-    const bool no_pin = !(flags & (CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS));
+    const bool no_pin = !(flags & (CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS | CRL_ROLLOUT_PAIR));
+    // (65,536 games of two players, 2048 steps: 499 against 632 us at 20x20, 508 against 642 at 13x13; the pair kernel copies
+    //  boards whose rows are not whole dwords byte by byte, which a launch of 256 steps earns back: profiles/r5_shape_sweep.txt)
+    const int kPairMinT = ((cfg.N & 3) == 0 && cfg.N >= 8) ? 32 : 256;
     const bool lds_fit = cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
     const bool wide_rows = (cfg.N & 3) == 0;
     const bool gquad_pays = small ? T == 1
@@ -4454,6 +4751,18 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
                                (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, tt, board, heads, dirs, deaths, st);
                 }
             });
+            CRL_LAUNCH_CHECK();
+        }
+        return CRL_OK;
+    }
+    // one or two players: two lanes per game (tron_rollout_pair_kernel) once the launch is long enough for its plainer copies
+    const bool use_pair = quad_ok && cfg.P <= 2 && use_quad && ((flags & CRL_ROLLOUT_PAIR) || (no_pin && T >= kPairMinT));
+    if (use_pair) {
+        constexpr int kQuadMaxT = 16383;
+        for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
+            launch(tron_rollout_pair_kernel<kRowBytesSmall>, dim3(blocks_for(B, 64)), dim3(128), (size_t)64 * pad.stride,
+                   t0 + kQuadMaxT >= T, cfg, g, pad, B, (uint32_t)seed, (uint32_t)(seed >> 32), first_env_id, std::min(kQuadMaxT, T - t0),
+                   board, heads, dirs, deaths, st);
             CRL_LAUNCH_CHECK();
         }
         return CRL_OK;

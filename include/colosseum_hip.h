@@ -62,6 +62,8 @@ extern "C" {
                                  * stay in global memory: the kernel's fixed cost is worth that many steps there); with more
                                  * than 4 players the flag is ignored */
 
+#define CRL_ROLLOUT_PAIR  128u  /* the byte-slab kernel with TWO lanes per game (boards up to 20x20, one or two players; elsewhere the
+                                 * flag is ignored): the default there for launches of 32 steps and more (256 where a row is not whole dwords) */
 #define CRL_ROLLOUT_GQUAD  64u  /* one lane per player on boards in GLOBAL memory (any board size, at most 4 players; with more
                                  * the flag is ignored): the default wherever the boards are not played out of LDS */
 

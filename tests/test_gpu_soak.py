@@ -15,7 +15,8 @@ from oracle import oracle as O
                                             (12, 8, 512, 1500, "bits"), (12, 8, 512, 1500, "bytes"), (23, 4, 512, 1200, "auto"),
                                             (16, 5, 700, 1200, "bytes"), (40, 4, 1000, 900, "bits"), (40, 4, 1000, 900, "bytes"),
                                             (36, 8, 300, 700, "bits"), (36, 8, 300, 700, "bytes"), (40, 4, 512, 600, "global"), (40, 4, 1000, 900, "gquad"), (20, 4, 4096, 1500, "gquad"), (13, 3, 1024 + 9, 1200, "gquad"), (6, 2, 512, 3000, "gquad"),
-                                            (50, 4, 300, 700, "gquad"), (45, 2, 130, 17000, "gquad"), (19, 1, 200, 500, "gquad"),
+                                            (50, 4, 300, 700, "gquad"), (45, 2, 130, 17000, "gquad"), (19, 1, 200, 500, "gquad"), (20, 2, 4096, 1500, "pair"), (13, 2, 1024 + 9, 1200, "pair"), (6, 2, 512, 3000, "pair"), (19, 1, 300, 900, "pair"),
+                                            (9, 2, 130, 40001, "pair"), (16, 2, 777, 2000, "pair"),
                                             (40, 4, 1000, 900, "qbits"), (30, 3, 1024 + 7, 800, "qbits"), (20, 4, 4096, 1500, "qbits"),
                                             (6, 2, 512, 3000, "qbits"), (13, 3, 1024 + 9, 1200, "qbits"), (33, 2, 130, 20000, "qbits"),
                                             (9, 3, 130, 40001, "quad")])      # (> 16,383 steps: the lane-per-player kernels split the launch)
@@ -56,7 +57,7 @@ def test_tron_random_configurations_all_kernels():
         O.tron_reset(ost, sh, sd)
         for T in chunks:
             O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=16)
-        for kernel in ("auto", "quad", "qbits", "bytes", "bits", "global", "gquad"):
+        for kernel in ("auto", "quad", "pair", "qbits", "bytes", "bits", "global", "gquad"):
             tb = TronBatch(N, P, B, first_env_id=first)
             for T in chunks:
                 tb.rollout(T, seed, kernel=kernel)

@@ -288,7 +288,7 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
     return ost
 
 
-@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global", "gquad", "auto"])
+@pytest.mark.parametrize("kernel", ["quad", "pair", "qbits", "bits", "bytes", "global", "gquad", "auto"])
 @pytest.mark.parametrize("N,P,B,chunks", [(20, 4, 8192 + 5, (64, 1, 31)), (20, 3, 1000 + 3, (40, 9)), (12, 2, 321, (60,)), (16, 4, 64 * 5 + 1, (25, 25)), (40, 4, 2048, (100,)), (19, 5, 1000, (50, 3, 47)),
                                            (9, 8, 640, (40,)), (25, 2, 300, (7, 9, 30)), (24, 6, 129, (33,)),
                                            (8, 4, 320, (700,)), (7, 8, 200, (400, 100)), (11, 3, 100, (900,)),
@@ -305,7 +305,7 @@ def test_rollout_vs_oracle(N, P, B, chunks, kernel):
     assert ost.n_episodes.sum() > B
 
 
-@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global", "gquad"])
+@pytest.mark.parametrize("kernel", ["quad", "pair", "qbits", "bits", "bytes", "global", "gquad"])
 def test_rollout_after_scripted_steps(kernel):
     """A rollout continues from whatever state the step API left (mid-episode, some players dead, histories that no
     RNG stream produced): the bitboard kernel must resume from the incoming board, not from the episode start."""
@@ -330,7 +330,7 @@ def test_rollout_after_scripted_steps(kernel):
             assert np.array_equal(getattr(hip.tb, k).cpu().numpy().view(want.dtype), want), (k, T)
 
 
-@pytest.mark.parametrize("kernel", ["quad", "qbits", "bits", "bytes", "global", "gquad"])
+@pytest.mark.parametrize("kernel", ["quad", "pair", "qbits", "bits", "bytes", "global", "gquad"])
 @pytest.mark.parametrize("N,P,B", [(20, 4, 1000), (33, 3, 300), (12, 7, 257)])
 def test_rollout_with_step_counters_that_differ_inside_a_wave(N, P, B, kernel):
     """Games of one batch (and of one wave) may stand at different step counters -- states assembled from several sources.

@@ -3,7 +3,7 @@
 kernels?  Prints, per (N, P, B), microseconds per call (median of back-to-back launches) and nanoseconds per game for the
 20-step rollout, a 512-step rollout (per step), step, step_observe, observe_all, observe, ranking and reset.
     python tools/debug/shape_sweep.py [N,N,...] [P,P,...] [B,B,...] [json path]
-    python tools/debug/shape_sweep.py kernels [N,N,...] [T,T,...] [B]
+    python tools/debug/shape_sweep.py kernels [N,N,...] [T,T,...] [B [P]]
     python tools/debug/shape_sweep.py others [quick]
 `kernels`: the interchangeable rollout kernels ("auto" = the library's choice, "qbits", "bits", "bytes", "global", "gquad") against the
 launch length at P = 4 -- where the fixed cost of an LDS-resident launch (copy in, replay, copy out) is worth it.
@@ -72,9 +72,11 @@ if arg and arg[0] == "kernels":
     Ns = [int(x) for x in (arg[1] if len(arg) > 1 else "20,21,24,28,32,39,40").split(",")]
     Ts = [int(x) for x in (arg[2] if len(arg) > 2 else "1,4,20,64,256").split(",")]
     Bk = int(arg[3]) if len(arg) > 3 else 65536
+    Pk = int(arg[4]) if len(arg) > 4 else 4
+    KERNS = ("auto", "quad", "pair", "qbits", "bits", "bytes", "global", "gquad") if Pk <= 2 else ("auto", "qbits", "bits", "bytes", "global", "gquad")
     for N in Ns:
-        st = TronBatch(N, 4, Bk, device=dev)
-        for kern in ("auto", "qbits", "bits", "bytes", "global", "gquad"):
+        st = TronBatch(N, Pk, Bk, device=dev)
+        for kern in KERNS:
             row = []
             for T in Ts:
                 for _ in range(2):

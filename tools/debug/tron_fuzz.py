@@ -35,7 +35,7 @@ for case in range(n_cases):
     O.tron_reset(ost, sh, sd)
     for T in chunks:
         O.tron_rollout(ost, seed, first, T, sh, sd, n_threads=16)
-    for kernel in ("auto", "quad", "qbits", "bytes", "bits", "global", "gquad"):
+    for kernel in ("auto", "quad", "pair", "qbits", "bytes", "bits", "global", "gquad"):
         tb = TronBatch(N, P, B, first_env_id=first)
         for T in chunks:
             tb.rollout(T, seed, kernel=kernel)
