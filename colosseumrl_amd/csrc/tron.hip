@@ -4756,7 +4756,10 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
         return CRL_OK;
     }
     // one or two players: two lanes per game (tron_rollout_pair_kernel) once the launch is long enough for its plainer copies
-    const bool use_pair = quad_ok && cfg.P <= 2 && use_quad && ((flags & CRL_ROLLOUT_PAIR) || (no_pin && T >= kPairMinT));
+    // (its slabs leave a SIMD two waves at 20x20, three from 15x15 down: with two it wins while the quad kernel's waves do not
+    //  fill the chip either -- up to ~100,000 games -- and ties beyond: 262,144 games of 20x20, 512 steps: 607 against 583 us)
+    const bool pair_pays = (size_t)pad.stride * 64 * 6 <= (size_t)160 * 1024 || B <= 98304;
+    const bool use_pair = quad_ok && cfg.P <= 2 && use_quad && ((flags & CRL_ROLLOUT_PAIR) || (no_pin && T >= kPairMinT && pair_pays));
     if (use_pair) {
         constexpr int kQuadMaxT = 16383;
         for (int t0 = 0; t0 < T; t0 += kQuadMaxT) {
