@@ -291,3 +291,39 @@ def test_shipped_build_compiles_no_bounds_asserts():
     assert rep["compiled"] == (os.environ.get("CRL_EXPECT_BOUNDS_BUILD") == "1")
     if not rep["compiled"]:
         assert all(v == 0 for k in ("tron", "ttt", "blokus") for v in rep[k].values())
+
+
+@pytest.mark.parametrize("N,P,B,shift", [(19, 4, 300, 1), (19, 4, 4096, 7), (5, 2, 70, 12), (21, 3, 129, 3), (41, 4, 65, 9), (15, 8, 100, 5)])
+def test_boards_at_any_byte_alignment(N, P, B, shift):
+    """Boards that are not whole 16-byte chunks may lie at ANY address (the header asks for 16-byte alignment only where
+    N * N % 16 == 0): every call then takes its byte / one-game-per-workgroup / global-memory kernel.  A batch whose board
+    buffer starts `shift` bytes off the grid must do what an aligned twin does: reset, step, sampled step_observe, rollouts on
+    every kernel choice that accepts it, observe, observe_all, ranking."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    NN = N * N
+    a, b = TronBatch(N, P, B, first_env_id=5), TronBatch(N, P, B, first_env_id=5)
+    raw = torch.zeros(B * NN + 32, dtype=torch.int8, device="cuda")
+    base = (-raw.data_ptr()) % 16 + shift                         # `shift` bytes behind a 16-byte boundary
+    b.board = raw[base:base + B * NN].view(B, NN)
+    assert b.board.data_ptr() % 16 == shift % 16 and b.board.is_contiguous()
+    b.reset()
+    out_a = out_b = None
+    rng = np.random.default_rng(N + shift)
+    for t in range(6):
+        act = torch.from_numpy(rng.integers(-1, 2, size=(P, B)).astype(np.int8)).cuda()
+        a.step(act, auto_reset=True); b.step(act, auto_reset=True)
+        out_a, out_b = a.step_observe(None, 3, True, out_a), b.step_observe(None, 3, True, out_b)
+        assert torch.equal(out_a["board"], out_b["board"]) and torch.equal(out_a["heads"], out_b["heads"]), t
+    for T, kernel in ((1, "auto"), (9, "auto"), (70, "auto"), (300, "auto"), (40, "gquad"), (40, "global"), (40, "qbits"), (40, "bytes")):
+        a.rollout(T, 11, kernel=kernel); b.rollout(T, 11, kernel=kernel)
+        for k in ("board", "heads", "dirs", "deaths", "tcount", "n_episodes", "ret_sum"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (T, kernel, k)
+    who = (torch.arange(B, device="cuda") % P).to(torch.int8)
+    oa, ob = a.observe(who), b.observe(who)
+    assert torch.equal(oa["board"], ob["board"]) and torch.equal(a.ranking(), b.ranking())
+    assert torch.equal(a.observe_all()["board"], b.observe_all()["board"])
+    mask = (torch.arange(B, device="cuda") % 3 == 0).to(torch.uint8)
+    a.reset(mask); b.reset(mask)
+    assert torch.equal(a.board, b.board) and torch.equal(a.heads, b.heads)
+    assert int(raw[:base].abs().sum()) == 0 and int(raw[base + B * NN:].abs().sum()) == 0      # nothing written outside the boards
