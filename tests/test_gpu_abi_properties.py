@@ -39,6 +39,30 @@ def test_calls_are_graph_capturable():
     assert torch.equal(oa["board"], ob["board"]) and torch.equal(a.results(), b.results())
 
 
+@pytest.mark.parametrize("N,P,T,kernel", [(40, 4, 64, "auto"), (40, 4, 8, "auto"), (20, 2, 64, "auto"), (20, 4, 1, "auto"), (12, 6, 50, "auto"),
+                                         (45, 3, 30, "auto"), (33, 4, 300, "bits"), (20, 4, 16383 + 9, "auto")])
+def test_every_rollout_kernel_is_graph_capturable(N, P, T, kernel):
+    """The rollout kernels the first test does not reach -- the bitboard kernel with its replay kernel behind it (two launches),
+    the lane-per-player kernel in global memory, the two-lanes-per-game kernel, the lane-per-game kernels, a split launch --
+    record into a HIP graph and replay to what eager calls give."""
+    import torch
+    from colosseumrl_amd.batched import TronBatch
+    a, b = TronBatch(N, P, 2048 + 3), TronBatch(N, P, 2048 + 3)
+    for tb in (a, b):                       # warm-up outside capture (one-time kernel attribute opt-in happens here)
+        tb.rollout(T, 2, kernel=kernel)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a.rollout(T, 2, kernel=kernel)
+    for _ in range(3):
+        g.replay()
+        b.rollout(T, 2, kernel=kernel)
+    torch.cuda.synchronize()
+    for k in ("board", "heads", "dirs", "deaths", "tcount", "tstep", "n_episodes", "ret_sum", "win_count"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert torch.equal(a.results(copy=False), b.results(copy=False))
+
+
 def test_side_stream_ordering():
     """Launches go to torch's CURRENT stream: work issued on a side stream is ordered on that stream."""
     import torch
