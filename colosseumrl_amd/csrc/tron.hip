@@ -4670,7 +4670,7 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     // So, unless a kernel is pinned, it takes (profiles/r5_shape_sweep.txt, `kernels`):
     //  * a ONE-step launch on boards up to 20x20 (11 us against the byte-slab kernel's 13-16);
     //  * short launches on boards 21..40 wide, where the bitboard kernel's copy in + replay kernel is 45-90 us (70-170 us on
-    //    boards that are not whole dwords a row): up to 20 steps (32 on the latter);
+    //    boards that are not whole dwords a row): up to 18 steps (32 on the latter);
     //  * boards above 40x40, which nothing else plays out of LDS: always up to 44x44, up to 200 steps up to 56x56 and up to
     //    64 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a finished
     //    board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch.
@@ -4682,7 +4682,7 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const bool lds_fit = cfg.N <= kLdsMaxNLarge && (((uintptr_t)board & 15) == 0);
     const bool wide_rows = (cfg.N & 3) == 0;
     const bool gquad_pays = small ? T == 1
-                          : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 20 : 32)
+                          : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 18 : 32)
                           : (cfg.N <= 44 || T <= (cfg.N <= 56 ? 200 : 64));
     const bool use_gquad = cfg.P <= 4 && ((flags & CRL_ROLLOUT_GQUAD) || (no_pin && (gquad_pays || (!lds_fit && cfg.N <= kLdsMaxNLarge))));
     const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !use_gquad && lds_fit;

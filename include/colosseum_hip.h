@@ -58,7 +58,7 @@ extern "C" {
 #define CRL_ROLLOUT_QUAD   16u  /* the lane-per-player kernel (four lanes per game): boards up to 20x20 with at most 4 players.
                                  * It is the default there; elsewhere the flag is ignored */
 #define CRL_ROLLOUT_QBITS  32u  /* the lane-per-player bitboard kernel with replay epilogue (at most 4 players, boards up to
-                                 * 40x40): the default for boards 21..40 wide in launches of more than 20 steps (shorter ones
+                                 * 40x40): the default for boards 21..40 wide in launches of more than 18 steps (shorter ones
                                  * stay in global memory: the kernel's fixed cost is worth that many steps there); with more
                                  * than 4 players the flag is ignored */
 
@@ -192,7 +192,7 @@ typedef struct {
  * byte-per-cell slab (one lane per player when P <= 4, else one lane per game), larger ones on an occupancy bitboard
  * (one lane per player when P <= 4; else one lane per game and T >= 256) whose unfinished episode is replayed with
  * owners at the end of the launch (P <= 4: by a second kernel queued behind the first).  Boards above 40x40 stay in global memory -- and so do, with P <= 4, launches too short
- * to earn an LDS kernel's copies back (one step on boards up to 20x20, up to 20 steps on boards 21..40 wide, 32 where a row
+ * to earn an LDS kernel's copies back (one step on boards up to 20x20, up to 18 steps on boards 21..40 wide, 32 where a row
  * is not whole dwords): one lane per player (CRL_ROLLOUT_GQUAD; no fixed cost per launch) or one lane per game
  * (CRL_ROLLOUT_NO_LDS; episode tags, one pass over the boards per launch: P > 4, and long launches on boards above 44x44).
  * CRL_ROLLOUT_BYTES / _BITS /
