@@ -4695,9 +4695,12 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     //  * a ONE-step launch on boards up to 20x20 (11 us against the byte-slab kernel's 13-16);
     //  * short launches on boards 21..40 wide, where the bitboard kernel's copy in + replay kernel is 45-90 us (70-170 us on
     //    boards that are not whole dwords a row): up to 18 steps (32 on the latter);
-    //  * boards above 40x40, which nothing else plays out of LDS: always up to 44x44, up to 200 steps up to 56x56 and up to
-    //    64 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a finished
-    //    board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch.
+    //  * boards above 40x40, which nothing else plays out of LDS: with four players always up to 44x44, up to 200 steps up to
+    //    56x56 and up to 48 steps above -- beyond that the lane-per-game global kernel, whose episode tags save the rewrite of a
+    //    finished board (N * N bytes per reset) at the price of a pass over all boards at the end of the launch, and whose step
+    //    gets cheaper with fewer players (a lane per game probes P cells; a lane per player idles, and shorter episodes mean
+    //    more rewrites): three players up to 56 / 24 steps, one or two up to 24 / 14 (41x41, 65,536 two-player games: 2.7 us
+    //    per step against this kernel's 6.8).
     // More than four players: the lane-per-game kernels.
     const bool no_pin = !(flags & (CRL_ROLLOUT_NO_LDS | CRL_ROLLOUT_BYTES | CRL_ROLLOUT_BITS | CRL_ROLLOUT_QUAD | CRL_ROLLOUT_QBITS | CRL_ROLLOUT_PAIR));
     // (65,536 games of two players, 2048 steps: 499 against 632 us at 20x20, 508 against 642 at 13x13; the pair kernel copies
@@ -4707,7 +4710,9 @@ static int tron_rollout_impl(const crl_ctx *ctx, int64_t B, uint64_t seed, uint6
     const bool wide_rows = (cfg.N & 3) == 0;
     const bool gquad_pays = small ? T == 1
                           : cfg.N <= kLdsMaxNLarge ? T <= (wide_rows ? 18 : 32)
-                          : (cfg.N <= 44 || T <= (cfg.N <= 56 ? 200 : 64));
+                          : cfg.P == 4 ? (cfg.N <= 44 || T <= (cfg.N <= 56 ? 200 : 48))
+                          : cfg.P == 3 ? T <= (cfg.N <= 56 ? 56 : 24)
+                                       : T <= (cfg.N <= 56 ? 24 : 14);
     const bool use_gquad = cfg.P <= 4 && ((flags & CRL_ROLLOUT_GQUAD) || (no_pin && (gquad_pays || (!lds_fit && cfg.N <= kLdsMaxNLarge))));
     const bool lds_ok = !(flags & CRL_ROLLOUT_NO_LDS) && !use_gquad && lds_fit;
     if (use_gquad) {

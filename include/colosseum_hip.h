@@ -194,7 +194,8 @@ typedef struct {
  * owners at the end of the launch (P <= 4: by a second kernel queued behind the first).  Boards above 40x40 stay in global memory -- and so do, with P <= 4, launches too short
  * to earn an LDS kernel's copies back (one step on boards up to 20x20, up to 18 steps on boards 21..40 wide, 32 where a row
  * is not whole dwords): one lane per player (CRL_ROLLOUT_GQUAD; no fixed cost per launch) or one lane per game
- * (CRL_ROLLOUT_NO_LDS; episode tags, one pass over the boards per launch: P > 4, and long launches on boards above 44x44).
+ * (CRL_ROLLOUT_NO_LDS; episode tags, one pass over the boards per launch: P > 4, and launches on boards above 40x40 that are
+ * long enough to earn that pass back -- from 15..57 steps on with one to three players, from 49..201 with four above 44x44).
  * CRL_ROLLOUT_BYTES / _BITS /
  * _QUAD / _QBITS pin one of the LDS kernels.  All give identical results.  The LDS kernels rely on the invariant of every state
  * produced by crl_tron_reset / crl_tron_step / crl_tron_rollout: board[heads[p]] == p + 1 for every player; callers
