@@ -295,10 +295,11 @@ def _rollout_pair(N, P, B, chunks, seed, first, kernel="auto"):
                                            (20, 4, 1000, (300, 2, 260)), (40, 4, 700, (1, 1, 290)), (37, 7, 130, (280,)),
                                            (4, 2, 200, (50,)), (4, 4, 70, (20,)), (4, 3, 130, (30,)), (5, 4, 100, (40,))])
 def test_rollout_vs_oracle(N, P, B, chunks, kernel):
-    """Fused random-agent rollout == oracle rollout, bit for bit, for the five kernels behind crl_tron_rollout (lane per
-    player on byte slabs "quad" / on bitboards with replay "qbits" -- where they do not apply, P > 4 or for quad boards
-    above 20x20, the flag falls through to the library's choice -- lane-per-game LDS bitboard with replay epilogue, LDS
-    byte slabs, global memory) and the library's own choice: ragged batches, odd
+    """Fused random-agent rollout == oracle rollout, bit for bit, for the seven kernels behind crl_tron_rollout (lane per
+    player on byte slabs "quad" / two lanes per game "pair" / on bitboards with a replay kernel "qbits" / in global memory
+    "gquad" -- where they do not apply, P > 4 (P > 2) or for quad boards above 20x20, the flag falls through to the
+    library's choice -- lane-per-game LDS bitboard with replay epilogue, LDS byte slabs, global memory) and the library's
+    own choice: ragged batches, odd
     boards (byte copy path), split launches (state and RNG position carry over; a 1-step launch makes the bitboard
     kernel replay from the incoming state), and launches long enough to wrap the byte kernel's episode tags."""
     ost = _rollout_pair(N, P, B, chunks, seed=0xC0FFEE12345, first=123456, kernel=kernel)
