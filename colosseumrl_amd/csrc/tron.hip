@@ -2232,35 +2232,13 @@ __device__ __forceinline__ void tron_replay_copy_in(const int8_t *__restrict__ g
             }
         }
     } else {
-        // rows that are not whole dwords: the boards come in as aligned 16-byte chunks of the games' one run of bytes where its
-        // start allows, and a chunk is dealt out cell by cell (a row ends, a game ends inside it) -- byte by byte a wave made
-        // 380 dependent loads for its 16 boards at 39x39, and every wave with ONE game that was not reset pays for them
-        const int cells = n_games * NN;
-        const int full = (N >= 2 && (((uintptr_t)gslab & 15) == 0)) ? cells & ~15 : 0;
-#pragma unroll 2
-        for (int off = lane * 16; off < full; off += CRL_WAVE * 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(gslab + off);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-            const int r = off - e * NN;
-            int y = (int)__umulhi((uint32_t)r, g.inv_n), x = r - y * N;
-            int a = lds0 + e * pad.stride + (y + 1) * RS + x;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                *(lds_u8 *)(uintptr_t)(uint32_t)a = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                ++x; ++a;
-                if (x == N) {
-                    x = 0; ++y; a += RS - N;
-                    if (y == N) { y = 0; ++e; a = lds0 + e * pad.stride + RS; }
-                }
+        // (rows that are not whole dwords: cell by cell; aligned 16-byte chunks dealt out cell by cell were tried in round 5 and
+        //  change nothing measurable -- this copy runs only in waves that hold a game the launch did not reset)
+        for (int e = 0; e < n_games; ++e)
+            for (int c = lane; c < NN; c += CRL_WAVE) {
+                const int y = (int)__umulhi((uint32_t)c, g.inv_n);
+                *(lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[(int64_t)e * NN + c];
             }
-        }
-        for (int i = full + lane; i < cells; i += CRL_WAVE) {
-            const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
-            const int c = i - e * NN;
-            const int y = (int)__umulhi((uint32_t)c, g.inv_n);
-            *(lds_u8 *)(uintptr_t)(uint32_t)(lds0 + e * pad.stride + (y + 1) * RS + (c - y * N)) = (uint8_t)gslab[i];
-        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2359,28 +2337,11 @@ __device__ __forceinline__ void tron_replay_copy_out(int8_t *__restrict__ gslab,
             *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
-        // rows that are not whole dwords: the games' boards are still one run of bytes, and it leaves in aligned 16-byte chunks
-        // where its start allows (a chunk is gathered cell by cell out of the slabs: a row ends, a game ends inside it) -- a
-        // byte per lane and store made the copy back 380 store instructions per wave at 39x39, 64 bytes each
+        // rows that are not whole dwords: a cell per thread and store.  (Gathering 16 cells per aligned 16-byte store was tried
+        // in round 5 and is SLOWER here -- 39x39 at T = 64: 163 against 145 us, 30x30: 111 against 100: sixteen LDS byte reads with
+        // their row / game carries per chunk cost a wave more than the byte stores they save.)
         const int cells = n_games * NN;
-        const int full = (N >= 2 && (((uintptr_t)gslab & 15) == 0)) ? cells & ~15 : 0;
-        for (int off = tid * 16; off < full; off += nthreads * 16) {
-            int e = (int)__umulhi((uint32_t)off, pad.inv_nn);
-            const int r = off - e * NN;
-            int y = (int)__umulhi((uint32_t)r, g.inv_n), x = r - y * N;
-            int a = lds0 + e * pad.stride + (y + 1) * RS + x;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                w[k >> 2] |= (uint32_t)*(const lds_u8 *)(uintptr_t)(uint32_t)a << (8 * (k & 3));
-                ++x; ++a;
-                if (x == N) {                                   // next row; behind the last one, the next game's first
-                    x = 0; ++y; a += RS - N;
-                    if (y == N) { y = 0; ++e; a = lds0 + e * pad.stride + RS; }
-                }
-            }
-            *reinterpret_cast<uint4 *>(gslab + off) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
+        const int full = 0;
         for (int i = full + tid; i < cells; i += nthreads) {
             const int e = (int)__umulhi((uint32_t)i, pad.inv_nn);
             const int c = i - e * NN;
